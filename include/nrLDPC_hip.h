@@ -1,0 +1,153 @@
+/*
+ * nrLDPC_hip.h -- C ABI of libldpc_hip.so, the MI355X (gfx950) drop-in for OAI's NR LDPC coding library.
+ *
+ * Part 1 is the reference's own plugin ABI: the four symbols load_LDPClib() resolves from
+ * "libldpc<version>.so" (reference openair1/PHY/CODING/nrLDPC_load.c:45-75, nrLDPC_extern.h:27-45) with
+ * the reference's parameter structures restated field for field, so that `ldpctest -v _hip`,
+ * `nr_ulsim --loader.ldpc.shlibversion _hip` or the gNB softmodem can load this library unchanged.
+ * A translation unit that already includes the reference's nrLDPC_defs.h must define
+ * NRLDPC_HIP_NO_REFERENCE_TYPES before including this header.
+ *
+ * Part 2 adds batched entry points (many code blocks per call, device- or host-resident buffers, caller
+ * stream) -- the form in which a GPU is actually fed -- plus the TB-level helpers around the codec.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions are thread safe.
+ */
+#ifndef NRLDPC_HIP_H
+#define NRLDPC_HIP_H
+#include <stdint.h>
+#include <stdbool.h>
+#include <pthread.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================================================
+ * Part 1 -- reference plugin ABI
+ * =================================================================================================== */
+#ifndef NRLDPC_HIP_NO_REFERENCE_TYPES
+
+/* nrLDPC_decoder/nrLDPC_types.h:75-79 */
+typedef enum nrLDPC_outMode {
+  nrLDPC_outMode_BIT,     /* 32 bits per uint32_t output, MSB-first inside each byte */
+  nrLDPC_outMode_BITINT8, /* 1 bit per int8_t output */
+  nrLDPC_outMode_LLRINT8  /* reference quirk: delivers the BITINT8 result at this revision (decoder.c:866-877) */
+} e_nrLDPC_outMode;
+
+/* nrLDPC_decoder/nrLDPC_types.h:84-97 */
+typedef struct nrLDPC_dec_params {
+  uint8_t BG;         /* base graph 1 / 2 */
+  uint16_t Z;         /* lifting size */
+  uint8_t R;          /* decoder rate mode: 13, 23, 89 (BG1) / 15, 13, 23 (BG2) */
+  uint16_t F;         /* filler bits (offload back ends only) */
+  uint8_t Qm;         /* modulation (offload back ends only) */
+  uint8_t rv;         /* (offload back ends only) */
+  uint8_t numMaxIter; /* iteration cap; up to numMaxIter+1 CN/BN passes run (decoder.c:552-558) */
+  int E;              /* number of leading output bits covered by the CRC check */
+  e_nrLDPC_outMode outMode;
+  int crc_type;       /* CRC24_A 0, CRC24_B 1, CRC16 2, CRC8 3 (coding_defs.h:33-36) */
+  /* NULL: stop on parity check.  Non-NULL: stop on CRC.  The reference calls this pointer on the host
+   * after every pass >= 3; this library evaluates the same CRC (crc_byte.c:314-380 check_crc) on the GPU
+   * from crc_type/E and never calls the pointer. */
+  int (*check_crc)(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type);
+  uint8_t setCombIn;
+} t_nrLDPC_dec_params;
+
+/* nrLDPC_decoder/nrLDPC_types.h:115-127 -- 11 x time_stats_t; opaque here, never dereferenced. */
+typedef struct nrLDPC_time_stats t_nrLDPC_time_stats;
+/* common/utils/time_meas.h:61-74 -- opaque, the encoder's optional meters are ignored. */
+typedef struct time_stats time_stats_t;
+
+/* openair1/PHY/defs_common.h:998-1027 -- transport-block wide "stop decoding" flag shared by the segments */
+typedef struct {
+  pthread_mutex_t mutex_failure;
+  bool failed;
+} decode_abort_t;
+
+/* nrLDPC_defs.h:40-66 */
+typedef struct {
+  unsigned int n_segments; /* number of segments in input[]/output[] */
+  unsigned int macro_num;  /* this call encodes segments 8*macro_num .. min(n_segments, 8*macro_num+8) */
+  unsigned char gen_code;
+  time_stats_t *tinput;
+  time_stats_t *tprep;
+  time_stats_t *tparity;
+  time_stats_t *toutput;
+  int Kr;
+  uint32_t Kb;  /* information columns entering the parity (22; 10/9/8/6 for BG2) */
+  uint32_t Zc;
+  void *harq;
+  uint8_t BG;
+  unsigned char *output;
+  uint32_t K;   /* bits per segment incl. fillers = 22*Zc / 10*Zc */
+  uint32_t F;
+  uint8_t Qm;
+  uint32_t E;
+  unsigned int G;
+  uint8_t rv;
+} encoder_implemparams_t;
+
+#endif /* NRLDPC_HIP_NO_REFERENCE_TYPES */
+
+/* nrLDPC_defs.h:68-87.  LDPCinit: 0 on success (the loader asserts on anything else, nrLDPC_load.c:67);
+ * here it selects the GPU (env NRLDPC_HIP_DEVICE, default 0) and fails (-1) when no gfx950-capable HIP
+ * device is usable -- there is no CPU fallback. */
+int32_t LDPCinit(void);
+int32_t LDPCshutdown(void);
+/* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
+ * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
+ * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);
+ * numMaxIter+2 when *ab was already set on entry. */
+int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
+                    int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
+/* Up to 8 segments per call (ldpc_encoder_optim8segmulti.c:46-213): input[j] K/8 bytes MSB first,
+ * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Returns 0, -1 on bad parameters. */
+int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp);
+
+/* ===================================================================================================
+ * Part 2 -- batched / device-resident entry points
+ * =================================================================================================== */
+#define NRLDPC_HIP_MEM_HOST 0   /* pointers are host memory: staged through pinned buffers, call is synchronous */
+#define NRLDPC_HIP_MEM_DEVICE 1 /* pointers are device memory on the library's GPU: call only enqueues on `stream` */
+
+typedef struct nrLDPC_hip_dec_batch {
+  t_nrLDPC_dec_params params; /* shared by every block of the batch (homogeneous batch = one launch) */
+  uint32_t n_blocks;
+  const int8_t *llr;          /* block b at llr + b*llr_stride, ncols*Z int8 each */
+  uint32_t llr_stride;        /* bytes, >= ncols*Z; multiples of 16 give the widest loads */
+  int8_t *out;                /* block b at out + b*out_stride; BIT: 4*ceil(ncols*Z/32) bytes, else ncols*Z bytes */
+  uint32_t out_stride;        /* bytes, multiple of 4 */
+  int32_t *n_iter;            /* [n_blocks] return value of each block (same meaning as LDPCdecoder's) */
+  int32_t mem;                /* NRLDPC_HIP_MEM_* for llr/out/n_iter alike */
+  void *stream;               /* hipStream_t for DEVICE mem; NULL = HIP's default (null) stream */
+  int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code) */
+} nrLDPC_hip_dec_batch_t;
+/* 0 on success, negative on bad parameters / HIP error.  DEVICE mem: asynchronous w.r.t. the host. */
+int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b);
+
+typedef struct nrLDPC_hip_enc_batch {
+  uint8_t BG;
+  uint16_t Zc;
+  uint8_t Kb;            /* information columns entering the parity (see encoder_implemparams_t.Kb) */
+  uint32_t n_blocks;
+  const uint8_t *in;     /* block b at in + b*in_stride: K/8 bytes, MSB first (K = 22*Zc / 10*Zc) */
+  uint32_t in_stride;
+  uint8_t *out;          /* block b at out + b*out_stride: (66|50)*Zc bytes, one bit per byte */
+  uint32_t out_stride;
+  int32_t mem;
+  void *stream;
+} nrLDPC_hip_enc_batch_t;
+int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b);
+
+/* Introspection for tests and benchmarks */
+int32_t nrLDPC_hip_num_llr(int BG, int Z, int R);      /* ncols*Z, -1 if invalid */
+int32_t nrLDPC_hip_out_bytes(int BG, int Z, int R, int outMode);
+int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R);    /* LDS a decoder workgroup uses for this code */
+const char *nrLDPC_hip_last_error(void);
+const char *nrLDPC_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,399 @@
+/*
+ * ldpc_api.cpp -- C ABI of libldpc_hip.so (see include/nrLDPC_hip.h).
+ *
+ * Host side of the drop-in: the four plugin symbols of the reference
+ * (openair1/PHY/CODING/nrLDPC_extern.h:27-45, resolved by nrLDPC_load.c:45-75) plus the batched entry
+ * points.  Everything numeric runs in the HIP kernels; there is no CPU decode/encode path in this
+ * library -- without a usable GPU LDPCinit() fails and every other entry point returns an error.
+ */
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/nrLDPC_hip.h"
+#include "ldpc_graph.h"
+#include "ldpc_kernels.h"
+
+namespace {
+
+thread_local std::string tls_error;
+int set_error(const char *what, hipError_t e = hipSuccess)
+{
+  tls_error = what;
+  if (e != hipSuccess) {
+    tls_error += ": ";
+    tls_error += hipGetErrorString(e);
+  }
+  return -1;
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess)                               \
+      return set_error(#expr, e_);                      \
+  } while (0)
+
+struct CodeEntry {
+  ldpc_code_desc_t host;
+  ldpc_code_desc_t *dev = nullptr;
+};
+
+struct Library {
+  std::mutex mu;
+  bool ready = false;
+  int device = 0;
+  std::map<uint32_t, CodeEntry *> codes;
+  uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8 */
+} g;
+
+/* x^j mod g(x), left aligned in 32 bits, for the polynomials of crc_byte.c:46-58 */
+void fill_crc_pow(uint32_t poly, std::vector<uint32_t> &t)
+{
+  /* degree from the lowest set bit position of the left-aligned polynomial is not needed: the left-aligned
+   * register arithmetic of crcbit() (crc_byte.c:65-84) already works modulo g for any degree. */
+  t.resize(LDPC_CRC_POW_LEN);
+  /* x^0 as "remainder register" = the CRC of a single 1 bit followed by nothing is poly itself only after
+   * the degree shift; build it as: rem(j) = register after clocking a 1 followed by j zeros ... */
+  /* A message bit at distance j from the end of an E-bit word contributes x^j (mod g) to word(x) mod g.
+   * With the left-aligned register, word(x)*x^deg mod g is what crcbit computes; divisibility is the same
+   * question, so tabulate r_j = (x^j * x^deg) mod g: r_0 = poly (one 1 bit clocked in), r_{j+1} = r_j * x mod g */
+  uint32_t r = poly;
+  for (int j = 0; j < LDPC_CRC_POW_LEN; j++) {
+    t[j] = r;
+    r = (r & 0x80000000u) ? ((r << 1) ^ poly) : (r << 1);
+  }
+}
+
+int ensure_ready_locked()
+{
+  if (g.ready)
+    return 0;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return set_error("no HIP device available (libldpc_hip.so has no CPU fallback)", e);
+  const char *env = getenv("NRLDPC_HIP_DEVICE");
+  g.device = env ? atoi(env) : 0;
+  if (g.device < 0 || g.device >= ndev)
+    return set_error("NRLDPC_HIP_DEVICE out of range");
+  HIP_TRY(hipSetDevice(g.device));
+  HIP_TRY(ldpc_kernels_init());
+  static const uint32_t polys[4] = {0x864cfb00u, 0x80006300u, 0x10210000u, 0x9B000000u};
+  for (int i = 0; i < 4; i++) {
+    std::vector<uint32_t> t;
+    fill_crc_pow(polys[i], t);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow[i]), t.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(g.crc_pow[i], t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  g.ready = true;
+  return 0;
+}
+
+int ensure_ready()
+{
+  std::lock_guard<std::mutex> lk(g.mu);
+  return ensure_ready_locked();
+}
+
+/* descriptor cache: built on first use of a (BG, Z, R), uploaded once, never modified afterwards */
+const CodeEntry *get_code(int BG, int Z, int R)
+{
+  const uint32_t key = ((uint32_t)BG << 24) | ((uint32_t)Z << 8) | (uint32_t)R;
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (ensure_ready_locked() != 0)
+    return nullptr;
+  auto it = g.codes.find(key);
+  if (it != g.codes.end())
+    return it->second;
+  CodeEntry *ce = new CodeEntry();
+  if (ldpc_build_code_desc(BG, Z, R, &ce->host) != 0) {
+    delete ce;
+    set_error("invalid (BG, Z, R)");
+    return nullptr;
+  }
+  hipError_t e = hipSetDevice(g.device);
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void **>(&ce->dev), sizeof(ldpc_code_desc_t));
+  if (e == hipSuccess)
+    e = hipMemcpy(ce->dev, &ce->host, sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("descriptor upload", e);
+    delete ce;
+    return nullptr;
+  }
+  g.codes[key] = ce;
+  return ce;
+}
+
+int out_bytes_of(const ldpc_code_desc_t &c, int outMode)
+{
+  return outMode == 0 ? ((c.num_llr + 31) / 32) * 4 : c.num_llr;
+}
+
+/* per-thread staging for the synchronous host-buffer entry points (callers are thread-pool workers:
+ * reference nr_ulsch_decoding.c:435-468, nr_dlsch_coding.c:389-403) */
+struct ThreadCtx {
+  hipStream_t stream = nullptr;
+  uint8_t *h_in = nullptr, *h_out = nullptr; /* pinned */
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  int32_t *h_iter = nullptr, *d_iter = nullptr;
+  size_t cap_in = 0, cap_out = 0, cap_iter = 0;
+  int ensure(size_t in_bytes, size_t out_bytes, size_t n_iter)
+  {
+    HIP_TRY(hipSetDevice(g.device));
+    if (!stream)
+      HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (in_bytes > cap_in) {
+      if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
+      cap_in = in_bytes + in_bytes / 2 + 4096;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_in), cap_in, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), cap_in));
+    }
+    if (out_bytes > cap_out) {
+      if (h_out) { (void)hipHostFree(h_out); (void)hipFree(d_out); }
+      cap_out = out_bytes + out_bytes / 2 + 4096;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_out), cap_out, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), cap_out));
+    }
+    if (n_iter > cap_iter) {
+      if (h_iter) { (void)hipHostFree(h_iter); (void)hipFree(d_iter); }
+      cap_iter = n_iter + n_iter / 2 + 64;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_iter), cap_iter * sizeof(int32_t), hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_iter), cap_iter * sizeof(int32_t)));
+    }
+    return 0;
+  }
+};
+thread_local ThreadCtx tls_ctx;
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_args &a)
+{
+  a.code = ce->dev;
+  a.num_max_iter = p.numMaxIter;
+  a.out_mode = p.outMode == nrLDPC_outMode_BIT ? 0 : 1;
+  a.use_crc = p.check_crc != nullptr;
+  a.E = 0;
+  a.crc_pow = nullptr;
+  if (a.use_crc) {
+    if (p.crc_type < 0 || p.crc_type > 3)
+      return set_error("invalid crc_type");
+    if (p.E <= 0 || (p.E & 7) || p.E > ce->host.kb_full * ce->host.Z || p.E > LDPC_CRC_POW_LEN)
+      return set_error("CRC mode needs E > 0, E % 8 == 0, E <= K");
+    if (p.outMode != nrLDPC_outMode_BIT)
+      return set_error("CRC mode needs outMode BIT (the reference checks the packed bytes)");
+    a.E = p.E;
+    a.crc_pow = g.crc_pow[p.crc_type];
+  }
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
+const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.1 (gfx950)"; }
+
+int32_t nrLDPC_hip_num_llr(int BG, int Z, int R)
+{
+  ldpc_code_desc_t d;
+  return ldpc_build_code_desc(BG, Z, R, &d) == 0 ? d.num_llr : -1;
+}
+int32_t nrLDPC_hip_out_bytes(int BG, int Z, int R, int outMode)
+{
+  ldpc_code_desc_t d;
+  return ldpc_build_code_desc(BG, Z, R, &d) == 0 ? out_bytes_of(d, outMode) : -1;
+}
+int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R)
+{
+  ldpc_code_desc_t d;
+  return ldpc_build_code_desc(BG, Z, R, &d) == 0 ? d.lds_total : -1;
+}
+
+int32_t LDPCinit(void) { return ensure_ready() == 0 ? 0 : -1; }
+
+int32_t LDPCshutdown(void)
+{
+  /* The reference's LDPCshutdown is a no-op (nrLDPC_decoder.c:167).  Device objects are kept: the loader
+   * maps the library RTLD_NODELETE (common/utils/load_module_shlib.c:160) and other threads may still be
+   * inside a call. */
+  return 0;
+}
+
+int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
+{
+  if (!b || !b->llr || !b->out || !b->n_iter)
+    return set_error("null argument");
+  const t_nrLDPC_dec_params &p = b->params;
+  const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
+  if (!ce)
+    return -1;
+  const ldpc_code_desc_t &hc = ce->host;
+  const int ob = out_bytes_of(hc, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
+  if (b->llr_stride < (uint32_t)hc.num_llr || b->out_stride < (uint32_t)ob || (b->out_stride & 3))
+    return set_error("bad stride");
+  ldpc_dec_args a;
+  if (fill_dec_args(p, ce, a) != 0)
+    return -1;
+  if (b->n_blocks == 0)
+    return 0;
+  if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
+    if ((reinterpret_cast<uintptr_t>(b->out) & 3))
+      return set_error("out must be 4-byte aligned");
+    a.llr = b->llr; a.llr_stride = b->llr_stride;
+    a.out = b->out; a.out_stride = b->out_stride;
+    a.n_iter = b->n_iter;
+    hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
+    HIP_TRY(ldpc_launch_dec_generic(a, hc, b->n_blocks, s));
+    return 0;
+  }
+  /* host buffers: stage through this thread's pinned buffers, synchronous */
+  ThreadCtx &c = tls_ctx;
+  const size_t in_stride = align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
+  if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks, b->n_blocks) != 0)
+    return -1;
+  for (uint32_t i = 0; i < b->n_blocks; i++)
+    memcpy(c.h_in + i * in_stride, b->llr + (size_t)i * b->llr_stride, hc.num_llr);
+  HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * b->n_blocks, hipMemcpyHostToDevice, c.stream));
+  a.llr = reinterpret_cast<const int8_t *>(c.d_in); a.llr_stride = (uint32_t)in_stride;
+  a.out = reinterpret_cast<int8_t *>(c.d_out); a.out_stride = (uint32_t)out_stride;
+  a.n_iter = c.d_iter;
+  HIP_TRY(ldpc_launch_dec_generic(a, hc, b->n_blocks, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.h_iter, c.d_iter, sizeof(int32_t) * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (uint32_t i = 0; i < b->n_blocks; i++) {
+    const int32_t n = c.h_iter[i];
+    b->n_iter[i] = n;
+    if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+      memcpy(b->out + (size_t)i * b->out_stride, c.h_out + i * out_stride, ob);
+  }
+  return 0;
+}
+
+int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
+                    int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab)
+{
+  (void)harq_pid; (void)ulsch_id; (void)C; (void)p_profiler;
+  if (!p_decParams || !p_llr || !p_out)
+    return set_error("null argument");
+  /* decoder.c:556-559: a segment of an already failed transport block is not worked on */
+  if (ab) {
+    pthread_mutex_lock(&ab->mutex_failure);
+    const bool failed = ab->failed;
+    pthread_mutex_unlock(&ab->mutex_failure);
+    if (failed)
+      return p_decParams->numMaxIter + 2;
+  }
+  const CodeEntry *ce = get_code(p_decParams->BG, p_decParams->Z, p_decParams->R);
+  if (!ce)
+    return -1;
+  const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
+  nrLDPC_hip_dec_batch_t b;
+  memset(&b, 0, sizeof(b));
+  b.params = *p_decParams;
+  b.n_blocks = 1;
+  b.llr = p_llr; b.llr_stride = (uint32_t)ce->host.num_llr;
+  b.out = p_out; b.out_stride = (uint32_t)align_up(ob, 4);
+  int32_t n_iter = 0;
+  b.n_iter = &n_iter;
+  b.mem = NRLDPC_HIP_MEM_HOST;
+  if (LDPCdecoder_batch(&b) != 0)
+    return -1;
+  if (n_iter > p_decParams->numMaxIter && ab) { /* decoder.c:190-193 */
+    pthread_mutex_lock(&ab->mutex_failure);
+    ab->failed = true;
+    pthread_mutex_unlock(&ab->mutex_failure);
+  }
+  return n_iter;
+}
+
+int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b)
+{
+  if (!b || !b->in || !b->out)
+    return set_error("null argument");
+  const CodeEntry *ce = get_code(b->BG, b->Zc, b->BG == 1 ? 13 : 15);
+  if (!ce)
+    return -1;
+  const ldpc_code_desc_t &hc = ce->host;
+  const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
+  if (b->Kb < 1 || b->Kb > hc.kb_full)
+    return set_error("bad Kb");
+  if (b->in_stride < (uint32_t)in_bytes || b->out_stride < (uint32_t)N)
+    return set_error("bad stride");
+  if (b->n_blocks == 0)
+    return 0;
+  ldpc_enc_args a;
+  a.code = ce->dev;
+  a.Kb = b->Kb;
+  if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
+    a.in = b->in; a.in_stride = b->in_stride;
+    a.out = b->out; a.out_stride = b->out_stride;
+    hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
+    HIP_TRY(ldpc_launch_enc(a, hc, b->n_blocks, s));
+    return 0;
+  }
+  ThreadCtx &c = tls_ctx;
+  const size_t in_stride = align_up(in_bytes, 16), out_stride = align_up(N, 16);
+  if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks, 1) != 0)
+    return -1;
+  for (uint32_t i = 0; i < b->n_blocks; i++)
+    memcpy(c.h_in + i * in_stride, b->in + (size_t)i * b->in_stride, in_bytes);
+  HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * b->n_blocks, hipMemcpyHostToDevice, c.stream));
+  a.in = c.d_in; a.in_stride = (uint32_t)in_stride;
+  a.out = c.d_out; a.out_stride = (uint32_t)out_stride;
+  HIP_TRY(ldpc_launch_enc(a, hc, b->n_blocks, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (uint32_t i = 0; i < b->n_blocks; i++)
+    memcpy(b->out + (size_t)i * b->out_stride, c.h_out + i * out_stride, N);
+  return 0;
+}
+
+int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp)
+{
+  if (!input || !output || !impp)
+    return set_error("null argument");
+  /* ldpc_encoder_optim8segmulti.c:64-65: this call covers segments 8*macro_num .. min(n_segments, +8) */
+  const unsigned first = 8 * impp->macro_num;
+  const unsigned last = impp->n_segments > 8 * (impp->macro_num + 1) ? 8 * (impp->macro_num + 1) : impp->n_segments;
+  if (last <= first)
+    return 0;
+  const CodeEntry *ce = get_code(impp->BG, (int)impp->Zc, impp->BG == 1 ? 13 : 15);
+  if (!ce)
+    return -1;
+  const ldpc_code_desc_t &hc = ce->host;
+  const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
+  if ((uint32_t)K != impp->K)
+    return set_error("K must be 22*Zc (BG1) or 10*Zc (BG2)");
+  const unsigned n = last - first;
+  ThreadCtx &c = tls_ctx;
+  const size_t in_stride = align_up(in_bytes, 16), out_stride = align_up(N, 16);
+  if (c.ensure(in_stride * n, out_stride * n, 1) != 0)
+    return -1;
+  for (unsigned j = 0; j < n; j++)
+    memcpy(c.h_in + j * in_stride, input[first + j], in_bytes);
+  HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * n, hipMemcpyHostToDevice, c.stream));
+  ldpc_enc_args a;
+  a.code = ce->dev;
+  a.Kb = (int)impp->Kb;
+  if (a.Kb < 1 || a.Kb > hc.kb_full)
+    return set_error("bad Kb");
+  a.in = c.d_in; a.in_stride = (uint32_t)in_stride;
+  a.out = c.d_out; a.out_stride = (uint32_t)out_stride;
+  HIP_TRY(ldpc_launch_enc(a, hc, n, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * n, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (unsigned j = 0; j < n; j++)
+    memcpy(output[first + j], c.h_out + j * out_stride, N);
+  return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,206 @@
+/*
+ * ldpc_graph.c -- host-side builder of the lifted-code descriptor (see ldpc_graph.h).
+ * Plain C, no GPU dependency: unit-tested on CPU against the reference's LUT data.
+ */
+#include <string.h>
+#include <stdlib.h>
+#include "ldpc_graph.h"
+#include "nr_ldpc_bg_tables.h"
+
+int ldpc_lifting_set_index(int Z)
+{
+  /* 38.212 Table 5.3.2-1: Z = a * 2^j with a in {2,3,5,7,9,11,13,15}; set index = position of a */
+  static const int a[8] = {2, 3, 5, 7, 9, 11, 13, 15};
+  int ok = 0;
+  for (int i = 0; i < NR_LDPC_NUM_LIFT; i++)
+    ok |= nr_ldpc_lift_sizes[i] == Z;
+  if (!ok)
+    return -1;
+  int odd = Z;
+  while ((odd & 1) == 0)
+    odd >>= 1;
+  if (odd == 1)
+    return 0; /* pure power of two belongs to the a = 2 family */
+  for (int i = 1; i < 8; i++)
+    if (a[i] == odd)
+      return i;
+  return -1;
+}
+
+typedef struct { int key, id; } sort_item_t;
+static int by_key_desc(const void *pa, const void *pb)
+{
+  const sort_item_t *a = (const sort_item_t *)pa, *b = (const sort_item_t *)pb;
+  if (a->key != b->key)
+    return b->key - a->key;
+  return a->id - b->id;
+}
+
+static int align16(int x) { return (x + 15) & ~15; }
+
+int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d)
+{
+  const int ils = ldpc_lifting_set_index(Z);
+  if (ils < 0)
+    return -1;
+  memset(d, 0, sizeof(*d));
+  const uint8_t *deg, *col;
+  const uint16_t *sh;
+  if (BG == 1) {
+    deg = nr_ldpc_bg1_row_deg; col = nr_ldpc_bg1_col; sh = nr_ldpc_bg1_shift[ils];
+    d->ncore = 26; d->kb_full = 22;
+    /* nrLDPCdecoder_defs.h:53-57: columns kept per decoder rate mode */
+    d->ncols = R == 13 ? 68 : R == 23 ? 35 : R == 89 ? 27 : -1;
+  } else if (BG == 2) {
+    deg = nr_ldpc_bg2_row_deg; col = nr_ldpc_bg2_col; sh = nr_ldpc_bg2_shift[ils];
+    d->ncore = 14; d->kb_full = 10;
+    /* nrLDPCdecoder_defs.h:80-84 */
+    d->ncols = R == 15 ? 52 : R == 13 ? 32 : R == 23 ? 17 : -1;
+  } else
+    return -1;
+  if (d->ncols < 0)
+    return -1;
+  d->BG = BG; d->Z = Z; d->R = R; d->ils = ils;
+  d->nrows = d->ncols - d->kb_full;
+  d->zw = (Z + 63) / 64;
+  d->num_llr = d->ncols * Z;
+
+  int e = 0;
+  for (int r = 0; r < d->nrows; r++) {
+    d->row_ptr[r] = e;
+    d->row_deg[r] = deg[r];
+    for (int k = 0; k < deg[r]; k++, e++) {
+      d->e_col[e] = col[e];
+      d->e_info[e] = ((uint32_t)(col[e] * Z) << 16) | (uint32_t)(sh[e] % Z);
+    }
+  }
+  d->row_ptr[d->nrows] = e;
+  d->nedges = e;
+
+  /* bit-node adjacency of the core columns */
+  int n = 0;
+  for (int c = 0; c < d->ncore; c++) {
+    d->col_ptr[c] = n;
+    for (int k = 0; k < d->nedges; k++)
+      if (d->e_col[k] == c)
+        d->col_edge[n++] = ((uint32_t)k << 16) | (d->e_info[k] & 0xffffu);
+  }
+  d->col_ptr[d->ncore] = n;
+
+  /* [F6] parity-check lane exclusion.  The reference walks the CNs of one degree class back to back
+   * (class = CN group, ascending degree; CNs in base-graph row order, Z lanes each) in 32-lane chunks
+   * and ignores the last chunk when the class holds a multiple of 32 lanes
+   * (nrLDPC_cnProc.h:937-965, same pattern for every group of BG1 and BG2). */
+  for (int r = 0; r < d->nrows; r++)
+    d->pc_lo[r] = Z;
+  for (int dg = 1; dg <= 19; dg++) {
+    int rows[LDPC_MAX_ROWS], nr = 0;
+    for (int r = 0; r < d->nrows; r++)
+      if (d->row_deg[r] == dg)
+        rows[nr++] = r;
+    if (!nr)
+      continue;
+    const int M = nr * Z;
+    if (M & 31)
+      continue;
+    const int first_dropped = M - 32; /* flattened lane index m = k*Z + t */
+    for (int k = 0; k < nr; k++) {
+      int lo = first_dropped - k * Z;
+      if (lo < 0)
+        lo = 0;
+      if (lo < Z)
+        d->pc_lo[rows[k]] = lo;
+    }
+  }
+
+  /* schedules (longest work first, then round-robin over the waves of the workgroup) */
+  sort_item_t items[LDPC_MAX_ROWS * LDPC_MAX_ZW];
+  d->n_cn_slots = d->nrows * d->zw;
+  for (int s = 0; s < d->n_cn_slots; s++) {
+    items[s].id = s;
+    items[s].key = d->row_deg[s / d->zw];
+  }
+  qsort(items, d->n_cn_slots, sizeof(items[0]), by_key_desc);
+  for (int s = 0; s < d->n_cn_slots; s++)
+    d->cn_order[s] = ((items[s].id / d->zw) << 4) | (items[s].id % d->zw);
+  d->n_bn_slots = d->ncore * d->zw;
+  for (int s = 0; s < d->n_bn_slots; s++) {
+    const int c = s / d->zw;
+    items[s].id = s;
+    items[s].key = d->col_ptr[c + 1] - d->col_ptr[c];
+  }
+  qsort(items, d->n_bn_slots, sizeof(items[0]), by_key_desc);
+  for (int s = 0; s < d->n_bn_slots; s++)
+    d->bn_order[s] = ((items[s].id / d->zw) << 4) | (items[s].id % d->zw);
+
+
+  /* encoder core-parity solve order (only meaningful for the full-rate descriptors R13 / R15, but the
+   * four core rows are present in every mode) */
+  {
+    int has[4][4], shf[4][4], cnt[LDPC_MAX_Z];
+    memset(has, 0, sizeof(has));
+    memset(shf, 0, sizeof(shf));
+    memset(cnt, 0, sizeof(cnt));
+    for (int r = 0; r < 4; r++)
+      for (int k = d->row_ptr[r]; k < d->row_ptr[r + 1]; k++) {
+        const int c = d->e_col[k] - d->kb_full;
+        if (c >= 0 && c < 4) {
+          has[r][c] = 1;
+          shf[r][c] = (int)(d->e_info[k] & 0xffffu);
+        }
+      }
+    for (int r = 0; r < 4; r++)
+      if (has[r][0])
+        cnt[shf[r][0]]++;
+    d->enc_p0_shift = -1;
+    for (int s = 0; s < Z; s++)
+      if (cnt[s] & 1) {
+        if (d->enc_p0_shift >= 0)
+          return -1;
+        d->enc_p0_shift = s;
+      }
+    if (d->enc_p0_shift < 0)
+      return -1;
+    int known[4] = {1, 0, 0, 0};
+    for (int step = 0; step < 3; step++) {
+      int found = 0;
+      for (int r = 0; r < 4 && !found; r++) {
+        int unk = -1, nunk = 0;
+        for (int j = 0; j < 4; j++)
+          if (has[r][j] && !known[j]) {
+            unk = j;
+            nunk++;
+          }
+        if (nunk != 1)
+          continue;
+        d->enc_row[step] = r;
+        d->enc_unk[step] = unk;
+        d->enc_ushift[step] = shf[r][unk];
+        int nk = 0;
+        for (int j = 0; j < 4; j++)
+          if (has[r][j] && known[j]) {
+            d->enc_kcol[step][nk] = j;
+            d->enc_kshift[step][nk] = shf[r][j];
+            nk++;
+          }
+        d->enc_nk[step] = nk;
+        known[unk] = 1;
+        found = 1;
+      }
+      if (!found)
+        return -1;
+    }
+  }
+
+  /* LDS carve-up of the generic kernel: messages, APP of the core columns, channel LLRs, flags */
+  d->lds_r = 0;
+  d->lds_app = align16(d->nedges * Z);
+  d->lds_llr = d->lds_app + align16(d->ncore * Z);
+  d->lds_misc = d->lds_llr + align16(d->num_llr);
+  d->lds_total = d->lds_misc + 64;
+  int waves = (d->n_cn_slots + 3) / 4; /* aim at >= 4 slots per wave and phase */
+  if (waves < 1) waves = 1;
+  if (waves > 16) waves = 16;
+  d->n_threads = waves * 64;
+  return 0;
+}

@@ -1,0 +1,43 @@
+/*
+ * ldpc_kernels.h -- launch interface between the C-ABI layer (ldpc_api.cpp) and the HIP kernels.
+ */
+#ifndef LDPC_KERNELS_H
+#define LDPC_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ldpc_graph.h"
+
+#define LDPC_CRC_POW_LEN 8448 /* x^j mod g for j < 8448 = largest code block */
+
+struct ldpc_dec_args {
+  const ldpc_code_desc_t *code; /* device copy of the descriptor */
+  const int8_t *llr;
+  uint32_t llr_stride;
+  int8_t *out;
+  uint32_t out_stride;
+  int32_t *n_iter;
+  int32_t num_max_iter;
+  int32_t out_mode; /* 0 packed bits, else one bit per byte */
+  int32_t use_crc;  /* 0: parity-check stop, 1: CRC stop */
+  int32_t E;        /* bits covered by the CRC check (use_crc) */
+  const uint32_t *crc_pow; /* device table, crc_pow[j] = x^j mod g(x), left aligned in 32 bits */
+};
+
+struct ldpc_enc_args {
+  const ldpc_code_desc_t *code; /* full-rate descriptor (R13 / R15) */
+  const uint8_t *in;
+  uint32_t in_stride;
+  uint8_t *out;
+  uint32_t out_stride;
+  int32_t Kb;
+};
+
+/* one-time per-process kernel attribute setup (dynamic LDS limit); returns hipSuccess or the error */
+hipError_t ldpc_kernels_init(void);
+/* generic flooding min-sum decoder: one workgroup per code block, any (BG, Z, R) */
+hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
+                                   hipStream_t stream);
+/* encoder: one workgroup per code block */
+hipError_t ldpc_launch_enc(const ldpc_enc_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
+                           hipStream_t stream);
+#endif

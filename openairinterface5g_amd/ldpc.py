@@ -1,0 +1,238 @@
+"""Python host side of libldpc_hip.so -- mirrors the reference's LDPC plugin interface.
+
+The reference exposes the codec as ``ldpc_interface_t {LDPCinit, LDPCshutdown, LDPCdecoder, LDPCencoder}``
+(openair1/PHY/CODING/nrLDPC_extern.h:27-33) taking ``t_nrLDPC_dec_params`` / ``encoder_implemparams_t``
+(nrLDPC_types.h:84-97, nrLDPC_defs.h:40-66).  This module binds the same four symbols plus the batched
+entry points of include/nrLDPC_hip.h with ctypes; argument names and meaning follow the reference.
+
+There is no fallback: if the shared library is missing or no GPU is usable, calls raise.
+torch is used only as the owner of device memory and streams for the ``*_device`` calls.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libldpc_hip.so"
+
+# e_nrLDPC_outMode (nrLDPC_types.h:75-79)
+nrLDPC_outMode_BIT, nrLDPC_outMode_BITINT8, nrLDPC_outMode_LLRINT8 = 0, 1, 2
+# coding_defs.h:33-36
+CRC24_A, CRC24_B, CRC16, CRC8 = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+
+NCOLS = {(1, 13): 68, (1, 23): 35, (1, 89): 27, (2, 15): 52, (2, 13): 32, (2, 23): 17}
+LIFT_SIZES = sorted(a * (1 << j) for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * (1 << j) <= 384)
+
+CHECK_CRC_T = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint8)
+
+
+class t_nrLDPC_dec_params(C.Structure):
+    """nrLDPC_types.h:84-97"""
+    _fields_ = [("BG", C.c_uint8), ("Z", C.c_uint16), ("R", C.c_uint8), ("F", C.c_uint16), ("Qm", C.c_uint8),
+                ("rv", C.c_uint8), ("numMaxIter", C.c_uint8), ("E", C.c_int), ("outMode", C.c_int),
+                ("crc_type", C.c_int), ("check_crc", C.c_void_p), ("setCombIn", C.c_uint8)]
+
+
+class encoder_implemparams_t(C.Structure):
+    """nrLDPC_defs.h:40-66"""
+    _fields_ = [("n_segments", C.c_uint), ("macro_num", C.c_uint), ("gen_code", C.c_ubyte),
+                ("tinput", C.c_void_p), ("tprep", C.c_void_p), ("tparity", C.c_void_p), ("toutput", C.c_void_p),
+                ("Kr", C.c_int), ("Kb", C.c_uint32), ("Zc", C.c_uint32), ("harq", C.c_void_p), ("BG", C.c_uint8),
+                ("output", C.c_void_p), ("K", C.c_uint32), ("F", C.c_uint32), ("Qm", C.c_uint8), ("E", C.c_uint32),
+                ("G", C.c_uint), ("rv", C.c_uint8)]
+
+
+class decode_abort_t(C.Structure):
+    """openair1/PHY/defs_common.h:998-1001 (pthread_mutex_t is 40 bytes on x86-64 glibc; all-zero = initialised)"""
+    _fields_ = [("mutex_failure", C.c_uint8 * 40), ("failed", C.c_bool)]
+
+
+class nrLDPC_hip_dec_batch_t(C.Structure):
+    _fields_ = [("params", t_nrLDPC_dec_params), ("n_blocks", C.c_uint32), ("llr", C.c_void_p),
+                ("llr_stride", C.c_uint32), ("out", C.c_void_p), ("out_stride", C.c_uint32), ("n_iter", C.c_void_p),
+                ("mem", C.c_int32), ("stream", C.c_void_p), ("kernel", C.c_int32)]
+
+
+class nrLDPC_hip_enc_batch_t(C.Structure):
+    _fields_ = [("BG", C.c_uint8), ("Zc", C.c_uint16), ("Kb", C.c_uint8), ("n_blocks", C.c_uint32),
+                ("in_", C.c_void_p), ("in_stride", C.c_uint32), ("out", C.c_void_p), ("out_stride", C.c_uint32),
+                ("mem", C.c_int32), ("stream", C.c_void_p)]
+
+
+# any non-NULL pointer selects CRC early stop; the library never calls it (include/nrLDPC_hip.h)
+_CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
+
+EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "LDPCdecoder_batch", "LDPCencoder_batch",
+           "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_last_error",
+           "nrLDPC_hip_version"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libldpc_hip.so (the analogue of load_LDPClib, nrLDPC_load.c:45-75). Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C {_PKG / 'csrc'}` -- there is no CPU fallback")
+    L = C.CDLL(str(p), mode=os.RTLD_NOW | os.RTLD_GLOBAL)
+    L.LDPCinit.restype = C.c_int32
+    L.LDPCshutdown.restype = C.c_int32
+    L.LDPCdecoder.restype = C.c_int32
+    L.LDPCdecoder.argtypes = [C.POINTER(t_nrLDPC_dec_params), C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]
+    L.LDPCencoder.restype = C.c_int32
+    L.LDPCencoder.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(encoder_implemparams_t)]
+    L.LDPCdecoder_batch.restype = C.c_int32
+    L.LDPCdecoder_batch.argtypes = [C.POINTER(nrLDPC_hip_dec_batch_t)]
+    L.LDPCencoder_batch.restype = C.c_int32
+    L.LDPCencoder_batch.argtypes = [C.POINTER(nrLDPC_hip_enc_batch_t)]
+    for n in ("nrLDPC_hip_num_llr", "nrLDPC_hip_lds_bytes"):
+        getattr(L, n).argtypes = [C.c_int] * 3
+        getattr(L, n).restype = C.c_int32
+    L.nrLDPC_hip_out_bytes.argtypes = [C.c_int] * 4
+    L.nrLDPC_hip_out_bytes.restype = C.c_int32
+    L.nrLDPC_hip_last_error.restype = C.c_char_p
+    L.nrLDPC_hip_version.restype = C.c_char_p
+    if path is None:
+        _lib = L
+    return L
+
+
+def last_error():
+    return load_library().nrLDPC_hip_last_error().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+
+
+def LDPCinit():
+    """nrLDPC_decoder.c:162.  Raises when no MI355X/HIP device is usable."""
+    _check(load_library().LDPCinit(), "LDPCinit")
+    return 0
+
+
+def LDPCshutdown():
+    return load_library().LDPCshutdown()
+
+
+def num_llr(BG, Z, R):
+    return NCOLS[(BG, R)] * Z
+
+
+def out_bytes(BG, Z, R, outMode=nrLDPC_outMode_BIT):
+    n = num_llr(BG, Z, R)
+    return ((n + 31) // 32) * 4 if outMode == nrLDPC_outMode_BIT else n
+
+
+def make_dec_params(BG, Z, R, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_crc=False, E=0, crc_type=CRC24_B):
+    p = t_nrLDPC_dec_params(BG=BG, Z=Z, R=R, numMaxIter=numMaxIter, outMode=outMode, E=E, crc_type=crc_type)
+    if check_crc:
+        p.check_crc = C.cast(_CRC_SENTINEL, C.c_void_p)
+    return p
+
+
+def LDPCdecoder(p_decParams, p_llr, p_out=None, ab=None, harq_pid=0, ulsch_id=0, C_=0):
+    """One code block through the reference's own entry point (nrLDPC_decoder.c:172).
+    p_llr: int8[ncols*Z]; returns (numIter, p_out)."""
+    L = load_library()
+    p_llr = np.ascontiguousarray(p_llr, dtype=np.int8)
+    nb = out_bytes(p_decParams.BG, p_decParams.Z, p_decParams.R, p_decParams.outMode)
+    if p_out is None:
+        p_out = np.zeros(nb, dtype=np.uint8)
+    n = L.LDPCdecoder(C.byref(p_decParams), harq_pid, ulsch_id, C_, p_llr.ctypes.data, p_out.ctypes.data, None,
+                      C.addressof(ab) if ab is not None else None)
+    if n < 0:
+        raise RuntimeError(f"LDPCdecoder failed: {last_error()}")
+    return n, p_out
+
+
+def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0):
+    """Up to 8 segments through the reference entry point (ldpc_encoder_optim8segmulti.c:46).
+    inputs: list of uint8[K/8]; returns list of uint8[(66|50)*Zc] (one bit per byte) for ALL n_segments
+    (entries outside this macro group are left zero)."""
+    L = load_library()
+    kbf = 22 if BG == 1 else 10
+    K = kbf * Zc
+    n_segments = len(inputs) if n_segments is None else n_segments
+    ins = [np.ascontiguousarray(np.concatenate([np.asarray(i, dtype=np.uint8), np.zeros(8, np.uint8)])) for i in inputs]
+    outs = [np.zeros(68 * 384, dtype=np.uint8) for _ in range(n_segments)]
+    ip = (C.c_void_p * n_segments)(*[a.ctypes.data for a in ins])
+    op = (C.c_void_p * n_segments)(*[a.ctypes.data for a in outs])
+    impp = encoder_implemparams_t(n_segments=n_segments, macro_num=macro_num, gen_code=0, Kr=K,
+                                  Kb=kbf if Kb is None else Kb, Zc=Zc, BG=BG, K=K, E=K)
+    rc = L.LDPCencoder(ip, op, C.byref(impp))
+    _check(rc, "LDPCencoder")
+    N = (66 if BG == 1 else 50) * Zc
+    return [o[:N] for o in outs]
+
+
+def decode_batch_host(BG, Z, R, llr, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_crc=False, E=0,
+                      crc_type=CRC24_B, out=None, kernel=0):
+    """llr: int8[n_blocks, >= ncols*Z] host array. Returns (n_iter int32[n], out uint8[n, out_bytes])."""
+    L = load_library()
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    n = llr.shape[0]
+    ob = out_bytes(BG, Z, R, outMode)
+    stride = (ob + 3) // 4 * 4
+    if out is None:
+        out = np.zeros((n, stride), dtype=np.uint8)
+    it = np.zeros(n, dtype=np.int32)
+    assert llr.ndim == 2 and out.ndim == 2 and out.flags.c_contiguous and out.shape[0] == n
+    # (strides of a length-1 axis are arbitrary in numpy, so derive the row pitch from the shape)
+    b = nrLDPC_hip_dec_batch_t(params=make_dec_params(BG, Z, R, numMaxIter, outMode, check_crc, E, crc_type),
+                               n_blocks=n, llr=llr.ctypes.data, llr_stride=llr.shape[1], out=out.ctypes.data,
+                               out_stride=out.shape[1], n_iter=it.ctypes.data, mem=MEM_HOST, stream=None, kernel=kernel)
+    _check(L.LDPCdecoder_batch(C.byref(b)), "LDPCdecoder_batch")
+    return it, out[:, :ob]
+
+
+def decode_batch_device(BG, Z, R, llr, out, n_iter, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_crc=False, E=0,
+                        crc_type=CRC24_B, stream=None, kernel=0):
+    """Enqueue a decode of device-resident blocks (torch tensors: llr int8[n, stride], out uint8[n, stride'],
+    n_iter int32[n]) on `stream` (default: torch's current stream). Asynchronous."""
+    import torch
+    L = load_library()
+    assert llr.is_cuda and out.is_cuda and n_iter.is_cuda and llr.dtype == torch.int8 and n_iter.dtype == torch.int32
+    assert llr.stride(1) == 1 and out.stride(1) == 1 and n_iter.is_contiguous()
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    b = nrLDPC_hip_dec_batch_t(params=make_dec_params(BG, Z, R, numMaxIter, outMode, check_crc, E, crc_type),
+                               n_blocks=llr.shape[0], llr=llr.data_ptr(), llr_stride=llr.stride(0) * llr.element_size(),
+                               out=out.data_ptr(), out_stride=out.stride(0) * out.element_size(),
+                               n_iter=n_iter.data_ptr(), mem=MEM_DEVICE, stream=s, kernel=kernel)
+    _check(L.LDPCdecoder_batch(C.byref(b)), "LDPCdecoder_batch")
+
+
+def encode_batch_host(BG, Zc, info, Kb=None):
+    """info: uint8[n_blocks, >= K/8] host array (MSB first). Returns uint8[n_blocks, (66|50)*Zc], one bit per byte."""
+    L = load_library()
+    info = np.ascontiguousarray(info, dtype=np.uint8)
+    assert info.ndim == 2
+    n = info.shape[0]
+    N = (66 if BG == 1 else 50) * Zc
+    out = np.zeros((n, N), dtype=np.uint8)
+    b = nrLDPC_hip_enc_batch_t(BG=BG, Zc=Zc, Kb=(22 if BG == 1 else 10) if Kb is None else Kb, n_blocks=n,
+                               in_=info.ctypes.data, in_stride=info.shape[1], out=out.ctypes.data,
+                               out_stride=out.shape[1], mem=MEM_HOST, stream=None)
+    _check(L.LDPCencoder_batch(C.byref(b)), "LDPCencoder_batch")
+    return out
+
+
+def encode_batch_device(BG, Zc, info, out, Kb=None, stream=None):
+    """info: torch uint8[n, >= K/8], out: torch uint8[n, >= (66|50)*Zc], both on the GPU. Asynchronous."""
+    import torch
+    L = load_library()
+    assert info.is_cuda and out.is_cuda and info.stride(1) == 1 and out.stride(1) == 1
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    b = nrLDPC_hip_enc_batch_t(BG=BG, Zc=Zc, Kb=(22 if BG == 1 else 10) if Kb is None else Kb, n_blocks=info.shape[0],
+                               in_=info.data_ptr(), in_stride=info.stride(0), out=out.data_ptr(),
+                               out_stride=out.stride(0), mem=MEM_DEVICE, stream=s)
+    _check(L.LDPCencoder_batch(C.byref(b)), "LDPCencoder_batch")

@@ -1,0 +1,161 @@
+"""-m gpu: the HIP decoder through the C ABI vs the oracle (bit-exact: output bytes AND pass counts)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import ALL_RATES, kbits, load_survey_decoder_vectors, make_llr, random_info
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(hip, BG, Z, R, llrs, it, mode=0, use_crc=False, E=0, ct=1):
+    llr = np.stack(llrs)
+    pre = np.full((llr.shape[0], (hip.ldpc.out_bytes(BG, Z, R, mode) + 3) // 4 * 4), 0x33, dtype=np.uint8)
+    n_gpu, out_gpu = hip.decode_batch_host(BG, Z, R, llr, numMaxIter=it, outMode=mode, check_crc=use_crc, E=E,
+                                           crc_type=ct, out=pre.copy())
+    for i in range(llr.shape[0]):
+        n_ref, out_ref = O.decode(BG, Z, R, llr[i], it, mode, use_crc, E, ct, out_init=0x33)
+        assert n_ref == n_gpu[i], (BG, Z, R, it, mode, use_crc, i, n_ref, int(n_gpu[i]))
+        assert np.array_equal(out_ref, out_gpu[i]), (BG, Z, R, it, mode, use_crc, i)
+
+
+@pytest.mark.parametrize("BG", [1, 2])
+def test_every_lifting_size_and_rate(hip, BG):
+    """All 51 lifting sizes x 3 decoder-rate modes: noisy code words at two SNRs + random int8 LLRs."""
+    rng = np.random.default_rng(100 + BG)
+    for Z in O.LIFT_SIZES:
+        for R in ALL_RATES[BG]:
+            llrs = [make_llr(rng, BG, Z, R, -1.0), make_llr(rng, BG, Z, R, 1.0), make_llr(rng, BG, Z, R, "rand")]
+            _compare(hip, BG, Z, R, llrs, 8)
+
+
+@pytest.mark.parametrize("cfg", [(1, 384, 13), (1, 384, 23), (1, 384, 89), (1, 176, 13), (2, 64, 15), (2, 208, 13),
+                                 (2, 208, 15), (2, 8, 15), (1, 2, 13), (2, 384, 23)])
+def test_iteration_caps_modes_and_saturation(hip, cfg):
+    BG, Z, R = cfg
+    rng = np.random.default_rng(7 * Z + R)
+    llrs = [make_llr(rng, BG, Z, R, k) for k in (-6.0, -1.5, -0.5, 0.5, 3.0, "rand", "sat")]
+    llrs.append(np.zeros_like(llrs[0]))                      # all-zero input
+    llrs.append(np.full_like(llrs[0], -128))                 # all -128
+    llrs.append(np.full_like(llrs[0], 127))
+    for it in (0, 1, 2, 3, 8, 20):
+        _compare(hip, BG, Z, R, llrs, it)
+    for mode in (1, 2):
+        _compare(hip, BG, Z, R, llrs, 8, mode)
+
+
+@pytest.mark.parametrize("cfg", [(1, 384, 13, 1), (1, 176, 23, 1), (2, 64, 15, 1), (2, 208, 13, 0), (2, 16, 23, 2),
+                                 (1, 8, 89, 1)])
+def test_crc_early_stop(hip, cfg):
+    """check_crc != NULL: stop on CRC from pass 3 on (decoder.c:849-861), p_out untouched before."""
+    BG, Z, R, ct = cfg
+    rng = np.random.default_rng(11 * Z + R)
+    K = kbits(BG, Z)
+    crc_len = {0: 24, 1: 24, 2: 16}[ct]
+    name = {0: "crc24a", 1: "crc24b", 2: "crc16"}[ct]
+    llrs = []
+    for snr in (-5.0, -1.0, 0.0, 1.0, 4.0):
+        info = random_info(rng, BG, Z)
+        crc = O.crc(name, info, K - crc_len) >> (32 - crc_len)
+        for j in range(crc_len // 8):
+            info[K // 8 - crc_len // 8 + j] = (crc >> (8 * (crc_len // 8 - 1 - j))) & 255
+        llrs.append(make_llr(rng, BG, Z, R, snr, info))
+    llrs.append(make_llr(rng, BG, Z, R, "rand"))
+    llrs.append(np.zeros_like(llrs[0]))
+    for it in (1, 2, 3, 8):
+        _compare(hip, BG, Z, R, llrs, it, 0, True, K, ct)
+    # E smaller than K (last bytes not covered)
+    _compare(hip, BG, Z, R, llrs, 8, 0, True, K - 8 * 5, ct)
+
+
+def test_survey_stage_vectors(hip):
+    """Supplementary vectors recorded from the survey-stage reference build (see tools/dev_make_survey_vectors.py
+    for their provenance: NOT the parity pin)."""
+    for v in load_survey_decoder_vectors():
+        pre = np.full((1, (v["out"].size + 3) // 4 * 4), 0x55, dtype=np.uint8)
+        n, out = hip.decode_batch_host(v["BG"], v["Z"], v["R"], v["llr"][None, :], numMaxIter=v["numMaxIter"],
+                                       outMode=v["outMode"], check_crc=v["use_crc"], E=v["E"], crc_type=v["crc_type"],
+                                       out=pre)
+        assert n[0] == v["n_iter"], v
+        assert np.array_equal(out[0], v["out"]), (v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"], v["use_crc"])
+
+
+def test_reference_entry_point_and_abort(hip):
+    """LDPCdecoder(), the symbol the reference's callers use, incl. the TB abort protocol (decoder.c:190-193,556-559)."""
+    BG, Z, R = 1, 176, 13
+    rng = np.random.default_rng(9)
+    good, bad = make_llr(rng, BG, Z, R, 2.0), make_llr(rng, BG, Z, R, "rand")
+    p = hip.make_dec_params(BG, Z, R, 8)
+    ab = hip.ldpc.decode_abort_t()
+    n, out = hip.LDPCdecoder(p, good, ab=ab)
+    n_ref, out_ref = O.decode(BG, Z, R, good, 8)
+    assert n == n_ref <= 8 and np.array_equal(out, out_ref) and not ab.failed
+    n, _ = hip.LDPCdecoder(p, bad, ab=ab)
+    assert n == 9 and ab.failed                       # failure raises the TB-wide flag
+    n, _ = hip.LDPCdecoder(p, good, ab=ab)
+    assert n == 10                                    # numMaxIter + 2: sibling segments bail out
+    # unaligned host pointers are fine
+    buf = np.zeros(good.size + 3, dtype=np.int8)
+    buf[3:] = good
+    n, out = hip.LDPCdecoder(p, buf[3:])
+    assert n == n_ref and np.array_equal(out, out_ref)
+
+
+def test_bad_parameters(hip):
+    with pytest.raises(RuntimeError):
+        hip.decode_batch_host(1, 17, 13, np.zeros((1, 68 * 17), np.int8))       # 17 is not a lifting size
+    with pytest.raises(KeyError):
+        hip.decode_batch_host(1, 16, 15, np.zeros((1, 68 * 16), np.int8))       # rate 1/5 does not exist for BG1
+    # zero blocks is a no-op
+    n, out = hip.decode_batch_host(1, 16, 13, np.zeros((0, 68 * 16), np.int8))
+    assert n.size == 0
+
+
+def test_full_size_batch_properties_device(hip):
+    """BASELINE config 2 at full size (1024 x BG1 Zc=384 R=1/3, 8-iteration cap) on device-resident buffers:
+    encode -> AWGN -> decode round trip, syndrome of every decoded block, linearity (decoding is
+    sign-symmetric: the all-zero code word with the same noise fails/succeeds identically), and a sample
+    checked bit-exactly against the oracle."""
+    import torch
+    BG, Z, R, n = 1, 384, 13, 1024
+    K = 22 * Z
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    info = torch.randint(0, 256, (n, K // 8), dtype=torch.uint8, device="cuda", generator=g)
+    coded = torch.empty((n, 66 * Z), dtype=torch.uint8, device="cuda")
+    hip.encode_batch_device(BG, Z, info, coded)
+    sigma = 1.0 / np.sqrt(2.0 * 10 ** (1.0 / 10.0))          # Es/N0 = 1 dB
+    noise = torch.randn((n, 66 * Z), device="cuda", generator=g) * sigma
+    def quant(y):
+        return torch.clamp(torch.floor(y / (sigma / 16.0)), -128, 127).to(torch.int8)
+    llr = torch.zeros((n, 68 * Z), dtype=torch.int8, device="cuda")
+    llr[:, 2 * Z:] = quant(1.0 - 2.0 * coded.float() + noise)
+    out = torch.zeros((n, 68 * Z // 8), dtype=torch.uint8, device="cuda")
+    it = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+    torch.cuda.synchronize()
+    it_h, out_h, info_h = it.cpu().numpy(), out.cpu().numpy(), info.cpu().numpy()
+    ok = it_h <= 8
+    assert ok.mean() > 0.99, ok.mean()
+    assert np.array_equal(out_h[ok][:, :K // 8], info_h[ok])                  # round trip
+    # decoded words of converged blocks satisfy every parity check (core columns = systematic + core parity)
+    for i in np.flatnonzero(ok)[:16]:
+        bits = np.unpackbits(out_h[i])[:26 * Z]
+        cw = O.encode(BG, Z, np.packbits(bits[:K]))
+        assert np.array_equal(cw[K - 2 * Z:K - 2 * Z + 4 * Z], bits[K:K + 4 * Z])
+    # bit-exact sample vs the oracle
+    llr_h = llr.cpu().numpy()
+    for i in list(range(0, n, 97)):
+        n_ref, out_ref = O.decode(BG, Z, R, llr_h[i], 8)
+        assert n_ref == it_h[i] and np.array_equal(out_ref, out_h[i]), i
+    # symmetry: same noise on the all-zero code word -> same pass counts, decoded word = 0
+    llr0 = torch.zeros_like(llr)
+    llr0[:, 2 * Z:] = quant(1.0 + noise * (1.0 - 2.0 * coded.float()))
+    # (multiplying the noise by the BPSK sign maps the channel of word c onto the channel of word 0;
+    #  floor() quantisation is not sign symmetric, so only statistics are compared)
+    out0 = torch.zeros_like(out)
+    it0 = torch.zeros_like(it)
+    hip.decode_batch_device(BG, Z, R, llr0, out0, it0, numMaxIter=8)
+    torch.cuda.synchronize()
+    ok0 = (it0 <= 8).cpu().numpy()
+    assert abs(ok0.mean() - ok.mean()) < 0.01
+    assert int(out0[torch.from_numpy(ok0).cuda()][:, :K // 8].max()) == 0
