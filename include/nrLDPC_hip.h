@@ -121,7 +121,7 @@ typedef struct nrLDPC_hip_dec_batch {
   int32_t *n_iter;            /* [n_blocks] return value of each block (same meaning as LDPCdecoder's) */
   int32_t mem;                /* NRLDPC_HIP_MEM_* for llr/out/n_iter alike */
   void *stream;               /* hipStream_t for DEVICE mem; NULL = HIP's default (null) stream */
-  int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code) */
+  int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code); 2 = fast kernel or error */
 } nrLDPC_hip_dec_batch_t;
 /* 0 on success, negative on bad parameters / HIP error.  DEVICE mem: asynchronous w.r.t. the host. */
 int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b);

@@ -83,6 +83,7 @@ int ensure_ready_locked()
     return set_error("NRLDPC_HIP_DEVICE out of range");
   HIP_TRY(hipSetDevice(g.device));
   HIP_TRY(ldpc_kernels_init());
+  HIP_TRY(ldpc_fast_kernel_init());
   static const uint32_t polys[4] = {0x864cfb00u, 0x80006300u, 0x10210000u, 0x9B000000u};
   for (int i = 0; i < 4; i++) {
     std::vector<uint32_t> t;
@@ -173,6 +174,19 @@ thread_local ThreadCtx tls_ctx;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+/* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it) */
+int launch_decoder(int kernel, const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t s)
+{
+  const bool fast_ok = hc.f_ok && ((reinterpret_cast<uintptr_t>(a.llr) | a.llr_stride) & 3) == 0;
+  if (kernel == 2 && !fast_ok)
+    return set_error("fast kernel not applicable (needs Zc % 4 == 0, Zc >= 8, 4-byte aligned LLR rows)");
+  if (kernel != 1 && fast_ok)
+    HIP_TRY(ldpc_launch_dec_fast(a, hc, n_blocks, s));
+  else
+    HIP_TRY(ldpc_launch_dec_generic(a, hc, n_blocks, s));
+  return 0;
+}
+
 int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_args &a)
 {
   a.code = ce->dev;
@@ -251,8 +265,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     a.out = b->out; a.out_stride = b->out_stride;
     a.n_iter = b->n_iter;
     hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
-    HIP_TRY(ldpc_launch_dec_generic(a, hc, b->n_blocks, s));
-    return 0;
+    return launch_decoder(b->kernel, a, hc, b->n_blocks, s);
   }
   /* host buffers: stage through this thread's pinned buffers, synchronous */
   ThreadCtx &c = tls_ctx;
@@ -265,7 +278,8 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
   a.llr = reinterpret_cast<const int8_t *>(c.d_in); a.llr_stride = (uint32_t)in_stride;
   a.out = reinterpret_cast<int8_t *>(c.d_out); a.out_stride = (uint32_t)out_stride;
   a.n_iter = c.d_iter;
-  HIP_TRY(ldpc_launch_dec_generic(a, hc, b->n_blocks, c.stream));
+  if (launch_decoder(b->kernel, a, hc, b->n_blocks, c.stream) != 0)
+    return -1;
   HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipMemcpyAsync(c.h_iter, c.d_iter, sizeof(int32_t) * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));

@@ -1,0 +1,209 @@
+/*
+ * ldpc_dec_fast_core.h -- per-thread bodies of the "fast" flooding min-sum decoder kernel (gfx950).
+ *
+ * Same decoder semantics as ldpc_dec_core.h (reference nrLDPC_decoder.c:206-880, rules listed there);
+ * different data layout and arithmetic:
+ *   - a thread owns 4 consecutive lanes of a lifted row (check-node phase) or 4 consecutive bits of a
+ *     column (bit-node phase); messages and APPs live in LDS as BIASED bytes b = v + 128 (= v ^ 0x80),
+ *     four to a dword, so one ds_read_b32 / ds_write_b32 moves four messages;
+ *   - the circularly shifted 4-byte window of a neighbour is fetched as two aligned dwords +
+ *     v_alignbyte_b32; APP rows are stored twice back to back (no modulo on t + shift), message rows
+ *     carry 4 wrap-around pad bytes;
+ *   - arithmetic runs on packed 16-bit pairs (v_pk_*_i16/u16): biased bytes are zero-extended with
+ *     v_perm_b32, the bias cancels in a' - r', sums of biased bytes cannot overflow 16 bits
+ *     (<= 31 * 255), saturation is done once per result.
+ * Bit-exactness argument for the rewritten min-sum (DESIGN.md "Kernel arithmetic"):
+ *   q = clamp(app - r, -127, 127) only enters as |q| (capped at 127) and sign(q); |q| = min(|app - r|, 127)
+ *   and sign(q) = sign(app - r), so the clamp is applied to the magnitude only.
+ *
+ * Host build (tests/emul) uses the same code with portable fall-backs for the gfx950 builtins.
+ */
+#ifndef LDPC_DEC_FAST_CORE_H
+#define LDPC_DEC_FAST_CORE_H
+#include "ldpc_dec_core.h"
+
+typedef short ldpc_v2i __attribute__((ext_vector_type(2)));
+typedef unsigned short ldpc_v2u __attribute__((ext_vector_type(2)));
+
+#if defined(__HIP_DEVICE_COMPILE__)
+LDPC_HD uint32_t ldpc_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+LDPC_HD uint32_t ldpc_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+LDPC_HD uint32_t ldpc_umulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+#else
+LDPC_HD uint32_t ldpc_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{ /* v_perm_b32: byte i of the result = byte sel[i] of {s0 (4..7), s1 (0..3)}; 0x0c -> 0x00 */
+  const uint64_t src = ((uint64_t)s0 << 32) | s1;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t s = (sel >> (8 * i)) & 0xff;
+    const uint32_t b = s <= 7 ? (uint32_t)((src >> (8 * s)) & 0xff) : (s == 0x0c ? 0u : 0xffu);
+    r |= b << (8 * i);
+  }
+  return r;
+}
+LDPC_HD uint32_t ldpc_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
+}
+LDPC_HD uint32_t ldpc_umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+#endif
+
+LDPC_HD ldpc_v2i ldpc_as_v2i(uint32_t x) { return __builtin_bit_cast(ldpc_v2i, x); }
+LDPC_HD uint32_t ldpc_as_u32(ldpc_v2i x) { return __builtin_bit_cast(uint32_t, x); }
+LDPC_HD ldpc_v2i ldpc_splat(int v) { return (ldpc_v2i){(short)v, (short)v}; }
+LDPC_HD ldpc_v2i ldpc_pmin(ldpc_v2i a, ldpc_v2i b) { return __builtin_elementwise_min(a, b); }
+LDPC_HD ldpc_v2i ldpc_pmax(ldpc_v2i a, ldpc_v2i b) { return __builtin_elementwise_max(a, b); }
+/* bytes 0,1 resp. 2,3 of w zero-extended into the two 16-bit halves */
+LDPC_HD ldpc_v2i ldpc_unpack_lo(uint32_t w) { return ldpc_as_v2i(ldpc_perm(0u, w, 0x0c010c00u)); }
+LDPC_HD ldpc_v2i ldpc_unpack_hi(uint32_t w) { return ldpc_as_v2i(ldpc_perm(0u, w, 0x0c030c02u)); }
+/* low bytes of the four 16-bit halves of (lo, hi) -> one dword */
+LDPC_HD uint32_t ldpc_pack4(ldpc_v2i lo, ldpc_v2i hi) { return ldpc_perm(ldpc_as_u32(hi), ldpc_as_u32(lo), 0x06040200u); }
+
+/* LDS views used by the fast kernel (byte pointers into the workgroup's LDS) */
+struct ldpc_fast_lds {
+  uint8_t *r;    /* [nedges][Z+4]  biased check-to-bit messages (+4 wrap bytes) */
+  uint8_t *app;  /* [ncore][2Z]    biased clamped APP, stored twice */
+  uint8_t *ext;  /* [ncols-ncore][Z] biased channel LLR of the degree-1 columns */
+  const uint32_t *etbl, *ctbl, *rowtbl, *coltbl;
+};
+
+/* unaligned 4-byte window starting at byte offset `off` of `base` (base 4-aligned) */
+LDPC_HD uint32_t ldpc_window(const uint8_t *base, int off)
+{
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (off & ~3));
+  return ldpc_alignbyte(p[1], p[0], (uint32_t)off);
+}
+
+/* One check-node item: lifted row with first edge e0, lanes t..t+3 (t = 4j).  D = row degree; EXT = the
+ * last edge goes to the row's degree-1 column.  Returns a 4-bit mask: bit i set = the parity of the
+ * previous pass' hard decisions of lane t+i is odd. */
+template <int D, bool EXT>
+LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
+{
+  const int t = 4 * j;
+  ldpc_v2i d_lo[D], d_hi[D];
+  ldpc_v2i m1l = ldpc_splat(255), m2l = ldpc_splat(255), m1h = ldpc_splat(255), m2h = ldpc_splat(255);
+  uint32_t sxl = 0, sxh = 0, parw = 0, extl = 0, exth = 0;
+  const ldpc_v2i c127 = ldpc_splat(127), zero = ldpc_splat(0);
+  uint8_t *rrow = L.r + e0 * rstride + t;
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    const uint32_t info = L.etbl[e0 + k];
+    const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
+    ldpc_v2i al, ah, rl, rh;
+    if (EXT && k == D - 1) {
+      const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.ext + info + t);
+      al = ldpc_unpack_lo(lw);
+      ah = ldpc_unpack_hi(lw);
+      /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
+      extl = ldpc_as_u32(al + ldpc_unpack_lo(rw));
+      exth = ldpc_as_u32(ah + ldpc_unpack_hi(rw));
+      rl = ldpc_splat(128); /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
+      rh = ldpc_splat(128);
+    } else {
+      const uint32_t aw = ldpc_window(L.app, (int)info + t);
+      parw ^= aw;
+      al = ldpc_unpack_lo(aw);
+      ah = ldpc_unpack_hi(aw);
+      rl = ldpc_unpack_lo(rw);
+      rh = ldpc_unpack_hi(rw);
+    }
+    const ldpc_v2i dl = al - rl, dh = ah - rh; /* app - r, exact */
+    d_lo[k] = dl;
+    d_hi[k] = dh;
+    const ldpc_v2i ml = ldpc_pmin(ldpc_pmax(dl, zero - dl), c127), mh = ldpc_pmin(ldpc_pmax(dh, zero - dh), c127);
+    sxl ^= ldpc_as_u32(dl);
+    sxh ^= ldpc_as_u32(dh);
+    m2l = ldpc_pmin(m2l, ldpc_pmax(m1l, ml));
+    m1l = ldpc_pmin(m1l, ml);
+    m2h = ldpc_pmin(m2h, ldpc_pmax(m1h, mh));
+    m1h = ldpc_pmin(m1h, mh);
+  }
+  const ldpc_v2i sl = m1l + m2l, sh = m1h + m2h;
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    const ldpc_v2i dl = d_lo[k], dh = d_hi[k];
+    const ldpc_v2i ml = ldpc_pmin(ldpc_pmax(dl, zero - dl), c127), mh = ldpc_pmin(ldpc_pmax(dh, zero - dh), c127);
+    const ldpc_v2i ol = sl - ldpc_pmin(ml, m2l), oh = sh - ldpc_pmin(mh, m2h);
+    /* sign of the product of the other edges' signs = sign bit of (xor of all) ^ own; zero inputs give o = 0 */
+    const ldpc_v2i gl = ldpc_as_v2i(sxl ^ ldpc_as_u32(dl)) >> 15, gh = ldpc_as_v2i(sxh ^ ldpc_as_u32(dh)) >> 15;
+    const ldpc_v2i nl = (ol ^ gl) - gl, nh = (oh ^ gh) - gh;
+    const uint32_t w = ldpc_pack4(nl, nh) ^ 0x80808080u;
+    *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
+    if (j == 0)
+      *reinterpret_cast<uint32_t *>(rrow + k * rstride + Z) = w; /* wrap-around copy of lanes 0..3 */
+  }
+  /* per lane: number of "not negative" neighbours mod 2, from bit 7 of the biased APP bytes and bit 8 of
+   * the extension sums; parity of the hard decisions = that ^ (D & 1) */
+  uint32_t np = (parw >> 7) & 0x01010101u;
+  if (EXT) {
+    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
+    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
+  }
+  if (D & 1)
+    np ^= 0x01010101u;
+  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+}
+
+/* dispatch on the task's (wave-uniform) degree */
+LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
+{
+  if (!ext) {
+    switch (deg) {
+      case 19: return ldpc_fast_cn<19, false>(L, e0, j, Z, rstride);
+      case 10: return ldpc_fast_cn<10, false>(L, e0, j, Z, rstride);
+      default: return ldpc_fast_cn<8, false>(L, e0, j, Z, rstride);
+    }
+  }
+  switch (deg) {
+    case 3: return ldpc_fast_cn<3, true>(L, e0, j, Z, rstride);
+    case 4: return ldpc_fast_cn<4, true>(L, e0, j, Z, rstride);
+    case 5: return ldpc_fast_cn<5, true>(L, e0, j, Z, rstride);
+    case 6: return ldpc_fast_cn<6, true>(L, e0, j, Z, rstride);
+    case 7: return ldpc_fast_cn<7, true>(L, e0, j, Z, rstride);
+    case 8: return ldpc_fast_cn<8, true>(L, e0, j, Z, rstride);
+    case 9: return ldpc_fast_cn<9, true>(L, e0, j, Z, rstride);
+    default: return ldpc_fast_cn<10, true>(L, e0, j, Z, rstride);
+  }
+}
+
+/* One bit-node item: core column c, bits u..u+3 (u = 4j): APP = clamp_s8(llr + sum r) (bnProc.h:136-160).
+ * colrec = f_coltbl entry of the column; maxdeg = wave-uniform loop bound >= the column's degree;
+ * llr_word = the four channel LLRs (true int8 bytes). */
+LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, int j, int Z, int astride,
+                          uint32_t llr_word)
+{
+  const int u = 4 * j;
+  const int c = (int)(colrec & 0xffu), deg = (int)((colrec >> 8) & 0xffu), start = (int)(colrec >> 16);
+  uint32_t acc_e = 0, acc_o = 0; /* packed 16-bit sums of the biased bytes: lanes (0,2) and (1,3) */
+  for (int k = 0; k < maxdeg; k++) {
+    if (k < deg) {
+      const uint32_t ce = L.ctbl[start + k];
+      const int s = (int)(ce & 0x1ffu), roff = (int)(ce >> 9);
+      int p = u - s;
+      p = p < 0 ? p + Z : p;
+      const uint32_t w = ldpc_window(L.r + roff, p);
+      acc_e += w & 0x00ff00ffu;
+      acc_o += (w >> 8) & 0x00ff00ffu;
+    }
+  }
+  const uint32_t lw = llr_word ^ 0x80808080u;
+  acc_e += lw & 0x00ff00ffu;
+  acc_o += (lw >> 8) & 0x00ff00ffu;
+  const ldpc_v2i bias = ldpc_splat((deg + 1) * 128), lo = ldpc_splat(-128), hi = ldpc_splat(127), b128 = ldpc_splat(128);
+  const ldpc_v2i ve = ldpc_pmin(ldpc_pmax(ldpc_as_v2i(acc_e) - bias, lo), hi) + b128;
+  const ldpc_v2i vo = ldpc_pmin(ldpc_pmax(ldpc_as_v2i(acc_o) - bias, lo), hi) + b128;
+  /* bytes: lane0 = ve.lo, lane1 = vo.lo, lane2 = ve.hi, lane3 = vo.hi */
+  const uint32_t w = ldpc_perm(ldpc_as_u32(vo), ldpc_as_u32(ve), 0x06020400u);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + u);
+  dst[0] = w;
+  *reinterpret_cast<uint32_t *>(L.app + c * astride + u + Z) = w;
+}
+
+/* hard decision of code bit `b` (< ncore*Z) from the biased APP store */
+LDPC_HD int ldpc_fast_hd(const ldpc_fast_lds &L, int b, int Z, uint32_t zmagic, int astride)
+{
+  const int c = (int)ldpc_umulhi((uint32_t)b, zmagic), u = b - c * Z;
+  return L.app[c * astride + u] < 128;
+}
+#endif

@@ -1,0 +1,175 @@
+/*
+ * ldpc_decoder_fast.hip -- "fast" NR LDPC flooding min-sum decoder kernel for gfx950 (MI355X).
+ *
+ * Same contract as the generic kernel (ldpc_decoder.hip; reference nrLDPC_decoder.c:206-880), one
+ * workgroup per code block, everything resident in LDS between the LLR load and the bit store.
+ * What differs is the work decomposition (ldpc_dec_fast_core.h): 4 lanes per thread, biased-byte
+ * messages moved as dwords, packed 16-bit arithmetic, degree-sorted 64-item tasks balanced over the
+ * waves by the host (ldpc_graph.c build_fast_section).  Requires Zc % 4 == 0 and 4-byte aligned LLR rows;
+ * other cases are served by the generic kernel.
+ */
+#include <hip/hip_runtime.h>
+#include "ldpc_kernels.h"
+#include "ldpc_dec_fast_core.h"
+
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
+  const uint32_t zq_magic = code->f_zq_magic;
+  const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u; /* ceil(2^32 / Z) for Z not a power of two, exact enough
+                                                               for b < 2^16 either way (checked on the host) */
+  ldpc_fast_lds L;
+  L.r = fsm + code->f_lds_r;
+  L.app = fsm + code->f_lds_app;
+  L.ext = fsm + code->f_lds_ext;
+  uint32_t *etbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_etbl);
+  uint32_t *ctbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_ctbl);
+  uint32_t *rowtbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_rowtbl);
+  uint32_t *coltbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_coltbl);
+  L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
+  int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int wave = LDPC_UNIFORM(tid >> 6);
+  const uint32_t blk = blockIdx.x;
+  const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
+  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (size_t)blk * a.llr_stride);
+
+  /* ---- tables and state into LDS -------------------------------------------------------------------- */
+  for (int i = tid; i < nedges; i += nt)
+    etbl[i] = code->f_etbl[i];
+  for (int i = tid; i < code->col_ptr[ncore]; i += nt)
+    ctbl[i] = code->f_ctbl[i];
+  for (int i = tid; i < code->nrows; i += nt)
+    rowtbl[i] = code->f_rowtbl[i];
+  for (int i = tid; i < ncore; i += nt)
+    coltbl[i] = code->f_coltbl[i];
+  if (tid < 4)
+    flags[tid] = 0;
+  /* APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
+  for (int i = tid; i < ncore * zq; i += nt) {
+    const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+    const uint32_t w = src32[i] ^ 0x80808080u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
+    dst[0] = w;
+    dst[zq] = w;
+  }
+  {
+    const int next4 = (code->ncols - ncore) * zq;
+    uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
+    for (int i = tid; i < next4; i += nt)
+      e32[i] = src32[ncore * zq + i] ^ 0x80808080u;
+    const int nr4 = (nedges * rstride) >> 2;
+    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
+    for (int i = tid; i < nr4; i += nt)
+      r32[i] = 0x80808080u;
+  }
+  __syncthreads();
+
+  /* ---- passes ------------------------------------------------------------------------------------------ */
+  const int max_pass = a.num_max_iter + 1;
+  int n_iter = max_pass;
+  const int cn0 = code->f_cn_ptr[wave], cn1 = code->f_cn_ptr[wave + 1];
+  const int bn0 = code->f_bn_ptr[wave], bn1 = code->f_bn_ptr[wave + 1];
+  for (int p = 1; p <= max_pass; ++p) {
+    uint32_t syn = 0;
+    for (int ti = cn0; ti < cn1; ti++) {
+      const int task = LDPC_UNIFORM(code->f_cn_list[ti]);
+      const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+      const int item = code->f_cn_task[task][2] + lane;
+      const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
+      if (item < gend) {
+        const int gi = item - gstart;
+        const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
+        const uint32_t rowrec = rowtbl[srow0 + rig];
+        const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
+        const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
+        const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+        syn |= m & mask;
+      }
+    }
+    if (__any(syn != 0) && lane == 0)
+      flags[p & 1] = 1;
+    if (tid == 0)
+      flags[2] = 0;
+    __syncthreads();
+    if (!a.use_crc && p >= 3 && flags[p & 1] == 0) {
+      n_iter = p - 1;
+      break;
+    }
+    for (int ti = bn0; ti < bn1; ti++) {
+      const int task = LDPC_UNIFORM(code->f_bn_list[ti]);
+      const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+      const int maxdeg = code->f_bn_task[task][2];
+      if (item < end) {
+        const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
+        const uint32_t colrec = coltbl[sc];
+        const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
+        ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+      }
+    }
+    if (tid == 0)
+      flags[(p + 1) & 1] = 0;
+    __syncthreads();
+    if (a.use_crc && p >= 3) { /* see ldpc_decoder.hip for the CRC argument */
+      uint32_t x = 0;
+      for (int i = tid; i < a.E; i += nt)
+        if (ldpc_fast_hd(L, i, Z, z_magic, astride))
+          x ^= a.crc_pow[a.E - 1 - i];
+      for (int off = 32; off; off >>= 1)
+        x ^= __shfl_xor(x, off);
+      if (lane == 0 && x)
+        atomicXor(reinterpret_cast<unsigned int *>(&flags[2]), x);
+      __syncthreads();
+      const int rem = flags[2];
+      __syncthreads();
+      if (rem == 0) {
+        n_iter = p;
+        break;
+      }
+    }
+  }
+
+  /* ---- hard decision ------------------------------------------------------------------------------------- */
+  if (!a.use_crc || n_iter >= 3) {
+    if (a.out_mode == 0) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (size_t)blk * a.out_stride);
+      const int nwords = (num_llr + 31) >> 5;
+      for (int w = tid; w < nwords; w += nt) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
+          if (b < ncz) {
+            const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+            const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+            word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
+          }
+        }
+        o[w] = word;
+      }
+    } else {
+      int8_t *o = a.out + (size_t)blk * a.out_stride;
+      for (int i = tid; i < num_llr; i += nt)
+        o[i] = (i < ncz) ? (int8_t)ldpc_fast_hd(L, i, Z, z_magic, astride) : (int8_t)0;
+    }
+  }
+  if (tid == 0)
+    a.n_iter[blk] = n_iter;
+}
+
+hipError_t ldpc_fast_kernel_init(void)
+{
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(ldpc_dec_fast_kernel, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}

@@ -38,6 +38,147 @@ static int by_key_desc(const void *pa, const void *pb)
 
 static int align16(int x) { return (x + 15) & ~15; }
 
+/* longest-processing-time-first assignment of `n` tasks (cost[i]) to `nw` waves; fills ptr[nw+1], list[n] */
+static void lpt_assign(int n, const int *cost, int nw, int32_t *ptr, int32_t *list)
+{
+  sort_item_t it[LDPC_F_MAX_CN_TASKS];
+  int load[LDPC_F_MAX_WAVES], cnt[LDPC_F_MAX_WAVES], owner[LDPC_F_MAX_CN_TASKS];
+  for (int i = 0; i < n; i++) {
+    it[i].key = cost[i];
+    it[i].id = i;
+  }
+  qsort(it, n, sizeof(it[0]), by_key_desc);
+  memset(load, 0, sizeof(load));
+  memset(cnt, 0, sizeof(cnt));
+  for (int i = 0; i < n; i++) {
+    int best = 0;
+    for (int w = 1; w < nw; w++)
+      if (load[w] < load[best])
+        best = w;
+    owner[i] = best;
+    load[best] += it[i].key;
+    cnt[best]++;
+  }
+  ptr[0] = 0;
+  for (int w = 0; w < nw; w++)
+    ptr[w + 1] = ptr[w] + cnt[w];
+  int fill[LDPC_F_MAX_WAVES];
+  memset(fill, 0, sizeof(fill));
+  for (int i = 0; i < n; i++) /* sorted order is kept inside a wave: its most expensive task first */
+    list[ptr[owner[i]] + fill[owner[i]]++] = it[i].id;
+}
+
+/* schedules and tables of the "fast" decoder kernel (see ldpc_graph.h) */
+static void build_fast_section(ldpc_code_desc_t *d)
+{
+  const int Z = d->Z;
+  d->f_ok = 0;
+  if ((Z & 3) || Z < 8)
+    return;
+  const int zq = Z / 4;
+  d->f_zq = zq;
+  d->f_zq_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq - 1) / (uint64_t)zq);
+  d->f_rstride = Z + 4;
+  d->f_astride = 2 * Z;
+  int ncore_edges = d->col_ptr[d->ncore];
+
+  /* rows sorted by degree (descending, stable) */
+  sort_item_t rows[LDPC_MAX_ROWS];
+  for (int r = 0; r < d->nrows; r++) {
+    rows[r].key = d->row_deg[r];
+    rows[r].id = r;
+  }
+  qsort(rows, d->nrows, sizeof(rows[0]), by_key_desc);
+  for (int i = 0; i < d->nrows; i++)
+    d->f_rowtbl[i] = (uint32_t)d->row_ptr[rows[i].id] | ((uint32_t)d->pc_lo[rows[i].id] << 16);
+  /* edge table */
+  for (int e = 0; e < d->nedges; e++) {
+    const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
+    d->f_etbl[e] = c < d->ncore ? (uint32_t)(c * d->f_astride + s) : (uint32_t)((c - d->ncore) * Z);
+  }
+  /* CN tasks: one degree group after the other, 64 items per task */
+  int nt = 0, item = 0, cost[LDPC_F_MAX_CN_TASKS];
+  for (int i = 0; i < d->nrows;) {
+    int j = i;
+    while (j < d->nrows && rows[j].key == rows[i].key)
+      j++;
+    const int gstart = item, gend = item + (j - i) * zq;
+    for (int b = gstart; b < gend; b += 64) {
+      if (nt >= LDPC_F_MAX_CN_TASKS)
+        return;
+      d->f_cn_task[nt][0] = rows[i].key;
+      d->f_cn_task[nt][1] = rows[i].id >= 4; /* rows of one degree group are all core or all extension rows? checked below */
+      d->f_cn_task[nt][2] = b;
+      d->f_cn_task[nt][3] = gstart;
+      d->f_cn_task[nt][4] = gend;
+      d->f_cn_task[nt][5] = i;
+      cost[nt] = rows[i].key;
+      nt++;
+    }
+    /* a degree group must not mix core rows (no extension column) with extension rows */
+    for (int k = i; k < j; k++)
+      if ((rows[k].id >= 4) != (rows[i].id >= 4))
+        return;
+    item = gend;
+    i = j;
+  }
+  d->f_n_cn_tasks = nt;
+  int waves = (nt + 3) / 4;
+  if (waves < 1) waves = 1;
+  if (waves > LDPC_F_MAX_WAVES) waves = LDPC_F_MAX_WAVES;
+  d->f_n_threads = waves * 64;
+  lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
+
+  /* columns sorted by degree (descending), their adjacency, BN tasks */
+  sort_item_t cols[LDPC_MAX_CORE];
+  for (int c = 0; c < d->ncore; c++) {
+    cols[c].key = d->col_ptr[c + 1] - d->col_ptr[c];
+    cols[c].id = c;
+  }
+  qsort(cols, d->ncore, sizeof(cols[0]), by_key_desc);
+  int n = 0;
+  for (int i = 0; i < d->ncore; i++) {
+    const int c = cols[i].id;
+    d->f_coltbl[i] = (uint32_t)c | ((uint32_t)cols[i].key << 8) | ((uint32_t)n << 16);
+    for (int k = d->col_ptr[c]; k < d->col_ptr[c + 1]; k++) {
+      const uint32_t ce = d->col_edge[k];
+      d->f_ctbl[n++] = (((ce >> 16) * (uint32_t)d->f_rstride) << 9) | (ce & 0xffffu);
+    }
+  }
+  const int nitems = d->ncore * zq;
+  int nb = 0, bcost[LDPC_F_MAX_CN_TASKS];
+  for (int b = 0; b < nitems; b += 64) {
+    if (nb >= LDPC_F_MAX_BN_TASKS)
+      return;
+    d->f_bn_task[nb][0] = b;
+    d->f_bn_task[nb][1] = nitems;
+    d->f_bn_task[nb][2] = cols[b / zq].key;
+    bcost[nb] = cols[b / zq].key + 3; /* + finalisation */
+    nb++;
+  }
+  d->f_n_bn_tasks = nb;
+  lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
+
+  /* the magic division must be exact for every item index that occurs */
+  const int max_item = d->nrows * zq > nitems ? d->nrows * zq : nitems;
+  for (int i = 0; i < max_item + 64; i++)
+    if ((int)(((uint64_t)i * d->f_zq_magic) >> 32) != i / zq)
+      return;
+
+  d->f_lds_r = 0;
+  d->f_lds_app = align16(d->nedges * d->f_rstride);
+  d->f_lds_ext = d->f_lds_app + align16(d->ncore * d->f_astride);
+  d->f_lds_etbl = d->f_lds_ext + align16((d->ncols - d->ncore) * Z);
+  d->f_lds_ctbl = d->f_lds_etbl + align16(d->nedges * 4);
+  d->f_lds_rowtbl = d->f_lds_ctbl + align16(ncore_edges * 4);
+  d->f_lds_coltbl = d->f_lds_rowtbl + align16(d->nrows * 4);
+  d->f_lds_misc = d->f_lds_coltbl + align16(d->ncore * 4);
+  d->f_lds_total = d->f_lds_misc + 64;
+  if (d->f_lds_total > 160 * 1024)
+    return;
+  d->f_ok = 1;
+}
+
 int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d)
 {
   const int ils = ldpc_lifting_set_index(Z);
@@ -202,5 +343,6 @@ int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d)
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;
   d->n_threads = waves * 64;
+  build_fast_section(d);
   return 0;
 }

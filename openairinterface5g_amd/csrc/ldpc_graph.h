@@ -19,6 +19,9 @@
 #define LDPC_MAX_EDGES 316
 #define LDPC_MAX_Z 384
 #define LDPC_MAX_ZW 6 /* ceil(384/64) wavefront-wide chunks per lifted row */
+#define LDPC_F_MAX_WAVES 16
+#define LDPC_F_MAX_CN_TASKS 96
+#define LDPC_F_MAX_BN_TASKS 48
 
 typedef struct ldpc_code_desc {
   int32_t BG, Z, R, ils;
@@ -57,6 +60,32 @@ typedef struct ldpc_code_desc {
    *   acc[t] = lambda_row[t] ^ XOR_k p_{kcol[k]}[(t + kshift[k]) mod Z];  p_unk[(t + ushift) mod Z] = acc[t] */
   int32_t enc_p0_shift;
   int32_t enc_row[3], enc_unk[3], enc_ushift[3], enc_nk[3], enc_kcol[3][4], enc_kshift[3][4];
+
+  /* ---- "fast" decoder kernel: 4 consecutive lanes per thread, messages as biased bytes (v + 128) packed
+   * four to a dword, arithmetic on packed 16-bit pairs.  Usable when f_ok (Z % 4 == 0, Z >= 8, fits LDS).
+   * Work item = (lifted row, 4-lane group) resp. (core column, 4-lane group); Z/4 items per row/column.
+   * Rows are sorted by degree and their items flattened per degree group, columns likewise; a task is 64
+   * consecutive items (one wavefront, uniform degree / loop bound); tasks are spread over the waves of
+   * the workgroup by longest-processing-time-first. */
+  int32_t f_ok;
+  int32_t f_zq;        /* Z/4 */
+  uint32_t f_zq_magic; /* ceil(2^32 / zq): i / zq == umulhi(i, magic) for every item index i that occurs */
+  int32_t f_rstride;   /* Z + 4: bytes per message row, the first 4 bytes repeated at the end (wrap-around window) */
+  int32_t f_astride;   /* 2Z: bytes per APP row, stored twice back to back so that (t + shift) needs no modulo */
+  int32_t f_lds_r, f_lds_app, f_lds_ext, f_lds_etbl, f_lds_ctbl, f_lds_rowtbl, f_lds_coltbl, f_lds_misc, f_lds_total;
+  int32_t f_n_threads;
+  int32_t f_n_cn_tasks, f_n_bn_tasks;
+  int32_t f_cn_ptr[LDPC_F_MAX_WAVES + 1], f_bn_ptr[LDPC_F_MAX_WAVES + 1]; /* wave w runs list[ptr[w] .. ptr[w+1]) */
+  int32_t f_cn_list[LDPC_F_MAX_CN_TASKS], f_bn_list[LDPC_F_MAX_BN_TASKS];
+  /* CN task: {degree, has_ext, first item, group first item, group end item, sorted-row index of the group's first row} */
+  int32_t f_cn_task[LDPC_F_MAX_CN_TASKS][6];
+  /* BN task: {first item, end item (all columns), loop bound = degree of the first item's column} */
+  int32_t f_bn_task[LDPC_F_MAX_BN_TASKS][3];
+  /* tables the kernel copies into LDS (read per lane): */
+  uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge | pc_lo << 16 */
+  uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: core column: col*astride + shift; extension column: (col-ncore)*Z */
+  uint32_t f_coltbl[LDPC_MAX_CORE + 2];  /* per sorted column: col | degree << 8 | first entry in f_ctbl << 16 */
+  uint32_t f_ctbl[LDPC_MAX_EDGES + 4];   /* per (sorted column, edge): (edge*rstride) << 9 | shift */
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus

@@ -37,6 +37,10 @@ hipError_t ldpc_kernels_init(void);
 /* generic flooding min-sum decoder: one workgroup per code block, any (BG, Z, R) */
 hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                    hipStream_t stream);
+/* fast decoder (Zc % 4 == 0, 4-byte aligned LLR rows, hc.f_ok): one workgroup per code block */
+hipError_t ldpc_fast_kernel_init(void);
+hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
+                                hipStream_t stream);
 /* encoder: one workgroup per code block */
 hipError_t ldpc_launch_enc(const ldpc_enc_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                            hipStream_t stream);

@@ -8,15 +8,22 @@ from common import ALL_RATES, kbits, load_survey_decoder_vectors, make_llr, rand
 pytestmark = pytest.mark.gpu
 
 
+def kernels_for(Z):
+    """1 = generic kernel (any code), 2 = fast kernel (Zc % 4 == 0, Zc >= 8); both must match the oracle."""
+    return (1, 2) if (Z % 4 == 0 and Z >= 8) else (1,)
+
+
 def _compare(hip, BG, Z, R, llrs, it, mode=0, use_crc=False, E=0, ct=1):
     llr = np.stack(llrs)
     pre = np.full((llr.shape[0], (hip.ldpc.out_bytes(BG, Z, R, mode) + 3) // 4 * 4), 0x33, dtype=np.uint8)
-    n_gpu, out_gpu = hip.decode_batch_host(BG, Z, R, llr, numMaxIter=it, outMode=mode, check_crc=use_crc, E=E,
-                                           crc_type=ct, out=pre.copy())
-    for i in range(llr.shape[0]):
-        n_ref, out_ref = O.decode(BG, Z, R, llr[i], it, mode, use_crc, E, ct, out_init=0x33)
-        assert n_ref == n_gpu[i], (BG, Z, R, it, mode, use_crc, i, n_ref, int(n_gpu[i]))
-        assert np.array_equal(out_ref, out_gpu[i]), (BG, Z, R, it, mode, use_crc, i)
+    refs = [O.decode(BG, Z, R, llr[i], it, mode, use_crc, E, ct, out_init=0x33) for i in range(llr.shape[0])]
+    for kern in kernels_for(Z):
+        n_gpu, out_gpu = hip.decode_batch_host(BG, Z, R, llr, numMaxIter=it, outMode=mode, check_crc=use_crc, E=E,
+                                               crc_type=ct, out=pre.copy(), kernel=kern)
+        for i in range(llr.shape[0]):
+            n_ref, out_ref = refs[i]
+            assert n_ref == n_gpu[i], (kern, BG, Z, R, it, mode, use_crc, i, n_ref, int(n_gpu[i]))
+            assert np.array_equal(out_ref, out_gpu[i]), (kern, BG, Z, R, it, mode, use_crc, i)
 
 
 @pytest.mark.parametrize("BG", [1, 2])
@@ -72,12 +79,13 @@ def test_survey_stage_vectors(hip):
     """Supplementary vectors recorded from the survey-stage reference build (see tools/dev_make_survey_vectors.py
     for their provenance: NOT the parity pin)."""
     for v in load_survey_decoder_vectors():
-        pre = np.full((1, (v["out"].size + 3) // 4 * 4), 0x55, dtype=np.uint8)
-        n, out = hip.decode_batch_host(v["BG"], v["Z"], v["R"], v["llr"][None, :], numMaxIter=v["numMaxIter"],
-                                       outMode=v["outMode"], check_crc=v["use_crc"], E=v["E"], crc_type=v["crc_type"],
-                                       out=pre)
-        assert n[0] == v["n_iter"], v
-        assert np.array_equal(out[0], v["out"]), (v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"], v["use_crc"])
+        for kern in kernels_for(v["Z"]):
+            pre = np.full((1, (v["out"].size + 3) // 4 * 4), 0x55, dtype=np.uint8)
+            n, out = hip.decode_batch_host(v["BG"], v["Z"], v["R"], v["llr"][None, :], numMaxIter=v["numMaxIter"],
+                                           outMode=v["outMode"], check_crc=v["use_crc"], E=v["E"],
+                                           crc_type=v["crc_type"], out=pre, kernel=kern)
+            assert n[0] == v["n_iter"], (kern, v)
+            assert np.array_equal(out[0], v["out"]), (kern, v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"])
 
 
 def test_reference_entry_point_and_abort(hip):
@@ -131,8 +139,11 @@ def test_full_size_batch_properties_device(hip):
     llr[:, 2 * Z:] = quant(1.0 - 2.0 * coded.float() + noise)
     out = torch.zeros((n, 68 * Z // 8), dtype=torch.uint8, device="cuda")
     it = torch.zeros(n, dtype=torch.int32, device="cuda")
-    hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+    out_g, it_g = torch.zeros_like(out), torch.zeros_like(it)
+    hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)               # best kernel (fast)
+    hip.decode_batch_device(BG, Z, R, llr, out_g, it_g, numMaxIter=8, kernel=1)  # generic kernel
     torch.cuda.synchronize()
+    assert torch.equal(out, out_g) and torch.equal(it, it_g)                   # the two kernels agree on all 1024 blocks
     it_h, out_h, info_h = it.cpu().numpy(), out.cpu().numpy(), info.cpu().numpy()
     ok = it_h <= 8
     assert ok.mean() > 0.99, ok.mean()
