@@ -47,7 +47,7 @@ class encoder_implemparams_t(C.Structure):
 
 class decode_abort_t(C.Structure):
     """openair1/PHY/defs_common.h:998-1001 (pthread_mutex_t is 40 bytes on x86-64 glibc; all-zero = initialised)"""
-    _fields_ = [("mutex_failure", C.c_uint8 * 40), ("failed", C.c_bool)]
+    _fields_ = [("mutex_failure", C.c_uint64 * 5), ("failed", C.c_bool)]
 
 
 class nrLDPC_hip_dec_batch_t(C.Structure):

@@ -251,3 +251,23 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
   }
   return n_iter;
 }
+
+/* product descriptor -> flat arrays, for tests/test_tables.py */
+extern "C" int ldpc_emul_desc_edges(int BG, int Z, int R, int *dims /*nrows,ncols,ncore,nedges,f_ok,lds_total,f_lds_total*/,
+                                    int *row_ptr, int *col, int *shift, int *pc_lo)
+{
+  ldpc_code_desc_t d;
+  if (ldpc_build_code_desc(BG, Z, R, &d) != 0)
+    return -1;
+  dims[0] = d.nrows; dims[1] = d.ncols; dims[2] = d.ncore; dims[3] = d.nedges; dims[4] = d.f_ok;
+  dims[5] = d.lds_total; dims[6] = d.f_lds_total;
+  for (int r = 0; r <= d.nrows; r++) row_ptr[r] = d.row_ptr[r];
+  for (int r = 0; r < d.nrows; r++) pc_lo[r] = d.pc_lo[r];
+  for (int e = 0; e < d.nedges; e++) {
+    col[e] = d.e_col[e];
+    shift[e] = (int)(d.e_info[e] & 0xffffu);
+    if ((int)(d.e_info[e] >> 16) != d.e_col[e] * Z)
+      return -2;
+  }
+  return 0;
+}
