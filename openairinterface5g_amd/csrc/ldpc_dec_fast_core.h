@@ -49,6 +49,11 @@ LDPC_HD uint32_t ldpc_umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint6
 #endif
 
 LDPC_HD ldpc_v2i ldpc_as_v2i(uint32_t x) { return __builtin_bit_cast(ldpc_v2i, x); }
+LDPC_HD ldpc_v2u ldpc_as_v2u(uint32_t x) { return __builtin_bit_cast(ldpc_v2u, x); }
+LDPC_HD uint32_t ldpc_u2u32(ldpc_v2u x) { return __builtin_bit_cast(uint32_t, x); }
+LDPC_HD ldpc_v2u ldpc_splatu(unsigned v) { return (ldpc_v2u){(unsigned short)v, (unsigned short)v}; }
+LDPC_HD ldpc_v2u ldpc_pminu(ldpc_v2u a, ldpc_v2u b) { return __builtin_elementwise_min(a, b); }
+LDPC_HD ldpc_v2u ldpc_pmaxu(ldpc_v2u a, ldpc_v2u b) { return __builtin_elementwise_max(a, b); }
 LDPC_HD uint32_t ldpc_as_u32(ldpc_v2i x) { return __builtin_bit_cast(uint32_t, x); }
 LDPC_HD ldpc_v2i ldpc_splat(int v) { return (ldpc_v2i){(short)v, (short)v}; }
 LDPC_HD ldpc_v2i ldpc_pmin(ldpc_v2i a, ldpc_v2i b) { return __builtin_elementwise_min(a, b); }
@@ -61,6 +66,7 @@ LDPC_HD uint32_t ldpc_pack4(ldpc_v2i lo, ldpc_v2i hi) { return ldpc_perm(ldpc_as
 
 /* LDS views used by the fast kernel (byte pointers into the workgroup's LDS) */
 struct ldpc_fast_lds {
+  uint8_t *base; /* start of the workgroup's LDS; f_etbl entries are byte offsets from here */
   uint8_t *r;    /* [nedges][Z+4]  biased check-to-bit messages (+4 wrap bytes) */
   uint8_t *app;  /* [ncore][2Z]    biased clamped APP, stored twice */
   uint8_t *ext;  /* [ncols-ncore][Z] biased channel LLR of the degree-1 columns */
@@ -75,63 +81,86 @@ LDPC_HD uint32_t ldpc_window(const uint8_t *base, int off)
 }
 
 /* One check-node item: lifted row with first edge e0, lanes t..t+3 (t = 4j).  D = row degree; EXT = the
- * last edge goes to the row's degree-1 column.  Returns a 4-bit mask: bit i set = the parity of the
- * previous pass' hard decisions of lane t+i is odd. */
-template <int D, bool EXT>
+ * last edge goes to the row's degree-1 column; KEEP = keep the per-edge magnitudes in registers between
+ * the two sweeps (false for the degree-19 rows, which would spill).  Returns a 4-bit mask: bit i set =
+ * the parity of the previous pass' hard decisions of lane t+i is odd.
+ *
+ * Arithmetic, per 16-bit half (two lanes per register, a' = app + 128, r' = r + 128 as stored):
+ *   D1 = (0x8000 | a') - r' = 0x8000 + d          d = app - r in [-255, 255]; bit 15 of D1 = (d >= 0)
+ *   D2 = 0x10000 - D1       = 0x8000 - d          (one 32-bit subtract: the low half always borrows)
+ *   M  = max_u16(D1, D2)    = 0x8000 + |d|        biased magnitude; running two smallest m1 <= m2
+ *   cap m1, m2 at 0x8000 + 127 once per check node (min(127, min_k |q_k|) = min_k min(127, |q_k|))
+ *   o_k = m1 + m2 - min(M_k, m2)  (= m2 if edge k holds the minimum, else m1), bias folded into the sum
+ *   sign_k = parity of the negative inputs among the other edges = bit 15 of (xor of all D1) ^ D1_k,
+ *            flipped when D-1 is odd (bit 15 counts the NON-negative ones)
+ * Only the packed min/max/shift/negate run on the half-rate packed-16 pipe; the rest are full-rate
+ * 32-bit ALU ops that cannot carry between the halves by construction. */
+template <int D, bool EXT, bool KEEP>
 LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
 {
   const int t = 4 * j;
-  ldpc_v2i d_lo[D], d_hi[D];
-  ldpc_v2i m1l = ldpc_splat(255), m2l = ldpc_splat(255), m1h = ldpc_splat(255), m2h = ldpc_splat(255);
+  uint32_t d_lo[D], d_hi[D], g_lo[KEEP ? D : 1], g_hi[KEEP ? D : 1];
+  ldpc_v2u m1l = ldpc_splatu(0xffff), m2l = m1l, m1h = m1l, m2h = m1l;
   uint32_t sxl = 0, sxh = 0, parw = 0, extl = 0, exth = 0;
-  const ldpc_v2i c127 = ldpc_splat(127), zero = ldpc_splat(0);
   uint8_t *rrow = L.r + e0 * rstride + t;
+  uint8_t *rpad = rrow + (j == 0 ? Z : 0); /* lanes 0..3 are written twice: wrap-around copy behind the row */
 #pragma unroll
   for (int k = 0; k < D; k++) {
     const uint32_t info = L.etbl[e0 + k];
     const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
-    ldpc_v2i al, ah, rl, rh;
+    uint32_t al, ah, rl, rh;
     if (EXT && k == D - 1) {
-      const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.ext + info + t);
-      al = ldpc_unpack_lo(lw);
-      ah = ldpc_unpack_hi(lw);
+      const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.base + info + t);
+      al = ldpc_perm(0x80808080u, lw, 0x05010400u);
+      ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
       /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
-      extl = ldpc_as_u32(al + ldpc_unpack_lo(rw));
-      exth = ldpc_as_u32(ah + ldpc_unpack_hi(rw));
-      rl = ldpc_splat(128); /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
-      rh = ldpc_splat(128);
+      extl = al + ldpc_perm(0u, rw, 0x0c010c00u);
+      exth = ah + ldpc_perm(0u, rw, 0x0c030c02u);
+      rl = 0x00800080u; /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
+      rh = 0x00800080u;
     } else {
-      const uint32_t aw = ldpc_window(L.app, (int)info + t);
+      const uint32_t aw = ldpc_window(L.base, (int)info + t);
       parw ^= aw;
-      al = ldpc_unpack_lo(aw);
-      ah = ldpc_unpack_hi(aw);
-      rl = ldpc_unpack_lo(rw);
-      rh = ldpc_unpack_hi(rw);
+      al = ldpc_perm(0x80808080u, aw, 0x05010400u); /* (0x8000 | byte 0), (0x8000 | byte 1) */
+      ah = ldpc_perm(0x80808080u, aw, 0x05030402u);
+      rl = ldpc_perm(0u, rw, 0x0c010c00u);
+      rh = ldpc_perm(0u, rw, 0x0c030c02u);
     }
-    const ldpc_v2i dl = al - rl, dh = ah - rh; /* app - r, exact */
+    const uint32_t dl = al - rl, dh = ah - rh;
     d_lo[k] = dl;
     d_hi[k] = dh;
-    const ldpc_v2i ml = ldpc_pmin(ldpc_pmax(dl, zero - dl), c127), mh = ldpc_pmin(ldpc_pmax(dh, zero - dh), c127);
-    sxl ^= ldpc_as_u32(dl);
-    sxh ^= ldpc_as_u32(dh);
-    m2l = ldpc_pmin(m2l, ldpc_pmax(m1l, ml));
-    m1l = ldpc_pmin(m1l, ml);
-    m2h = ldpc_pmin(m2h, ldpc_pmax(m1h, mh));
-    m1h = ldpc_pmin(m1h, mh);
+    const ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
+    const ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+    if (KEEP) {
+      g_lo[k] = ldpc_u2u32(ml);
+      g_hi[k] = ldpc_u2u32(mh);
+    }
+    sxl ^= dl;
+    sxh ^= dh;
+    m2l = ldpc_pminu(m2l, ldpc_pmaxu(m1l, ml));
+    m1l = ldpc_pminu(m1l, ml);
+    m2h = ldpc_pminu(m2h, ldpc_pmaxu(m1h, mh));
+    m1h = ldpc_pminu(m1h, mh);
   }
-  const ldpc_v2i sl = m1l + m2l, sh = m1h + m2h;
+  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
+  m1l = ldpc_pminu(m1l, cap); m2l = ldpc_pminu(m2l, cap);
+  m1h = ldpc_pminu(m1h, cap); m2h = ldpc_pminu(m2h, cap);
+  const uint32_t sl = (ldpc_u2u32(m1l) - 0x80008000u) + ldpc_u2u32(m2l), sh = (ldpc_u2u32(m1h) - 0x80008000u) + ldpc_u2u32(m2h);
+  if ((D - 1) & 1) {
+    sxl ^= 0x80008000u;
+    sxh ^= 0x80008000u;
+  }
 #pragma unroll
   for (int k = 0; k < D; k++) {
-    const ldpc_v2i dl = d_lo[k], dh = d_hi[k];
-    const ldpc_v2i ml = ldpc_pmin(ldpc_pmax(dl, zero - dl), c127), mh = ldpc_pmin(ldpc_pmax(dh, zero - dh), c127);
-    const ldpc_v2i ol = sl - ldpc_pmin(ml, m2l), oh = sh - ldpc_pmin(mh, m2h);
-    /* sign of the product of the other edges' signs = sign bit of (xor of all) ^ own; zero inputs give o = 0 */
-    const ldpc_v2i gl = ldpc_as_v2i(sxl ^ ldpc_as_u32(dl)) >> 15, gh = ldpc_as_v2i(sxh ^ ldpc_as_u32(dh)) >> 15;
-    const ldpc_v2i nl = (ol ^ gl) - gl, nh = (oh ^ gh) - gh;
+    const uint32_t dl = d_lo[k], dh = d_hi[k];
+    const ldpc_v2u ml = KEEP ? ldpc_as_v2u(g_lo[k]) : ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
+    const ldpc_v2u mh = KEEP ? ldpc_as_v2u(g_hi[k]) : ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+    const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h));
+    const ldpc_v2i gl = ldpc_as_v2i(sxl ^ dl) >> 15, gh = ldpc_as_v2i(sxh ^ dh) >> 15;
+    const ldpc_v2i nl = ldpc_as_v2i(ol ^ ldpc_as_u32(gl)) - gl, nh = ldpc_as_v2i(oh ^ ldpc_as_u32(gh)) - gh;
     const uint32_t w = ldpc_pack4(nl, nh) ^ 0x80808080u;
     *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
-    if (j == 0)
-      *reinterpret_cast<uint32_t *>(rrow + k * rstride + Z) = w; /* wrap-around copy of lanes 0..3 */
+    *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
   }
   /* per lane: number of "not negative" neighbours mod 2, from bit 7 of the biased APP bytes and bit 8 of
    * the extension sums; parity of the hard decisions = that ^ (D & 1) */
@@ -150,20 +179,20 @@ LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L,
 {
   if (!ext) {
     switch (deg) {
-      case 19: return ldpc_fast_cn<19, false>(L, e0, j, Z, rstride);
-      case 10: return ldpc_fast_cn<10, false>(L, e0, j, Z, rstride);
-      default: return ldpc_fast_cn<8, false>(L, e0, j, Z, rstride);
+      case 19: return ldpc_fast_cn<19, false, false>(L, e0, j, Z, rstride);
+      case 10: return ldpc_fast_cn<10, false, true>(L, e0, j, Z, rstride);
+      default: return ldpc_fast_cn<8, false, true>(L, e0, j, Z, rstride);
     }
   }
   switch (deg) {
-    case 3: return ldpc_fast_cn<3, true>(L, e0, j, Z, rstride);
-    case 4: return ldpc_fast_cn<4, true>(L, e0, j, Z, rstride);
-    case 5: return ldpc_fast_cn<5, true>(L, e0, j, Z, rstride);
-    case 6: return ldpc_fast_cn<6, true>(L, e0, j, Z, rstride);
-    case 7: return ldpc_fast_cn<7, true>(L, e0, j, Z, rstride);
-    case 8: return ldpc_fast_cn<8, true>(L, e0, j, Z, rstride);
-    case 9: return ldpc_fast_cn<9, true>(L, e0, j, Z, rstride);
-    default: return ldpc_fast_cn<10, true>(L, e0, j, Z, rstride);
+    case 3: return ldpc_fast_cn<3, true, true>(L, e0, j, Z, rstride);
+    case 4: return ldpc_fast_cn<4, true, true>(L, e0, j, Z, rstride);
+    case 5: return ldpc_fast_cn<5, true, true>(L, e0, j, Z, rstride);
+    case 6: return ldpc_fast_cn<6, true, true>(L, e0, j, Z, rstride);
+    case 7: return ldpc_fast_cn<7, true, true>(L, e0, j, Z, rstride);
+    case 8: return ldpc_fast_cn<8, true, true>(L, e0, j, Z, rstride);
+    case 9: return ldpc_fast_cn<9, true, true>(L, e0, j, Z, rstride);
+    default: return ldpc_fast_cn<10, true, true>(L, e0, j, Z, rstride);
   }
 }
 

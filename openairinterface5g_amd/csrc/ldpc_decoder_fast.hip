@@ -12,7 +12,8 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_core.h"
 
-__global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
+template <int MAX_THREADS>
+__global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
@@ -21,6 +22,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
   const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u; /* ceil(2^32 / Z) for Z not a power of two, exact enough
                                                                for b < 2^16 either way (checked on the host) */
   ldpc_fast_lds L;
+  L.base = fsm;
   L.r = fsm + code->f_lds_r;
   L.app = fsm + code->f_lds_app;
   L.ext = fsm + code->f_lds_ext;
@@ -162,7 +164,11 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess)
+    return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -170,6 +176,10 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
 {
   if (n_blocks == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(ldpc_dec_fast_kernel, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  /* up to 12 waves: 168 VGPRs per lane available (no spills in the degree-19 rows); 13..16 waves: 128 */
+  if (hc.f_n_threads <= 768)
+    hipLaunchKernelGGL(ldpc_dec_fast_kernel<768>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_kernel<1024>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }

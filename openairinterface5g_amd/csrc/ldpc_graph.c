@@ -91,11 +91,6 @@ static void build_fast_section(ldpc_code_desc_t *d)
   qsort(rows, d->nrows, sizeof(rows[0]), by_key_desc);
   for (int i = 0; i < d->nrows; i++)
     d->f_rowtbl[i] = (uint32_t)d->row_ptr[rows[i].id] | ((uint32_t)d->pc_lo[rows[i].id] << 16);
-  /* edge table */
-  for (int e = 0; e < d->nedges; e++) {
-    const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
-    d->f_etbl[e] = c < d->ncore ? (uint32_t)(c * d->f_astride + s) : (uint32_t)((c - d->ncore) * Z);
-  }
   /* CN tasks: one degree group after the other, 64 items per task */
   int nt = 0, item = 0, cost[LDPC_F_MAX_CN_TASKS];
   for (int i = 0; i < d->nrows;) {
@@ -125,7 +120,11 @@ static void build_fast_section(ldpc_code_desc_t *d)
   d->f_n_cn_tasks = nt;
   int waves = (nt + 3) / 4;
   if (waves < 1) waves = 1;
-  if (waves > LDPC_F_MAX_WAVES) waves = LDPC_F_MAX_WAVES;
+  int max_waves = LDPC_F_DEFAULT_WAVES;
+  const char *env = getenv("NRLDPC_HIP_FAST_WAVES"); /* tuning knob: waves per workgroup of the fast kernel */
+  if (env && atoi(env) >= 1 && atoi(env) <= LDPC_F_MAX_WAVES)
+    max_waves = atoi(env);
+  if (waves > max_waves) waves = max_waves;
   d->f_n_threads = waves * 64;
   lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
 
@@ -176,6 +175,12 @@ static void build_fast_section(ldpc_code_desc_t *d)
   d->f_lds_total = d->f_lds_misc + 64;
   if (d->f_lds_total > 160 * 1024)
     return;
+  /* edge table: absolute LDS byte offset of the neighbour's row start + shift */
+  for (int e = 0; e < d->nedges; e++) {
+    const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
+    d->f_etbl[e] = c < d->ncore ? (uint32_t)(d->f_lds_app + c * d->f_astride + s)
+                                : (uint32_t)(d->f_lds_ext + (c - d->ncore) * Z);
+  }
   d->f_ok = 1;
 }
 

@@ -20,6 +20,7 @@
 #define LDPC_MAX_Z 384
 #define LDPC_MAX_ZW 6 /* ceil(384/64) wavefront-wide chunks per lifted row */
 #define LDPC_F_MAX_WAVES 16
+#define LDPC_F_DEFAULT_WAVES 16 /* waves per workgroup the fast kernel uses for large codes */
 #define LDPC_F_MAX_CN_TASKS 96
 #define LDPC_F_MAX_BN_TASKS 48
 
@@ -83,7 +84,8 @@ typedef struct ldpc_code_desc {
   int32_t f_bn_task[LDPC_F_MAX_BN_TASKS][3];
   /* tables the kernel copies into LDS (read per lane): */
   uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge | pc_lo << 16 */
-  uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: core column: col*astride + shift; extension column: (col-ncore)*Z */
+  uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;
+                                            extension column: f_lds_ext + (col-ncore)*Z */
   uint32_t f_coltbl[LDPC_MAX_CORE + 2];  /* per sorted column: col | degree << 8 | first entry in f_ctbl << 16 */
   uint32_t f_ctbl[LDPC_MAX_EDGES + 4];   /* per (sorted column, edge): (edge*rstride) << 9 | shift */
 } ldpc_code_desc_t;

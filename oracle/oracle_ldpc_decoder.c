@@ -239,3 +239,40 @@ int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int us
   free(app);
   return (int)numIter;
 }
+
+/* ---- multi-threaded driver used by bench.py's cpu_baseline leg: the reference parallelises this path by
+ * one thread-pool job per code segment (openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:435-468); here block b
+ * is decoded by thread b % nthreads.  PC-stop mode, BIT output. */
+#include <pthread.h>
+typedef struct {
+  int tid, nthreads, nblocks, BG, Z, R, numMaxIter;
+  const int8_t *llr;
+  int llr_stride;
+  int8_t *out;
+  int out_stride;
+  int *iters;
+} mt_arg_t;
+static void *mt_worker(void *p)
+{
+  mt_arg_t *a = (mt_arg_t *)p;
+  for (int b = a->tid; b < a->nblocks; b += a->nthreads)
+    a->iters[b] = oracle_ldpc_decode(a->BG, a->Z, a->R, a->numMaxIter, ORACLE_OUT_BIT, 0, 0, 0,
+                                     a->llr + (size_t)b * a->llr_stride, a->out + (size_t)b * a->out_stride);
+  return NULL;
+}
+int oracle_ldpc_decode_mt(int nthreads, int nblocks, int BG, int Z, int R, int numMaxIter, const int8_t *llr,
+                          int llr_stride, int8_t *out, int out_stride, int *iters)
+{
+  if (nthreads < 1 || nthreads > 1024)
+    return -1;
+  pthread_t th[1024];
+  mt_arg_t args[1024];
+  for (int t = 0; t < nthreads; t++) {
+    args[t] = (mt_arg_t){t, nthreads, nblocks, BG, Z, R, numMaxIter, llr, llr_stride, out, out_stride, iters};
+    if (pthread_create(&th[t], NULL, mt_worker, &args[t]) != 0)
+      return -1;
+  }
+  for (int t = 0; t < nthreads; t++)
+    pthread_join(th[t], NULL);
+  return 0;
+}

@@ -54,6 +54,10 @@ enum { ORACLE_OUT_BIT = 0, ORACLE_OUT_BITINT8 = 1, ORACLE_OUT_LLRINT8 = 2 }; /* 
 int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int use_crc, int E, int crc_type,
                        const int8_t *p_llr, int8_t *p_out);
 
+/* block b decoded by thread b % nthreads (pthreads); PC-stop mode, BIT output; used for the CPU baseline timing */
+int oracle_ldpc_decode_mt(int nthreads, int nblocks, int BG, int Z, int R, int numMaxIter, const int8_t *llr,
+                          int llr_stride, int8_t *out, int out_stride, int *iters);
+
 /* ---- encoder: nrLDPC_encoder/ldpc_encoder.c:44-252 (code word), via H instead of the generator lists */
 /* in: K/8 bytes MSB-first (K = 22*Zc or 10*Zc); out: one bit per byte, (BG1 ? 66 : 50)*Zc bytes =
  * c[2Zc..K) followed by all parity bits.  Kb = number of information columns that enter the parity

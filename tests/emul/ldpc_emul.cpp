@@ -136,6 +136,7 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
   const int zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
   const uint32_t zq_magic = code->f_zq_magic, z_magic = 0xffffffffu / (uint32_t)Z + 1u;
   ldpc_fast_lds L;
+  L.base = fsm;
   L.r = fsm + code->f_lds_r;
   L.app = fsm + code->f_lds_app;
   L.ext = fsm + code->f_lds_ext;

@@ -48,6 +48,8 @@ def lib():
         i8p, u8p, i16p = C.POINTER(C.c_int8), C.POINTER(C.c_uint8), C.POINTER(C.c_int16)
         L.oracle_ldpc_decode.argtypes = [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
         L.oracle_ldpc_decode.restype = C.c_int
+        L.oracle_ldpc_decode_mt.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_ldpc_decode_mt.restype = C.c_int
         L.oracle_ldpc_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_ldpc_encode.restype = C.c_int
         L.oracle_ldpc_syndrome_weight.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -102,6 +104,18 @@ def decode(BG, Z, R, llr, max_iter=8, out_mode=OUT_BIT, use_crc=False, E=0, crc_
     out = np.full(max(out_bytes(BG, Z, R, OUT_BIT), out_bytes(BG, Z, R, OUT_BITINT8)), out_init, dtype=np.uint8)
     n = lib().oracle_ldpc_decode(BG, Z, R, max_iter, out_mode, int(use_crc), E, crc_type, _p(llr), _p(out))
     return n, out[:out_bytes(BG, Z, R, out_mode)]
+
+
+def decode_mt(nthreads, BG, Z, R, llr, max_iter=8):
+    """Many blocks on `nthreads` pthreads (PC stop, packed bits). llr: int8[n, >= ncols*Z]. Returns (n_iter, out)."""
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    n = llr.shape[0]
+    ob = out_bytes(BG, Z, R, OUT_BIT)
+    out = np.zeros((n, ob), dtype=np.uint8)
+    it = np.zeros(n, dtype=np.int32)
+    rc = lib().oracle_ldpc_decode_mt(nthreads, n, BG, Z, R, max_iter, _p(llr), llr.shape[1], _p(out), ob, _p(it))
+    assert rc == 0
+    return it, out
 
 
 def encode(BG, Z, info_bytes, Kb=None):
