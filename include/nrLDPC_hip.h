@@ -140,6 +140,52 @@ typedef struct nrLDPC_hip_enc_batch {
 } nrLDPC_hip_enc_batch_t;
 int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Transport-block chain on the GPU (what the reference does on the CPU around the codec):
+ *   nrLDPC_hip_dlsch_encode: TB CRC attach -> nr_segmentation (+ CB CRC24B, fillers) -> LDPC encode ->
+ *     nr_rate_matching_ldpc -> nr_interleaving_ldpc, the body of nr_dlsch_encoding()/ldpc8blocks()
+ *     (openair1/PHY/NR_TRANSPORT/nr_dlsch_coding.c:145-404), for a batch of transport blocks;
+ *   nrLDPC_hip_ulsch_decode: nr_deinterleaving_ldpc -> nr_rate_matching_ldpc_rx (HARQ combining) -> int8 pack
+ *     -> LDPC decode with CRC early stop -> reassembly + TB CRC, the body of nr_ulsch_decoding()/
+ *     nr_processULSegment()/nr_postDecode() (nr_ulsch_decoding.c:122-470, SCHED_NR/phy_procedures_nr_gNB.c:271-300).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct nrLDPC_hip_tb {
+  uint32_t A;        /* transport block size in bits (multiple of 8) */
+  uint32_t G;        /* coded bits of the TB (nr_get_G) */
+  uint32_t tbslbrm;  /* Tbslbrm as passed to nr_rate_matching_ldpc (0 = full circular buffer) */
+  uint8_t BG;        /* base graph (rel15->maintenance_parms_v3.ldpcBaseGraph) */
+  uint8_t Qm;        /* modulation order 2/4/6/8 */
+  uint8_t Nl;        /* layers */
+  uint8_t rv;        /* redundancy version */
+  /* decode only */
+  uint8_t numMaxIter;
+  uint8_t round;     /* HARQ round; 0 clears the soft buffer first (d_to_be_cleared) */
+  int32_t llrLen;    /* in/out: state of nr_get_R_ldpc_decoder across rounds (ulsch_harq->llrLen) */
+  /* buffer placement (bytes for payload/coded, int16 elements for llr/harq) */
+  uint64_t payload_off; /* A/8 bytes */
+  uint64_t coded_off;   /* encode: G bytes, one bit per byte (the reference's `output`); decode: G int16 LLRs */
+  uint64_t harq_off;    /* decode: C soft buffers of harq_stride int16 each, kept by the caller across rounds */
+} nrLDPC_hip_tb_t;
+
+typedef struct nrLDPC_hip_tb_batch {
+  uint32_t n_tb;
+  nrLDPC_hip_tb_t *tb;     /* host array [n_tb] (llrLen is updated by the decode call) */
+  uint8_t *payload;        /* encode: in, decode: out */
+  void *coded;             /* encode: uint8_t* out; decode: const int16_t* in */
+  int16_t *harq;           /* decode: soft buffers (device memory when mem = DEVICE) */
+  uint32_t harq_stride;    /* int16 per code block, >= 66*384 */
+  uint8_t *ack;            /* decode out [n_tb]: 1 = every segment decoded and the TB CRC holds */
+  int32_t *iter_max;       /* decode out [n_tb]: largest per-segment pass count */
+  int32_t mem;             /* NRLDPC_HIP_MEM_*: payload / coded / harq / ack / iter_max alike */
+  void *stream;            /* DEVICE mem: enqueue only (except the small per-call job upload) */
+} nrLDPC_hip_tb_batch_t;
+int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b);
+int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b);
+/* helpers with the reference's semantics (nr_segmentation parameter part, nr_get_E, nr_get_R_ldpc_decoder) */
+int32_t nrLDPC_hip_segmentation(uint32_t B, uint8_t BG, uint32_t *C, uint32_t *K, uint32_t *Zc, uint32_t *F); /* returns Kb, -1 */
+uint32_t nrLDPC_hip_get_E(uint32_t G, uint32_t C, uint32_t Qm, uint32_t Nl, uint32_t r);
+int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int32_t Z, int32_t *llrLen, int32_t round);
+
 /* Introspection for tests and benchmarks */
 int32_t nrLDPC_hip_num_llr(int BG, int Z, int R);      /* ncols*Z, -1 if invalid */
 int32_t nrLDPC_hip_out_bytes(int BG, int Z, int R, int outMode);

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -18,6 +19,8 @@
 #include "../../include/nrLDPC_hip.h"
 #include "ldpc_graph.h"
 #include "ldpc_kernels.h"
+#include "nr_coding_host.h"
+#include "tb_chain.h"
 
 namespace {
 
@@ -48,22 +51,23 @@ struct Library {
   bool ready = false;
   int device = 0;
   std::map<uint32_t, CodeEntry *> codes;
-  uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8 */
+  uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8: x^j mod g, j < 8448 */
+  uint32_t *crc_pow_24a_long = nullptr;                        /* CRC24_A up to a whole transport block */
 } g;
 
 /* x^j mod g(x), left aligned in 32 bits, for the polynomials of crc_byte.c:46-58 */
-void fill_crc_pow(uint32_t poly, std::vector<uint32_t> &t)
+void fill_crc_pow(uint32_t poly, std::vector<uint32_t> &t, size_t len = LDPC_CRC_POW_LEN)
 {
   /* degree from the lowest set bit position of the left-aligned polynomial is not needed: the left-aligned
    * register arithmetic of crcbit() (crc_byte.c:65-84) already works modulo g for any degree. */
-  t.resize(LDPC_CRC_POW_LEN);
+  t.resize(len);
   /* x^0 as "remainder register" = the CRC of a single 1 bit followed by nothing is poly itself only after
    * the degree shift; build it as: rem(j) = register after clocking a 1 followed by j zeros ... */
   /* A message bit at distance j from the end of an E-bit word contributes x^j (mod g) to word(x) mod g.
    * With the left-aligned register, word(x)*x^deg mod g is what crcbit computes; divisibility is the same
    * question, so tabulate r_j = (x^j * x^deg) mod g: r_0 = poly (one 1 bit clocked in), r_{j+1} = r_j * x mod g */
   uint32_t r = poly;
-  for (int j = 0; j < LDPC_CRC_POW_LEN; j++) {
+  for (size_t j = 0; j < len; j++) {
     t[j] = r;
     r = (r & 0x80000000u) ? ((r << 1) ^ poly) : (r << 1);
   }
@@ -90,6 +94,12 @@ int ensure_ready_locked()
     fill_crc_pow(polys[i], t);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow[i]), t.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(g.crc_pow[i], t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<uint32_t> t;
+    fill_crc_pow(polys[0], t, TB_CRC24A_POW_LEN);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow_24a_long), t.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(g.crc_pow_24a_long, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   g.ready = true;
   return 0;
@@ -195,6 +205,9 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
   a.use_crc = p.check_crc != nullptr;
   a.E = 0;
   a.crc_pow = nullptr;
+  a.jobs = nullptr;
+  for (int i = 0; i < 4; i++)
+    a.crc_pow_tbl[i] = g.crc_pow[i];
   if (a.use_crc) {
     if (p.crc_type < 0 || p.crc_type > 3)
       return set_error("invalid crc_type");
@@ -345,6 +358,7 @@ int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b)
   if (b->n_blocks == 0)
     return 0;
   ldpc_enc_args a;
+  a.jobs = nullptr;
   a.code = ce->dev;
   a.Kb = b->Kb;
   if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
@@ -396,6 +410,7 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
     memcpy(c.h_in + j * in_stride, input[first + j], in_bytes);
   HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * n, hipMemcpyHostToDevice, c.stream));
   ldpc_enc_args a;
+  a.jobs = nullptr;
   a.code = ce->dev;
   a.Kb = (int)impp->Kb;
   if (a.Kb < 1 || a.Kb > hc.kb_full)
@@ -411,3 +426,5 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
 }
 
 } /* extern "C" */
+
+#include "tb_api.inc.cpp"

@@ -17,7 +17,8 @@
 __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code; /* never written while a kernel runs */
+  const ldpc_dec_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code); /* never written while a kernel runs */
   const int Z = code->Z;
   int8_t *r = smem + code->lds_r;
   int8_t *app = smem + code->lds_app;
@@ -29,7 +30,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   const int num_llr = code->num_llr, ncz = code->ncore * Z;
 
   /* ---- stage the channel LLRs, clear the messages ------------------------------------------------ */
-  const int8_t *__restrict__ src = a.llr + (size_t)blk * a.llr_stride;
+  const int8_t *__restrict__ src = a.llr + (job ? (size_t)job->llr_off : (size_t)blk * a.llr_stride);
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int n16 = num_llr >> 4;
     for (int i = tid; i < n16; i += nt)
@@ -52,7 +53,9 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   __syncthreads();
 
   /* ---- passes (decoder.c:552-558: one unconditional pass + up to numMaxIter more) ------------------ */
-  const int max_pass = a.num_max_iter + 1;
+  const int max_pass = (job ? job->num_max_iter : a.num_max_iter) + 1;
+  const int crcE = job ? job->E : a.E;
+  const uint32_t *crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   int n_iter = max_pass;
   for (int p = 1; p <= max_pass; ++p) {
     /* check-node phase; its syndrome is that of pass p-1 */
@@ -92,9 +95,9 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
      * XOR over the set bits i of x^(E-1-i) mod g. */
     if (a.use_crc && p >= 3) {
       uint32_t x = 0;
-      for (int i = tid; i < a.E; i += nt)
+      for (int i = tid; i < crcE; i += nt)
         if (app[i] < 0)
-          x ^= a.crc_pow[a.E - 1 - i];
+          x ^= crc_pow[crcE - 1 - i];
       for (int off = 32; off; off >>= 1)
         x ^= __shfl_xor(x, off);
       if (lane == 0 && x)
@@ -112,18 +115,18 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   /* ---- hard decision (decoder.c:864-879; in CRC mode p_out is only written from pass 3 on) ----------- */
   if (!a.use_crc || n_iter >= 3) {
     if (a.out_mode == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (size_t)blk * a.out_stride);
+      uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride));
       const int nwords = (num_llr + 31) >> 5;
       for (int w = tid; w < nwords; w += nt)
         o[w] = (32 * w < ncz) ? ldpc_pack_word(app, w, ncz) : 0u;
     } else {
-      int8_t *o = a.out + (size_t)blk * a.out_stride;
+      int8_t *o = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
       for (int i = tid; i < num_llr; i += nt)
         o[i] = (i < ncz) ? (int8_t)(app[i] < 0) : (int8_t)0;
     }
   }
   if (tid == 0)
-    a.n_iter[blk] = n_iter;
+    a.n_iter[job ? (uint32_t)job->iter_idx : blk] = n_iter;
 }
 
 hipError_t ldpc_kernels_init(void)
@@ -138,5 +141,13 @@ hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_
   if (n_blocks == 0)
     return hipSuccess;
   hipLaunchKernelGGL(ldpc_dec_generic_kernel, dim3(n_blocks), dim3(hc.n_threads), hc.lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_generic_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(ldpc_dec_generic_kernel, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

@@ -16,7 +16,8 @@ template <int MAX_THREADS>
 __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const ldpc_dec_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
   const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
   const uint32_t zq_magic = code->f_zq_magic;
   const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u; /* ceil(2^32 / Z) for Z not a power of two, exact enough
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const int wave = LDPC_UNIFORM(tid >> 6);
   const uint32_t blk = blockIdx.x;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
-  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (size_t)blk * a.llr_stride);
+  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (job ? (size_t)job->llr_off : (size_t)blk * a.llr_stride));
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
   for (int i = tid; i < nedges; i += nt)
@@ -70,7 +71,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   __syncthreads();
 
   /* ---- passes ------------------------------------------------------------------------------------------ */
-  const int max_pass = a.num_max_iter + 1;
+  const int max_pass = (job ? job->num_max_iter : a.num_max_iter) + 1;
+  const int crcE = job ? job->E : a.E;
+  const uint32_t *crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   int n_iter = max_pass;
   const int cn0 = code->f_cn_ptr[wave], cn1 = code->f_cn_ptr[wave + 1];
   const int bn0 = code->f_bn_ptr[wave], bn1 = code->f_bn_ptr[wave + 1];
@@ -116,9 +119,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     __syncthreads();
     if (a.use_crc && p >= 3) { /* see ldpc_decoder.hip for the CRC argument */
       uint32_t x = 0;
-      for (int i = tid; i < a.E; i += nt)
+      for (int i = tid; i < crcE; i += nt)
         if (ldpc_fast_hd(L, i, Z, z_magic, astride))
-          x ^= a.crc_pow[a.E - 1 - i];
+          x ^= crc_pow[crcE - 1 - i];
       for (int off = 32; off; off >>= 1)
         x ^= __shfl_xor(x, off);
       if (lane == 0 && x)
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   /* ---- hard decision ------------------------------------------------------------------------------------- */
   if (!a.use_crc || n_iter >= 3) {
     if (a.out_mode == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (size_t)blk * a.out_stride);
+      uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride));
       const int nwords = (num_llr + 31) >> 5;
       for (int w = tid; w < nwords; w += nt) {
         uint32_t word = 0;
@@ -153,13 +156,13 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
         o[w] = word;
       }
     } else {
-      int8_t *o = a.out + (size_t)blk * a.out_stride;
+      int8_t *o = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
       for (int i = tid; i < num_llr; i += nt)
         o[i] = (i < ncz) ? (int8_t)ldpc_fast_hd(L, i, Z, z_magic, astride) : (int8_t)0;
     }
   }
   if (tid == 0)
-    a.n_iter[blk] = n_iter;
+    a.n_iter[job ? (uint32_t)job->iter_idx : blk] = n_iter;
 }
 
 hipError_t ldpc_fast_kernel_init(void)
@@ -181,5 +184,16 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     hipLaunchKernelGGL(ldpc_dec_fast_kernel<768>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else
     hipLaunchKernelGGL(ldpc_dec_fast_kernel<1024>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  if (n_threads <= 768)
+    hipLaunchKernelGGL(ldpc_dec_fast_kernel<768>, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_kernel<1024>, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

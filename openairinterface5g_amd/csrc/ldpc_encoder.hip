@@ -10,15 +10,17 @@
 __global__ void __launch_bounds__(1024) ldpc_enc_kernel(const ldpc_enc_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t esm[];
-  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const ldpc_enc_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
   uint8_t *x = esm;
   uint8_t *lam = esm + ((code->ncols * code->Z + 15) & ~15);
   const uint32_t blk = blockIdx.x;
-  const uint8_t *in = a.in + (size_t)blk * a.in_stride;
-  uint8_t *out = a.out + (size_t)blk * a.out_stride;
+  const uint8_t *in = a.in + (job ? (size_t)job->in_off : (size_t)blk * a.in_stride);
+  uint8_t *out = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
+  const int Kb = job ? job->Kb : a.Kb;
 #pragma unroll
   for (int ph = 0; ph < LDPC_ENC_NUM_PHASES; ph++) {
-    ldpc_enc_phase(ph, code, a.Kb, in, x, lam, out, threadIdx.x, blockDim.x);
+    ldpc_enc_phase(ph, code, Kb, in, x, lam, out, threadIdx.x, blockDim.x);
     __syncthreads();
   }
 }
@@ -31,5 +33,13 @@ hipError_t ldpc_launch_enc(const ldpc_enc_args &a, const ldpc_code_desc_t &hc, u
   int waves = (hc.Z + 63) / 64 * 2;
   if (waves > 16) waves = 16;
   hipLaunchKernelGGL(ldpc_enc_kernel, dim3(n_blocks), dim3(waves * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(ldpc_enc_kernel, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

@@ -9,6 +9,23 @@
 
 #define LDPC_CRC_POW_LEN 8448 /* x^j mod g for j < 8448 = largest code block */
 
+/* heterogeneous batches (transport-block chain): one job per workgroup overrides code / buffers / E / crc */
+struct ldpc_dec_job {
+  const ldpc_code_desc_t *code; /* device */
+  uint64_t llr_off;             /* bytes from ldpc_dec_args.llr */
+  uint64_t out_off;             /* bytes from ldpc_dec_args.out */
+  int32_t num_max_iter;
+  int32_t E;                    /* CRC mode: bits covered */
+  int32_t crc_type;             /* CRC mode: index into ldpc_dec_args.crc_pow_tbl */
+  int32_t iter_idx;             /* where in ldpc_dec_args.n_iter this block reports */
+};
+struct ldpc_enc_job {
+  const ldpc_code_desc_t *code; /* device, full-rate descriptor */
+  uint64_t in_off, out_off;     /* bytes from ldpc_enc_args.in / .out */
+  int32_t Kb;
+  int32_t pad;
+};
+
 struct ldpc_dec_args {
   const ldpc_code_desc_t *code; /* device copy of the descriptor */
   const int8_t *llr;
@@ -21,6 +38,8 @@ struct ldpc_dec_args {
   int32_t use_crc;  /* 0: parity-check stop, 1: CRC stop */
   int32_t E;        /* bits covered by the CRC check (use_crc) */
   const uint32_t *crc_pow; /* device table, crc_pow[j] = x^j mod g(x), left aligned in 32 bits */
+  const ldpc_dec_job *jobs; /* NULL: homogeneous batch addressed by strides */
+  const uint32_t *crc_pow_tbl[4]; /* per crc_type, used with jobs */
 };
 
 struct ldpc_enc_args {
@@ -30,6 +49,7 @@ struct ldpc_enc_args {
   uint8_t *out;
   uint32_t out_stride;
   int32_t Kb;
+  const ldpc_enc_job *jobs; /* NULL: homogeneous batch */
 };
 
 /* one-time per-process kernel attribute setup (dynamic LDS limit); returns hipSuccess or the error */
@@ -37,6 +57,10 @@ hipError_t ldpc_kernels_init(void);
 /* generic flooding min-sum decoder: one workgroup per code block, any (BG, Z, R) */
 hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                    hipStream_t stream);
+/* job-array launches: explicit workgroup size and dynamic LDS (maxima over the jobs) */
+hipError_t ldpc_launch_dec_generic_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
+hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
+hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
 /* fast decoder (Zc % 4 == 0, 4-byte aligned LLR rows, hc.f_ok): one workgroup per code block */
 hipError_t ldpc_fast_kernel_init(void);
 hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,

@@ -1,0 +1,376 @@
+/*
+ * tb_api.inc.cpp -- transport-block chain entry points (included at the end of ldpc_api.cpp; shares its
+ * library state).  Host part = the parameter arithmetic of nr_dlsch_encoding()/nr_ulsch_decoding()
+ * (segmentation, E per segment, decoder rate mode, rate-matching geometry: nr_coding_host.c) and the job lists;
+ * every byte of payload/LLR data is touched on the GPU only (tb_chain.hip + the codec kernels).
+ */
+
+namespace {
+
+struct DevBuf { /* growable device buffer */
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n)
+  {
+    if (n <= cap)
+      return 0;
+    if (p)
+      (void)hipFree(p);
+    cap = n + n / 4 + 65536;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), cap));
+    return 0;
+  }
+};
+struct PinBuf { /* growable pinned host buffer */
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n)
+  {
+    if (n <= cap)
+      return 0;
+    if (p)
+      (void)hipHostFree(p);
+    cap = n + n / 4 + 65536;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), cap, hipHostMallocDefault));
+    return 0;
+  }
+};
+
+struct TbCtx {
+  DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small;
+  PinBuf jobs_h, small_h;
+  hipStream_t own = nullptr, last = nullptr;
+  hipEvent_t uploaded = nullptr;
+  bool pending = false;
+};
+thread_local TbCtx tls_tb;
+
+struct Arena { /* bump allocator over the scratch buffer, 16-byte granules */
+  size_t top = 0;
+  size_t take(size_t n)
+  {
+    const size_t o = top;
+    top += align_up(n, 16);
+    return o;
+  }
+};
+
+int tb_begin(const nrLDPC_hip_tb_batch_t *b, hipStream_t &s)
+{
+  if (!b || !b->tb || !b->payload || !b->coded)
+    return set_error("null argument");
+  if (ensure_ready() != 0)
+    return -1;
+  TbCtx &c = tls_tb;
+  HIP_TRY(hipSetDevice(g.device));
+  if (!c.own) {
+    HIP_TRY(hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c.uploaded, hipEventDisableTiming));
+  }
+  s = b->mem == NRLDPC_HIP_MEM_DEVICE ? static_cast<hipStream_t>(b->stream) : c.own;
+  if (c.pending) { /* the previous call's job upload must have left the pinned staging buffer */
+    HIP_TRY(hipEventSynchronize(c.uploaded));
+    if (c.last != s)
+      HIP_TRY(hipStreamSynchronize(c.last)); /* scratch is reused: calls on different streams are serialised */
+    c.pending = false;
+  }
+  return 0;
+}
+
+int tb_validate(const nrLDPC_hip_tb_t &t)
+{
+  if (t.A == 0 || (t.A & 7) || (t.BG != 1 && t.BG != 2) || t.rv > 3 || t.Nl == 0 ||
+      !(t.Qm == 2 || t.Qm == 4 || t.Qm == 6 || t.Qm == 8) || t.G == 0 || t.G % (t.Nl * t.Qm))
+    return set_error("invalid transport block parameters");
+  if (t.A + 24 > TB_CRC24A_POW_LEN)
+    return set_error("transport block too large");
+  return 0;
+}
+
+/* upload `n` bytes of jobs staged at c.jobs_h.p to c.jobs_d.p */
+int tb_upload_jobs(TbCtx &c, size_t n, hipStream_t s)
+{
+  HIP_TRY(hipMemcpyAsync(c.jobs_d.p, c.jobs_h.p, n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(c.uploaded, s));
+  c.pending = true;
+  c.last = s;
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t nrLDPC_hip_segmentation(uint32_t B, uint8_t BG, uint32_t *C, uint32_t *K, uint32_t *Zc, uint32_t *F)
+{
+  nr_hip_seg_t s;
+  if ((BG != 1 && BG != 2) || nr_hip_segmentation(B, BG, &s) != 0)
+    return -1;
+  if (C) *C = s.C;
+  if (K) *K = s.K;
+  if (Zc) *Zc = s.Zc;
+  if (F) *F = s.F;
+  return (int32_t)s.Kb;
+}
+uint32_t nrLDPC_hip_get_E(uint32_t G, uint32_t C, uint32_t Qm, uint32_t Nl, uint32_t r) { return nr_hip_get_E(G, C, Qm, Nl, r); }
+int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int32_t Z, int32_t *llrLen, int32_t round)
+{
+  return nr_hip_get_R_ldpc_decoder(rvidx, E, BG, Z, llrLen, round);
+}
+
+int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
+{
+  hipStream_t s;
+  if (tb_begin(b, s) != 0)
+    return -1;
+  if (b->n_tb == 0)
+    return 0;
+  TbCtx &c = tls_tb;
+  std::vector<tb_tx_tb_job> tbj(b->n_tb);
+  std::vector<tb_tx_seg_job> sj;
+  std::vector<ldpc_enc_job> ej;
+  Arena ar;
+  int enc_threads = 64, enc_lds = 0;
+  size_t payload_end = 0, coded_end = 0;
+  for (uint32_t i = 0; i < b->n_tb; i++) {
+    const nrLDPC_hip_tb_t &t = b->tb[i];
+    if (tb_validate(t) != 0)
+      return -1;
+    /* nr_dlsch_coding.c:300-331 */
+    const uint32_t B = t.A + (t.A > NR_HIP_MAX_PDSCH_TBS ? 24 : 16);
+    nr_hip_seg_t sg;
+    if (nr_hip_segmentation(B, t.BG, &sg) != 0)
+      return set_error("nr_segmentation: unsupported block size");
+    const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
+    if (!ce)
+      return -1;
+    tbj[i].payload_off = t.payload_off;
+    tbj[i].b_off = ar.take(B / 8 + 4);
+    tbj[i].A = t.A;
+    tbj[i].B = B;
+    tbj[i].crc_type = t.A > NR_HIP_MAX_PDSCH_TBS ? NR_HIP_CRC24_A : NR_HIP_CRC16;
+    payload_end = std::max(payload_end, (size_t)t.payload_off + t.A / 8);
+    coded_end = std::max(coded_end, (size_t)t.coded_off + t.G);
+    const ldpc_code_desc_t &hc = ce->host;
+    const int N = (hc.ncols - 2) * hc.Z;
+    int waves = (hc.Z + 63) / 64 * 2;
+    if (waves > 16) waves = 16;
+    enc_threads = std::max(enc_threads, waves * 64);
+    enc_lds = std::max(enc_lds, (int)(align_up(hc.ncols * hc.Z, 16) + align_up(4 * hc.Z, 16)));
+    uint32_t r_offset = 0;
+    for (uint32_t r = 0; r < sg.C; r++) {
+      tb_tx_seg_job j;
+      memset(&j, 0, sizeof(j));
+      j.b_off = tbj[i].b_off;
+      j.c_off = ar.take(sg.K / 8 + 4);
+      j.d_off = ar.take(N);
+      j.out_off = t.coded_off + r_offset;
+      j.r = r; j.C = sg.C; j.Kprime = sg.Kprime; j.L = sg.L; j.K = sg.K;
+      j.E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
+      j.Qm = t.Qm;
+      nr_hip_rm_t rm;
+      if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, j.E, &rm) != 0)
+        return set_error("nr_rate_matching: invalid parameters");
+      j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+      r_offset += j.E;
+      sj.push_back(j);
+      ldpc_enc_job e;
+      e.code = ce->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
+      ej.push_back(e);
+    }
+  }
+  const size_t n_seg = sj.size();
+  const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_tx_tb_job), 16),
+               o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16), jobs_bytes = o_enc + n_seg * sizeof(ldpc_enc_job);
+  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || c.jobs_d.ensure(jobs_bytes) != 0)
+    return -1;
+  memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
+  memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
+  memcpy(c.jobs_h.p + o_enc, ej.data(), n_seg * sizeof(ldpc_enc_job));
+  if (tb_upload_jobs(c, jobs_bytes, s) != 0)
+    return -1;
+  const uint8_t *payload = b->payload;
+  uint8_t *coded = static_cast<uint8_t *>(b->coded);
+  if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
+    if (c.io_payload.ensure(payload_end) != 0 || c.io_coded.ensure(coded_end) != 0)
+      return -1;
+    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload, payload_end, hipMemcpyHostToDevice, s));
+    payload = c.io_payload.p;
+    coded = c.io_coded.p;
+  }
+  const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(c.jobs_d.p + o_tb);
+  const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(c.jobs_d.p + o_seg);
+  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, payload, c.scratch.p, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+  HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, g.crc_pow[NR_HIP_CRC24_B], s));
+  ldpc_enc_args ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.in = c.scratch.p;
+  ea.out = c.scratch.p;
+  ea.jobs = reinterpret_cast<const ldpc_enc_job *>(c.jobs_d.p + o_enc);
+  HIP_TRY(ldpc_launch_enc_jobs(ea, enc_threads, enc_lds, (uint32_t)n_seg, s));
+  HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
+  if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
+    HIP_TRY(hipMemcpyAsync(b->coded, coded, coded_end, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
+{
+  hipStream_t s;
+  if (tb_begin(b, s) != 0)
+    return -1;
+  if (!b->harq || !b->ack || !b->iter_max || b->harq_stride < 66 * 384)
+    return set_error("decode needs harq (stride >= 66*384), ack and iter_max buffers");
+  if (b->n_tb == 0)
+    return 0;
+  TbCtx &c = tls_tb;
+  std::vector<tb_rx_tb_job> tbj(b->n_tb);
+  std::vector<tb_rx_seg_job> sj;
+  std::vector<ldpc_dec_job> fast_jobs, gen_jobs;
+  Arena ar;
+  int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
+  size_t payload_end = 0, llr_end = 0, harq_end = 0;
+  for (uint32_t i = 0; i < b->n_tb; i++) {
+    nrLDPC_hip_tb_t &t = b->tb[i];
+    if (tb_validate(t) != 0)
+      return -1;
+    /* nr_ulsch_decoding.c:386-395: segmentation parameters from lenWithCrc(1, A) */
+    const uint32_t B = (uint32_t)nr_hip_len_with_crc(1, (int)t.A);
+    nr_hip_seg_t sg;
+    if (nr_hip_segmentation(B, t.BG, &sg) != 0)
+      return set_error("nr_segmentation: unsupported block size");
+    const CodeEntry *full = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
+    if (!full)
+      return -1;
+    const uint32_t cstride = (uint32_t)align_up(out_bytes_of(full->host, 0), 16);
+    tb_rx_tb_job &tj = tbj[i];
+    memset(&tj, 0, sizeof(tj));
+    tj.payload_off = t.payload_off;
+    tj.b_off = ar.take(B / 8 + 4);
+    tj.c_off0 = ar.take((size_t)cstride * sg.C);
+    tj.c_stride = cstride;
+    tj.seg0 = (uint32_t)sj.size();
+    tj.C = sg.C;
+    tj.A = t.A;
+    tj.B = B;
+    tj.crc_type = (uint32_t)nr_hip_crc_type(1, (int)t.A);
+    tj.num_max_iter = t.numMaxIter;
+    tj.seg_bytes = sg.K / 8 - sg.F / 8 - (sg.C > 1 ? 3 : 0); /* phy_procedures_nr_gNB.c:287 */
+    payload_end = std::max(payload_end, (size_t)t.payload_off + t.A / 8);
+    llr_end = std::max(llr_end, (size_t)t.coded_off + t.G);
+    harq_end = std::max(harq_end, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
+    uint32_t r_offset = 0;
+    int llrLen = t.llrLen;
+    for (uint32_t r = 0; r < sg.C; r++) {
+      const uint32_t E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
+      /* nr_ulsch_decoding.c:439-444: decoder rate mode, stateful in llrLen */
+      const int R = nr_hip_get_R_ldpc_decoder(t.rv, (int)E, t.BG, (int)sg.Zc, &llrLen, t.round);
+      const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, R);
+      if (!ce)
+        return -1;
+      const ldpc_code_desc_t &hc = ce->host;
+      nr_hip_rm_t rm;
+      if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, E, &rm) != 0)
+        return set_error("nr_rate_matching_rx: invalid parameters");
+      tb_rx_seg_job j;
+      memset(&j, 0, sizeof(j));
+      j.llr_off = t.coded_off + r_offset;
+      j.harq_off = t.harq_off + (uint64_t)r * b->harq_stride;
+      j.l_off = ar.take(hc.num_llr);
+      j.E = E; j.Qm = t.Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+      j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
+      j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
+      ldpc_dec_job dj;
+      dj.code = ce->dev;
+      dj.llr_off = j.l_off;
+      dj.out_off = tj.c_off0 + (uint64_t)r * cstride;
+      dj.num_max_iter = t.numMaxIter;
+      dj.E = nr_hip_len_with_crc((int)sg.C, (int)t.A); /* nr_ulsch_decoding.c:190 */
+      dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
+      dj.iter_idx = (int32_t)sj.size();
+      if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
+        return set_error("CRC length outside the code block");
+      if (hc.f_ok) {
+        fast_jobs.push_back(dj);
+        fast_threads = std::max(fast_threads, hc.f_n_threads);
+        fast_lds = std::max(fast_lds, hc.f_lds_total);
+      } else {
+        gen_jobs.push_back(dj);
+        gen_threads = std::max(gen_threads, hc.n_threads);
+        gen_lds = std::max(gen_lds, hc.lds_total);
+      }
+      sj.push_back(j);
+      r_offset += E;
+    }
+    t.llrLen = llrLen;
+  }
+  const size_t n_seg = sj.size();
+  const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
+               o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
+               o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
+               o_iter = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16),
+               jobs_bytes = o_iter; /* n_iter lives behind the jobs in the same device buffer */
+  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
+      c.jobs_d.ensure(jobs_bytes + n_seg * sizeof(int32_t)) != 0)
+    return -1;
+  memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
+  memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
+  memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
+  memcpy(c.jobs_h.p + o_gen, gen_jobs.data(), gen_jobs.size() * sizeof(ldpc_dec_job));
+  if (tb_upload_jobs(c, jobs_bytes, s) != 0)
+    return -1;
+  int32_t *d_iter = reinterpret_cast<int32_t *>(c.jobs_d.p + o_iter);
+  uint8_t *payload = b->payload;
+  const int16_t *llr = static_cast<const int16_t *>(b->coded);
+  int16_t *harq = b->harq;
+  uint8_t *ack = b->ack;
+  int32_t *iter_max = b->iter_max;
+  const bool host = b->mem != NRLDPC_HIP_MEM_DEVICE;
+  if (host) {
+    if (c.io_payload.ensure(payload_end) != 0 || c.io_coded.ensure(llr_end * 2) != 0 || c.io_harq.ensure(harq_end * 2) != 0 ||
+        c.io_small.ensure((size_t)b->n_tb * 8 + 64) != 0 || c.small_h.ensure((size_t)b->n_tb * 8 + 64) != 0)
+      return -1;
+    HIP_TRY(hipMemcpyAsync(c.io_coded.p, b->coded, llr_end * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq, harq_end * 2, hipMemcpyHostToDevice, s));
+    payload = c.io_payload.p;
+    llr = reinterpret_cast<const int16_t *>(c.io_coded.p);
+    harq = reinterpret_cast<int16_t *>(c.io_harq.p);
+    iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
+    ack = c.io_small.p + (size_t)b->n_tb * 4;
+  }
+  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(c.jobs_d.p + o_seg), (uint32_t)n_seg, llr, harq,
+                               reinterpret_cast<int8_t *>(c.scratch.p), s));
+  ldpc_dec_args da;
+  memset(&da, 0, sizeof(da));
+  da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);
+  da.out = reinterpret_cast<int8_t *>(c.scratch.p);
+  da.n_iter = d_iter;
+  da.out_mode = 0;
+  da.use_crc = 1;
+  for (int k = 0; k < 4; k++)
+    da.crc_pow_tbl[k] = g.crc_pow[k];
+  da.crc_pow_tbl[NR_HIP_CRC24_A] = g.crc_pow_24a_long;
+  if (!fast_jobs.empty()) {
+    da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_fast);
+    HIP_TRY(ldpc_launch_dec_fast_jobs(da, fast_threads, fast_lds, (uint32_t)fast_jobs.size(), s));
+  }
+  if (!gen_jobs.empty()) {
+    da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_gen);
+    HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)gen_jobs.size(), s));
+  }
+  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(c.jobs_d.p + o_tb), b->n_tb, d_iter, c.scratch.p,
+                                payload, ack, iter_max, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+  if (host) {
+    HIP_TRY(hipMemcpyAsync(b->payload, payload, payload_end, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->harq, harq, harq_end * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)b->n_tb * 5, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(b->iter_max, c.small_h.p, (size_t)b->n_tb * 4);
+    memcpy(b->ack, c.small_h.p + (size_t)b->n_tb * 4, b->n_tb);
+  }
+  return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,55 @@
+/*
+ * tb_chain.h -- device jobs of the transport-block chain around the LDPC codec (SURVEY section 8 rows a16-a20,
+ * f2, f3): TB CRC attach, code-block segmentation + CB CRC, rate matching + bit interleaving (TX);
+ * de-interleaving + rate de-matching with HARQ soft combining + int16->int8 pack, TB reassembly + TB CRC (RX).
+ */
+#ifndef TB_CHAIN_H
+#define TB_CHAIN_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TB_CRC24A_POW_LEN (1u << 21) /* x^j mod g for j < 2 Mi: covers any NR transport block */
+
+struct tb_tx_tb_job {      /* one per transport block */
+  uint64_t payload_off;    /* A/8 bytes in the payload buffer */
+  uint64_t b_off;          /* scratch: payload || TB CRC, B/8 bytes */
+  uint32_t A, B, crc_type; /* CRC24_A (0) or CRC16 (2) */
+  uint32_t pad;
+};
+struct tb_tx_seg_job {     /* one per code block */
+  uint64_t b_off;          /* the TB's b */
+  uint64_t c_off;          /* scratch: packed segment, K/8 bytes (encoder input) */
+  uint64_t d_off;          /* scratch: encoder output, one bit per byte */
+  uint64_t out_off;        /* coded output: TB offset + sum of the previous segments' E */
+  uint32_t r, C, Kprime, L, K; /* segment index, segments, bits incl. CB CRC, CB CRC length, K */
+  uint32_t E, Qm, Foffset, Fin, V, rank0;
+  uint32_t pad;
+};
+struct tb_rx_seg_job {
+  uint64_t llr_off;        /* int16 units: TB offset + sum of the previous segments' E */
+  uint64_t harq_off;       /* int16 units: soft buffer d[r] of this segment */
+  uint64_t l_off;          /* scratch: decoder input, int8 */
+  uint32_t E, Qm, Ncb, Foffset, Fin, V, rank0, clear;
+  uint32_t K, F, Z, num_llr; /* num_llr = ncols(R)*Z bytes the decoder reads */
+};
+struct tb_rx_tb_job {
+  uint64_t payload_off;    /* A/8 bytes out */
+  uint64_t b_off;          /* scratch: reassembled b (B/8 bytes) */
+  uint64_t c_off0;         /* scratch: first segment's decoded bits; segments are c_stride apart */
+  uint32_t c_stride;
+  uint32_t seg0, C;        /* index of the first segment in the n_iter array */
+  uint32_t A, B, crc_type, num_max_iter;
+  uint32_t seg_bytes;      /* payload bytes carried per segment = K/8 - F/8 - (C > 1 ? 3 : 0) */
+  uint32_t pad;
+};
+
+hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n, const uint8_t *payload, uint8_t *scratch,
+                            const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);
+hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s);
+hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s);
+hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
+                                hipStream_t s);
+hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n, const int32_t *n_iter, uint8_t *scratch,
+                                 uint8_t *payload, uint8_t *ack, int32_t *iter_max, const uint32_t *pow24a,
+                                 const uint32_t *pow16, hipStream_t s);
+#endif

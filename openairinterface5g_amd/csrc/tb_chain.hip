@@ -1,0 +1,226 @@
+/*
+ * tb_chain.hip -- transport-block chain kernels for gfx950 (see tb_chain.h).  All of them are byte/int16
+ * gather-scatter work bound by HBM/L2 traffic; one workgroup per transport block or per code block.
+ *
+ * Reference functions replaced (openair1/PHY/...):
+ *   TB CRC attach                       NR_TRANSPORT/nr_dlsch_coding.c:300-331 (crc24a / crc16, CODING/crc_byte.c)
+ *   nr_segmentation (data part)         CODING/nr_segmentation.c:147-175
+ *   nr_rate_matching_ldpc + nr_interleaving_ldpc   CODING/nr_rate_matching.c:424-505, :36-303 (ldpc8blocks, nr_dlsch_coding.c:177-245)
+ *   nr_deinterleaving_ldpc + nr_rate_matching_ldpc_rx + int8 pack
+ *                                       CODING/nr_rate_matching.c:310-388, :507-603; NR_TRANSPORT/nr_ulsch_decoding.c:153-210
+ *   nr_postDecode (reassembly, TB CRC)  SCHED_NR/phy_procedures_nr_gNB.c:271-300
+ */
+#include <hip/hip_runtime.h>
+#include "tb_chain.h"
+
+#define TB_THREADS 256
+
+/* XOR-reduce x over the workgroup; every thread gets the result.  red = 2 dwords of LDS. */
+__device__ __forceinline__ uint32_t tb_block_xor(uint32_t x, uint32_t *red)
+{
+  for (int off = 32; off; off >>= 1)
+    x ^= __shfl_xor(x, off);
+  if (threadIdx.x == 0)
+    red[0] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && x)
+    atomicXor(&red[0], x);
+  __syncthreads();
+  const uint32_t r = red[0];
+  __syncthreads();
+  return r;
+}
+
+/* Left-aligned CRC register of the nbits-bit string at `data` (MSB first), as crc24a()/crc24b()/crc16() return it
+ * (crc_byte.c:148-260): linear in the bits, bit i contributes pow[nbits-1-i] = x^(nbits-1-i) * x^deg mod g. */
+__device__ __forceinline__ uint32_t tb_block_crc(const uint8_t *__restrict__ data, uint32_t nbits, const uint32_t *__restrict__ pow,
+                                                 uint32_t *red)
+{
+  uint32_t x = 0;
+  const uint32_t nbytes = nbits >> 3;
+  for (uint32_t q = threadIdx.x; q < nbytes; q += blockDim.x) {
+    uint32_t v = data[q];
+    const uint32_t top = nbits - 1 - 8 * q; /* exponent of the byte's MSB */
+    while (v) {
+      const int b = 31 - __clz(v); /* bit b (0 = LSB) sits 7-b positions after the MSB */
+      x ^= pow[top - (7 - b)];
+      v &= ~(1u << b);
+    }
+  }
+  return tb_block_xor(x, red);
+}
+
+/* ---- TX 1: b = payload || CRC24A / CRC16 ------------------------------------------------------------------ */
+__global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_kernel(const tb_tx_tb_job *jobs, const uint8_t *payload,
+                                                               uint8_t *scratch, const uint32_t *pow24a, const uint32_t *pow16)
+{
+  __shared__ uint32_t red[2];
+  const tb_tx_tb_job j = jobs[blockIdx.x];
+  const uint8_t *a = payload + j.payload_off;
+  uint8_t *b = scratch + j.b_off;
+  const uint32_t nbytes = j.A >> 3;
+  for (uint32_t q = threadIdx.x; q < nbytes; q += blockDim.x)
+    b[q] = a[q];
+  const bool is24 = j.crc_type == 0;
+  const uint32_t crc = tb_block_crc(a, j.A, is24 ? pow24a : pow16, red);
+  if (threadIdx.x == 0) {
+    if (is24) {
+      b[nbytes] = (uint8_t)(crc >> 24);
+      b[nbytes + 1] = (uint8_t)(crc >> 16);
+      b[nbytes + 2] = (uint8_t)(crc >> 8);
+    } else {
+      b[nbytes] = (uint8_t)(crc >> 24);
+      b[nbytes + 1] = (uint8_t)(crc >> 16);
+    }
+  }
+}
+
+/* ---- TX 2: code-block segmentation: c_r = b[r*(K'-L) ..] || CRC24B (C > 1) || zero fillers ---------------- */
+__global__ void __launch_bounds__(TB_THREADS) tb_tx_segment_kernel(const tb_tx_seg_job *jobs, uint8_t *scratch,
+                                                                   const uint32_t *pow24b)
+{
+  __shared__ uint32_t red[2];
+  const tb_tx_seg_job j = jobs[blockIdx.x];
+  const uint32_t segbytes = (j.Kprime - j.L) >> 3, kbytes = j.K >> 3;
+  const uint8_t *src = scratch + j.b_off + (size_t)j.r * segbytes;
+  uint8_t *c = scratch + j.c_off;
+  for (uint32_t q = threadIdx.x; q < segbytes; q += blockDim.x)
+    c[q] = src[q];
+  for (uint32_t q = (j.Kprime >> 3) + threadIdx.x; q < kbytes; q += blockDim.x)
+    c[q] = 0;
+  if (j.C > 1) {
+    const uint32_t crc = tb_block_crc(src, j.Kprime - j.L, pow24b, red);
+    if (threadIdx.x == 0) {
+      c[segbytes] = (uint8_t)(crc >> 24);
+      c[segbytes + 1] = (uint8_t)(crc >> 16);
+      c[segbytes + 2] = (uint8_t)(crc >> 8);
+    }
+  }
+}
+
+/* ---- TX 3: bit selection (rate matching) fused with bit interleaving ---------------------------------------- *
+ * f[i + j*Qm] = e[i*E/Qm + j] (nr_rate_matching.c:262-268), e[k] = d[position of rank (rank0 + k) mod V], where the
+ * transmittable positions of the circular buffer [0, Ncb) are those outside the filler range. */
+__global__ void __launch_bounds__(TB_THREADS) tb_tx_ratematch_kernel(const tb_tx_seg_job *jobs, const uint8_t *scratch,
+                                                                     uint8_t *coded)
+{
+  const tb_tx_seg_job j = jobs[blockIdx.x];
+  const uint8_t *__restrict__ d = scratch + j.d_off;
+  uint8_t *__restrict__ f = coded + j.out_off;
+  const uint32_t EQ = j.E / j.Qm;
+  for (uint32_t m = threadIdx.x; m < j.E; m += blockDim.x) {
+    const uint32_t jj = m / j.Qm, i = m - jj * j.Qm;
+    const uint32_t k = i * EQ + jj;
+    const uint32_t rank = (j.rank0 + k) % j.V;
+    const uint32_t p = rank < j.Foffset ? rank : rank + j.Fin;
+    f[m] = d[p];
+  }
+}
+
+/* ---- RX 1: de-interleave + rate de-match (HARQ combining) + decoder input pack -------------------------------- */
+__global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
+                                                                   int16_t *harq, int8_t *scratch)
+{
+  const tb_rx_seg_job j = jobs[blockIdx.x];
+  const int16_t *__restrict__ f = llr + j.llr_off;
+  int16_t *__restrict__ w = harq + j.harq_off;
+  int8_t *__restrict__ l = scratch + j.l_off;
+  const uint32_t EQ = j.E / j.Qm, twoZ = 2 * j.Z;
+  const uint32_t np = j.num_llr > twoZ ? j.num_llr - twoZ : 0;     /* soft-buffer positions the decoder reads */
+  const uint32_t n = j.Ncb > np ? j.Ncb : np;
+  for (uint32_t i = threadIdx.x; i < twoZ && i < j.num_llr; i += blockDim.x)
+    l[i] = 0;                                                       /* punctured columns (nr_ulsch_decoding.c:198) */
+  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+    int16_t acc = 0;
+    const bool filler = p >= j.Foffset && p < j.Foffset + j.Fin;
+    if (p < j.Ncb) {
+      acc = j.clear ? (int16_t)0 : w[p];                            /* nr_rate_matching.c:554-555 */
+      if (!filler) {
+        const uint32_t rank = p < j.Foffset ? p : p - j.Fin;
+        uint32_t k = rank >= j.rank0 ? rank - j.rank0 : rank + j.V - j.rank0;
+        for (; k < j.E; k += j.V) {                                 /* every lap that reaches this position */
+          const uint32_t i = k / EQ, jj = k - i * EQ;
+          acc = (int16_t)(acc + f[i + jj * j.Qm]);                  /* nr_rate_matching.c:310-388 + :564 */
+        }
+      }
+      if (j.clear || !filler)
+        w[p] = acc;
+    } else {
+      acc = w[p];
+    }
+    const uint32_t i = p + twoZ;
+    if (i < j.num_llr) {                                            /* nr_ulsch_decoding.c:200-210 */
+      const int v = (i >= j.K - j.F && i < j.K) ? 127 : (int)acc;
+      l[i] = (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
+    }
+  }
+}
+
+/* ---- RX 2: reassemble b from the decoded segments, TB CRC, payload out ------------------------------------------ */
+__global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_tb_job *jobs, const int32_t *n_iter,
+                                                                    uint8_t *scratch, uint8_t *payload, uint8_t *ack,
+                                                                    int32_t *iter_max, const uint32_t *pow24a,
+                                                                    const uint32_t *pow16)
+{
+  __shared__ uint32_t red[2];
+  const tb_rx_tb_job j = jobs[blockIdx.x];
+  uint8_t *b = scratch + j.b_off;
+  const uint32_t bbytes = j.B >> 3;
+  bool all_ok = true;
+  int imax = 0;
+  for (uint32_t r = 0; r < j.C; r++) {
+    const int it = n_iter[j.seg0 + r];
+    imax = it > imax ? it : imax;
+    const bool ok = it <= (int)j.num_max_iter;
+    all_ok &= ok;
+    const uint8_t *c = scratch + j.c_off0 + (size_t)r * j.c_stride;
+    for (uint32_t q = threadIdx.x; q < j.seg_bytes; q += blockDim.x) {
+      const uint32_t dst = r * j.seg_bytes + q;
+      if (dst < bbytes)
+        b[dst] = ok ? c[q] : (uint8_t)0;   /* the reference leaves stale bytes for a failed segment; here: zeros */
+    }
+  }
+  __syncthreads();
+  bool crc_ok = true;
+  if (j.C > 1)  /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
+    crc_ok = tb_block_crc(b, j.B, j.crc_type == 0 ? pow24a : pow16, red) == 0;
+  for (uint32_t q = threadIdx.x; q < (j.A >> 3); q += blockDim.x)
+    payload[j.payload_off + q] = b[q];
+  if (threadIdx.x == 0) {
+    ack[blockIdx.x] = (uint8_t)(all_ok && crc_ok);
+    iter_max[blockIdx.x] = imax;
+  }
+}
+
+#define TB_LAUNCH(kernel, n, s, ...)                                              \
+  do {                                                                            \
+    if ((n) == 0)                                                                 \
+      return hipSuccess;                                                          \
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(TB_THREADS), 0, s, __VA_ARGS__);     \
+    return hipGetLastError();                                                     \
+  } while (0)
+
+hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n, const uint8_t *payload, uint8_t *scratch,
+                            const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s)
+{
+  TB_LAUNCH(tb_tx_crc_kernel, n, s, jobs, payload, scratch, pow24a, pow16);
+}
+hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s)
+{
+  TB_LAUNCH(tb_tx_segment_kernel, n, s, jobs, scratch, pow24b);
+}
+hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s)
+{
+  TB_LAUNCH(tb_tx_ratematch_kernel, n, s, jobs, scratch, coded);
+}
+hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
+                                hipStream_t s)
+{
+  TB_LAUNCH(tb_rx_dematch_kernel, n, s, jobs, llr, harq, scratch);
+}
+hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n, const int32_t *n_iter, uint8_t *scratch,
+                                 uint8_t *payload, uint8_t *ack, int32_t *iter_max, const uint32_t *pow24a,
+                                 const uint32_t *pow16, hipStream_t s)
+{
+  TB_LAUNCH(tb_rx_assemble_kernel, n, s, jobs, n_iter, scratch, payload, ack, iter_max, pow24a, pow16);
+}

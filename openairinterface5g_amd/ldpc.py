@@ -236,3 +236,108 @@ def encode_batch_device(BG, Zc, info, out, Kb=None, stream=None):
                                in_=info.data_ptr(), in_stride=info.stride(0), out=out.data_ptr(),
                                out_stride=out.stride(0), mem=MEM_DEVICE, stream=s)
     _check(L.LDPCencoder_batch(C.byref(b)), "LDPCencoder_batch")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Transport-block chain (include/nrLDPC_hip.h: nrLDPC_hip_dlsch_encode / nrLDPC_hip_ulsch_decode)
+# ---------------------------------------------------------------------------------------------------------
+class nrLDPC_hip_tb_t(C.Structure):
+    _fields_ = [("A", C.c_uint32), ("G", C.c_uint32), ("tbslbrm", C.c_uint32), ("BG", C.c_uint8), ("Qm", C.c_uint8),
+                ("Nl", C.c_uint8), ("rv", C.c_uint8), ("numMaxIter", C.c_uint8), ("round", C.c_uint8),
+                ("llrLen", C.c_int32), ("payload_off", C.c_uint64), ("coded_off", C.c_uint64), ("harq_off", C.c_uint64)]
+
+
+class nrLDPC_hip_tb_batch_t(C.Structure):
+    _fields_ = [("n_tb", C.c_uint32), ("tb", C.POINTER(nrLDPC_hip_tb_t)), ("payload", C.c_void_p), ("coded", C.c_void_p),
+                ("harq", C.c_void_p), ("harq_stride", C.c_uint32), ("ack", C.c_void_p), ("iter_max", C.c_void_p),
+                ("mem", C.c_int32), ("stream", C.c_void_p)]
+
+
+EXPORTS += ["nrLDPC_hip_dlsch_encode", "nrLDPC_hip_ulsch_decode", "nrLDPC_hip_segmentation", "nrLDPC_hip_get_E",
+            "nrLDPC_hip_get_R_ldpc_decoder"]
+HARQ_STRIDE = 66 * 384
+
+
+def _tb_lib():
+    L = load_library()
+    L.nrLDPC_hip_dlsch_encode.argtypes = [C.POINTER(nrLDPC_hip_tb_batch_t)]
+    L.nrLDPC_hip_ulsch_decode.argtypes = [C.POINTER(nrLDPC_hip_tb_batch_t)]
+    L.nrLDPC_hip_segmentation.argtypes = [C.c_uint32, C.c_uint8] + [C.POINTER(C.c_uint32)] * 4
+    L.nrLDPC_hip_segmentation.restype = C.c_int32
+    L.nrLDPC_hip_get_E.argtypes = [C.c_uint32] * 5
+    L.nrLDPC_hip_get_E.restype = C.c_uint32
+    L.nrLDPC_hip_get_R_ldpc_decoder.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32), C.c_int32]
+    L.nrLDPC_hip_get_R_ldpc_decoder.restype = C.c_int32
+    return L
+
+
+def nr_segmentation(B, BG):
+    """Parameter part of nr_segmentation (nr_segmentation.c:32-140): dict(C, K, Z, F, Kb) or None."""
+    L = _tb_lib()
+    Cn, K, Z, F = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    kb = L.nrLDPC_hip_segmentation(B, BG, C.byref(Cn), C.byref(K), C.byref(Z), C.byref(F))
+    return None if kb < 0 else dict(C=Cn.value, K=K.value, Z=Z.value, F=F.value, Kb=kb)
+
+
+def nr_get_E(G, C_, Qm, Nl, r):
+    return _tb_lib().nrLDPC_hip_get_E(G, C_, Qm, Nl, r)
+
+
+def nr_get_R_ldpc_decoder(rv, E, BG, Z, llrLen, rnd):
+    ll = C.c_int32(llrLen)
+    R = _tb_lib().nrLDPC_hip_get_R_ldpc_decoder(rv, E, BG, Z, C.byref(ll), rnd)
+    return R, ll.value
+
+
+def _tb_array(tbs, offs_payload, offs_coded, offs_harq, numMaxIter=8):
+    arr = (nrLDPC_hip_tb_t * len(tbs))()
+    for i, t in enumerate(tbs):
+        arr[i] = nrLDPC_hip_tb_t(A=t["A"], G=t["G"], tbslbrm=t.get("tbslbrm", 0), BG=t["BG"], Qm=t["Qm"], Nl=t["Nl"],
+                                 rv=t.get("rv", 0), numMaxIter=t.get("numMaxIter", numMaxIter), round=t.get("round", 0),
+                                 llrLen=t.get("llrLen", 0), payload_off=offs_payload[i], coded_off=offs_coded[i],
+                                 harq_off=offs_harq[i] if offs_harq is not None else 0)
+    return arr
+
+
+def dlsch_encode_host(tbs, payloads):
+    """TX chain for a batch of transport blocks, host buffers.  tbs: list of dict(A, G, BG, Qm, Nl, rv, tbslbrm);
+    payloads: list of uint8[A/8].  Returns list of uint8[G] (one bit per byte, the reference's `output`)."""
+    L = _tb_lib()
+    po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    co = np.cumsum([0] + [(t["G"] + 15) // 16 * 16 for t in tbs])
+    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    for i, p in enumerate(payloads):
+        pay[po[i]:po[i] + tbs[i]["A"] // 8] = np.asarray(p, np.uint8)[:tbs[i]["A"] // 8]
+    coded = np.zeros(int(co[-1]) + 16, np.uint8)
+    arr = _tb_array(tbs, po, co, None)
+    b = nrLDPC_hip_tb_batch_t(n_tb=len(tbs), tb=arr, payload=pay.ctypes.data, coded=coded.ctypes.data, harq=None,
+                              harq_stride=0, ack=None, iter_max=None, mem=MEM_HOST, stream=None)
+    _check(L.nrLDPC_hip_dlsch_encode(C.byref(b)), "nrLDPC_hip_dlsch_encode")
+    return [coded[co[i]:co[i] + tbs[i]["G"]].copy() for i in range(len(tbs))]
+
+
+def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8):
+    """RX chain for a batch of transport blocks, host buffers.  llrs: list of int16[G]; harq: int16 array
+    [total segments, HARQ_STRIDE] holding the soft buffers of all TBs back to back (updated in place); each tb dict
+    may carry 'round' and 'llrLen' ('llrLen' is updated).  Returns (payloads, ack bool[n], iter_max int32[n])."""
+    L = _tb_lib()
+    n = len(tbs)
+    po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
+    segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
+    ho = np.cumsum([0] + [c * HARQ_STRIDE for c in segs])
+    assert harq.dtype == np.int16 and harq.flags.c_contiguous and harq.size >= ho[-1]
+    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    llr = np.zeros(int(co[-1]) + 16, np.int16)
+    for i, x in enumerate(llrs):
+        llr[co[i]:co[i] + tbs[i]["G"]] = x
+    ack = np.zeros(n, np.uint8)
+    itm = np.zeros(n, np.int32)
+    arr = _tb_array(tbs, po, co, ho, numMaxIter)
+    b = nrLDPC_hip_tb_batch_t(n_tb=n, tb=arr, payload=pay.ctypes.data, coded=llr.ctypes.data, harq=harq.ctypes.data,
+                              harq_stride=HARQ_STRIDE, ack=ack.ctypes.data, iter_max=itm.ctypes.data, mem=MEM_HOST,
+                              stream=None)
+    _check(L.nrLDPC_hip_ulsch_decode(C.byref(b)), "nrLDPC_hip_ulsch_decode")
+    for i, t in enumerate(tbs):
+        t["llrLen"] = arr[i].llrLen
+    return [pay[po[i]:po[i] + tbs[i]["A"] // 8].copy() for i in range(n)], ack.astype(bool), itm

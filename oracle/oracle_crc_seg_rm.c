@@ -270,3 +270,15 @@ void oracle_ldpctest_channel(oracle_rng_t *s, const uint8_t *coded, int n, int Z
     llr[2 * Zc + i] = oracle_quantize(sigma / 4.0 / 4.0, mod + sigma * oracle_gaussdouble(s, 0.0, 1.0), (uint8_t)qbits);
   }
 }
+
+/* openair1/PHY/NR_TRANSPORT/nr_tbs_tools.c:50-64 */
+uint32_t oracle_nr_get_E(uint32_t G, uint8_t C, uint8_t Qm, uint8_t Nl, uint8_t r)
+{
+  uint32_t E;
+  uint8_t Cprime = C;
+  if (r <= Cprime - ((G / (Nl * Qm)) % Cprime) - 1)
+    E = Nl * Qm * (G / (Nl * Qm * Cprime));
+  else
+    E = Nl * Qm * ((G / (Nl * Qm * Cprime)) + 1);
+  return E;
+}

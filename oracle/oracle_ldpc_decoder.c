@@ -206,9 +206,10 @@ int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int us
   oracle_graph_t g;
   if (oracle_ldpc_graph(BG, Z, R, &g) != 0)
     return -1;
-  int8_t *q = (int8_t *)malloc((size_t)g.nedges * Z);
-  int8_t *r = (int8_t *)calloc((size_t)g.nedges * Z, 1);
-  int8_t *app = (int8_t *)calloc((size_t)g.ncore * Z, 1);
+  /* thread-local work buffers (no allocator traffic: the multi-threaded baseline driver calls this concurrently) */
+  static __thread int8_t q[316 * 384], r[316 * 384], app[26 * 384];
+  memset(r, 0, (size_t)g.nedges * Z);
+  memset(app, 0, (size_t)g.ncore * Z);
   /* [D1] nrLDPC_mPass.h:128-221 llr2CnProcBuf: CN inputs start as the channel LLRs */
   for (int e = 0; e < g.nedges; e++)
     for (int t = 0; t < Z; t++)
@@ -234,9 +235,6 @@ int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int us
   }
   if (!use_crc) /* decoder.c:864-879 */
     write_output(&g, outMode, app, p_out);
-  free(q);
-  free(r);
-  free(app);
   return (int)numIter;
 }
 

@@ -89,6 +89,7 @@ int oracle_nr_rate_matching_ldpc(uint32_t Tbslbrm, uint8_t BG, uint16_t Z, const
 int oracle_nr_rate_matching_ldpc_rx(uint32_t Tbslbrm, uint8_t BG, uint16_t Z, int16_t *w, const int16_t *soft_input,
                                     uint8_t C, uint8_t rvidx, uint8_t clear, uint32_t E, uint32_t F,
                                     uint32_t Foffset);                                           /* :507 */
+uint32_t oracle_nr_get_E(uint32_t G, uint8_t C, uint8_t Qm, uint8_t Nl, uint8_t r); /* NR_TRANSPORT/nr_tbs_tools.c:50 */
 /* caller pre-pack: openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:195-210 */
 void oracle_nr_llr_prepack(const int16_t *d, int8_t *l, int BG, int Z, int K, int F, int ncols_R);
 

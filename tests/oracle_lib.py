@@ -68,6 +68,8 @@ def lib():
                                                    C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]
         L.oracle_nr_rate_matching_ldpc_rx.argtypes = [C.c_uint32, C.c_uint8, C.c_uint16, C.c_void_p, C.c_void_p,
                                                       C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_nr_get_E.argtypes = [C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]
+        L.oracle_nr_get_E.restype = C.c_uint32
         L.oracle_nr_llr_prepack.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
         L.oracle_randominit.argtypes = [C.POINTER(Rng), C.c_ulong]
         L.oracle_uniformrandom.argtypes = [C.POINTER(Rng)]
@@ -197,6 +199,87 @@ def llr_prepack(d, BG, Z, K, F, ncols_R):
     l = np.zeros(ncols_R * Z, dtype=np.int8)
     lib().oracle_nr_llr_prepack(_p(d), _p(l), BG, Z, K, F, ncols_R)
     return l
+
+
+def get_E(G, C_, Qm, Nl, r):
+    return lib().oracle_nr_get_E(G, C_, Qm, Nl, r)
+
+
+NR_MAX_PDSCH_TBS = 3824  # openair1/PHY/defs_nr_common.h:84
+
+
+def len_with_crc(nseg, length):  # openair1/PHY/defs_gNB.h:224-229
+    if nseg > 1:
+        return (length + 24 + 24 * nseg) // nseg
+    return length + (24 if length > NR_MAX_PDSCH_TBS else 16)
+
+
+def crc_type(nseg, length):      # openair1/PHY/defs_gNB.h:230-235
+    if nseg > 1:
+        return CRC24_B
+    return CRC24_A if length > NR_MAX_PDSCH_TBS else CRC16
+
+
+def dlsch_encode(tb, payload):
+    """The reference's TX chain for one transport block, composed from the oracle pieces exactly as
+    nr_dlsch_encoding()/ldpc8blocks() compose theirs (openair1/PHY/NR_TRANSPORT/nr_dlsch_coding.c:145-404).
+    tb: dict(A, G, BG, Qm, Nl, rv, tbslbrm). Returns uint8[G], one bit per byte."""
+    A, BG = tb["A"], tb["BG"]
+    a = np.concatenate([np.asarray(payload, np.uint8)[:A // 8], np.zeros(4, np.uint8)])
+    if A > NR_MAX_PDSCH_TBS:
+        c = crc("crc24a", a, A) >> 8
+        a[A // 8:A // 8 + 3] = [(c >> 16) & 255, (c >> 8) & 255, c & 255]
+        B = A + 24
+    else:
+        c = crc("crc16", a, A) >> 16
+        a[A // 8:A // 8 + 2] = [(c >> 8) & 255, c & 255]
+        B = A + 16
+    s = segmentation(a, B, BG)
+    Z, K, F, Cn = s["Z"], s["K"], s["F"], s["C"]
+    out = []
+    for r in range(Cn):
+        d = encode(BG, Z, s["segs"][r], s["Kb"]).copy()
+        if F:
+            d[K - F - 2 * Z:K - 2 * Z] = 2                       # NR_NULL (nr_dlsch_coding.c:177-180)
+        E = get_E(tb["G"], Cn, tb["Qm"], tb["Nl"], r)
+        rc, e = rate_match(tb["tbslbrm"], BG, Z, d, Cn, F, K - F - 2 * Z, tb["rv"], E)
+        assert rc == 0
+        out.append(interleave(E, tb["Qm"], e))
+    return np.concatenate(out)
+
+
+def ulsch_decode(tb, llr, harq_d, max_iter=8, rnd=0, llrLen=0):
+    """The reference's RX chain for one transport block (nr_ulsch_decoding.c:122-470 + nr_postDecode).
+    llr: int16[G]; harq_d: list of C int16 arrays (soft buffers, updated in place).
+    Returns (payload uint8[A/8], ack, per-segment pass counts, llrLen)."""
+    A, BG = tb["A"], tb["BG"]
+    B = len_with_crc(1, A)
+    s = segmentation(None, B, BG)
+    Z, K, F, Cn = s["Z"], s["K"], s["F"], s["C"]
+    b = np.zeros(B // 8 + 4, np.uint8)
+    offset = r_off = 0
+    iters, all_ok = [], True
+    for r in range(Cn):
+        E = get_E(tb["G"], Cn, tb["Qm"], tb["Nl"], r)
+        R, llrLen = get_R(tb["rv"], E, BG, Z, llrLen, rnd)
+        e = deinterleave(E, tb["Qm"], llr[r_off:r_off + E])
+        rc, d = rate_match_rx(tb["tbslbrm"], BG, Z, harq_d[r], e, Cn, tb["rv"], 1 if rnd == 0 else 0, E, F, K - F - 2 * Z)
+        assert rc == 0
+        harq_d[r][:] = d
+        l = llr_prepack(d, BG, Z, K, F, NCOLS[(BG, R)])
+        n, out = decode(BG, Z, R, l, max_iter, OUT_BIT, True, len_with_crc(Cn, A), crc_type(Cn, A))
+        iters.append(n)
+        nb = K // 8 - F // 8 - (3 if Cn > 1 else 0)
+        if n <= max_iter:
+            b[offset:offset + nb] = out[:nb]
+        else:
+            all_ok = False
+        offset += nb
+        r_off += E
+    crc_ok = True
+    if Cn > 1:
+        crc_ok = bool(check_crc(b, len_with_crc(1, A), crc_type(1, A)))
+    return b[:A // 8], bool(all_ok and crc_ok), iters, llrLen
 
 
 class OaiRng:

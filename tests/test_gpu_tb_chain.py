@@ -1,0 +1,113 @@
+"""-m gpu: transport-block chain on the GPU (TB CRC, segmentation, encode, rate matching, interleaving; and back:
+de-interleaving, rate de-matching with HARQ combining, pack, decode with CRC stop, reassembly, TB CRC) vs the same
+chain composed from the oracle pieces the way the reference composes its functions."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def valid_tbs(target_bits, BG):
+    """Smallest A >= target whose segmentation is byte aligned, as every 38.214 TBS is (the reference copies bytes)."""
+    A = (target_bits + 7) // 8 * 8
+    while True:
+        B = O.len_with_crc(1, A)
+        s = O.segmentation(None, B, BG)
+        L = 24 if s["C"] > 1 else 0
+        if (s["K"] - s["F"] - L) % 8 == 0 and s["F"] % 8 == 0 and (B + L * s["C"]) % s["C"] == 0:
+            return A
+        A += 8
+
+
+def make_tbs():
+    mk = lambda bits, G, BG, Qm, Nl, rv=0, lbrm=0: dict(A=valid_tbs(bits, BG), G=G, BG=BG, Qm=Qm, Nl=Nl, rv=rv, tbslbrm=lbrm)
+    return [
+        mk(9600, 2 * 12 * 100 * 14, 1, 4, 1),            # 2 segments, 16QAM
+        mk(32000, 60000, 1, 6, 2),                       # 4 segments Zc=384, 64QAM, 2 layers
+        mk(5000, 14400, 2, 2, 1),                        # BG2, 2 segments
+        mk(800, 2400, 2, 2, 1),                          # single BG2 segment, CRC16
+        mk(3824, 12000, 1, 4, 1),                        # largest CRC16 block
+        mk(3832, 9600, 1, 8, 1),                         # smallest CRC24A block, 256QAM
+        mk(100000, 8 * 4 * 9000, 1, 8, 4, rv=0),         # 12 segments, 4 layers
+        mk(20000, 26400, 1, 2, 1, rv=2),                 # rv 2 start
+        mk(20000, 80000, 1, 4, 1, rv=3),                 # repetition (E > Ncb)
+        mk(30000, 54000, 1, 6, 1, rv=1, lbrm=40000 // 8 * 3),   # limited-buffer rate matching
+        mk(264, 1200, 2, 2, 1),                          # Kb = 8 (B in (192, 560])
+        mk(24, 240, 2, 2, 1),                            # Kb = 6
+        mk(600, 1800, 2, 2, 1),                          # Kb = 9 / 10 boundary
+    ]
+
+
+def test_dlsch_encode_matches_reference_chain(hip):
+    rng = np.random.default_rng(1)
+    tbs = make_tbs()
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+    for t, p, f in zip(tbs, pays, coded):
+        ref = O.dlsch_encode(t, p)
+        assert f.size == t["G"] == ref.size
+        assert np.array_equal(f, ref), t
+
+
+def test_ulsch_decode_matches_reference_chain_with_harq(hip):
+    """Two HARQ rounds (rv 0 then rv 2) at an SNR where the first round fails for some blocks: payload, ACK, pass
+    counts, soft buffers and the llrLen state must equal the oracle chain's after each round."""
+    rng = np.random.default_rng(2)
+    tbs = [t for t in make_tbs() if t["rv"] == 0 and t["tbslbrm"] == 0][:7]
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    harq_gpu = np.zeros((sum(segs), stride), np.int16)
+    harq_ref = [[np.zeros(stride, np.int16) for _ in range(c)] for c in segs]
+    state_ref = [0] * len(tbs)
+    for rnd, rv, sigma in ((0, 0, 9.0), (1, 2, 6.0)):
+        llrs = []
+        for t, p in zip(tbs, pays):
+            t["rv"], t["round"] = rv, rnd
+            f = O.dlsch_encode(t, p)
+            llrs.append(np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + sigma * rng.standard_normal(f.size)), -200, 200).astype(np.int16))
+        out, ack, itm = hip.ldpc.ulsch_decode_host(tbs, llrs, harq_gpu, numMaxIter=8)
+        row = 0
+        for i, t in enumerate(tbs):
+            p_ref, ack_ref, its, state_ref[i] = O.ulsch_decode(t, llrs[i], harq_ref[i], 8, rnd, state_ref[i])
+            assert bool(ack[i]) == ack_ref and itm[i] == max(its), (rnd, t, its, int(itm[i]))
+            assert t["llrLen"] == state_ref[i]
+            if ack_ref:
+                assert np.array_equal(out[i], p_ref) and np.array_equal(out[i], pays[i])
+            for r in range(segs[i]):
+                assert np.array_equal(harq_gpu[row + r], harq_ref[i][r]), (rnd, i, r)
+            row += segs[i]
+    assert ack.all()                                          # after combining every block decodes
+
+
+def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
+    rng = np.random.default_rng(3)
+    tbs = make_tbs()
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+    llrs = [((1 - 2 * f.astype(np.int16)) * 24 + rng.integers(-10, 11, f.size)).astype(np.int16) for f in coded]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    harq = np.zeros((sum(segs), hip.ldpc.HARQ_STRIDE), np.int16)
+    for t in tbs:
+        t["round"] = 0
+    out, ack, itm = hip.ldpc.ulsch_decode_host(tbs, llrs, harq)
+    for i, t in enumerate(tbs):
+        if t["rv"] in (0, 3) or t["G"] > 2 * t["A"]:           # self-decodable transmissions
+            assert ack[i] and np.array_equal(out[i], pays[i]), (t, int(itm[i]))
+    # a corrupted block is NACKed
+    bad = [l.copy() for l in llrs]
+    bad[1][:] = rng.integers(-5, 6, bad[1].size)
+    harq[:] = 0
+    out, ack, itm = hip.ldpc.ulsch_decode_host(tbs, bad, harq)
+    assert not ack[1] and itm[1] == 9 and ack[0]
+
+
+def test_invalid_parameters(hip):
+    with pytest.raises(RuntimeError):
+        hip.ldpc.dlsch_encode_host([dict(A=1001, G=4000, BG=1, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])     # A % 8
+    with pytest.raises(RuntimeError):
+        hip.ldpc.dlsch_encode_host([dict(A=1000, G=4001, BG=1, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])     # G % (Nl*Qm)
+    with pytest.raises(RuntimeError):
+        hip.ldpc.dlsch_encode_host([dict(A=1000, G=4000, BG=3, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])
