@@ -33,7 +33,7 @@ def make_tbs():
         mk(100000, 8 * 4 * 9000, 1, 8, 4, rv=0),         # 12 segments, 4 layers
         mk(20000, 26400, 1, 2, 1, rv=2),                 # rv 2 start
         mk(20000, 80000, 1, 4, 1, rv=3),                 # repetition (E > Ncb)
-        mk(30000, 54000, 1, 6, 1, rv=1, lbrm=40000 // 8 * 3),   # limited-buffer rate matching
+        mk(30000, 54000, 1, 6, 1, rv=1, lbrm=24000),            # limited-buffer rate matching (Ncb = 9000 < N)
         mk(264, 1200, 2, 2, 1),                          # Kb = 8 (B in (192, 560])
         mk(24, 240, 2, 2, 1),                            # Kb = 6
         mk(600, 1800, 2, 2, 1),                          # Kb = 9 / 10 boundary
