@@ -341,3 +341,42 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8):
     for i, t in enumerate(tbs):
         t["llrLen"] = arr[i].llrLen
     return [pay[po[i]:po[i] + tbs[i]["A"] // 8].copy() for i in range(n)], ack.astype(bool), itm
+
+
+def tb_layout(tbs):
+    """Offsets used by the *_device transport-block calls: payload bytes, coded elements, harq int16 elements."""
+    po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    co = np.cumsum([0] + [(t["G"] + 15) // 16 * 16 for t in tbs])
+    segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
+    ho = np.cumsum([0] + [c * HARQ_STRIDE for c in segs])
+    return po, co, ho, segs
+
+
+def dlsch_encode_device(tbs, payload, coded, stream=None):
+    """payload: torch uint8 [>= tb_layout po[-1]] on the GPU, coded: torch uint8 [>= co[-1]] (out). Asynchronous."""
+    import torch
+    L = _tb_lib()
+    po, co, _, _ = tb_layout(tbs)
+    assert payload.is_cuda and coded.is_cuda and payload.numel() >= po[-1] and coded.numel() >= co[-1]
+    arr = _tb_array(tbs, po, co, None)
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    b = nrLDPC_hip_tb_batch_t(n_tb=len(tbs), tb=arr, payload=payload.data_ptr(), coded=coded.data_ptr(), harq=None,
+                              harq_stride=0, ack=None, iter_max=None, mem=MEM_DEVICE, stream=s)
+    _check(L.nrLDPC_hip_dlsch_encode(C.byref(b)), "nrLDPC_hip_dlsch_encode")
+
+
+def ulsch_decode_device(tbs, llr, harq, payload, ack, iter_max, numMaxIter=8, stream=None):
+    """llr: torch int16 [>= co[-1]], harq: torch int16 [>= ho[-1]], payload: torch uint8 [>= po[-1]] (out),
+    ack: torch uint8 [n], iter_max: torch int32 [n].  Asynchronous; tb dicts get their llrLen updated."""
+    import torch
+    L = _tb_lib()
+    po, co, ho, _ = tb_layout(tbs)
+    assert llr.is_cuda and llr.dtype == torch.int16 and harq.dtype == torch.int16 and harq.numel() >= ho[-1]
+    arr = _tb_array(tbs, po, co, ho, numMaxIter)
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    b = nrLDPC_hip_tb_batch_t(n_tb=len(tbs), tb=arr, payload=payload.data_ptr(), coded=llr.data_ptr(), harq=harq.data_ptr(),
+                              harq_stride=HARQ_STRIDE, ack=ack.data_ptr(), iter_max=iter_max.data_ptr(), mem=MEM_DEVICE,
+                              stream=s)
+    _check(L.nrLDPC_hip_ulsch_decode(C.byref(b)), "nrLDPC_hip_ulsch_decode")
+    for i, t in enumerate(tbs):
+        t["llrLen"] = arr[i].llrLen

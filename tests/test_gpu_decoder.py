@@ -170,3 +170,19 @@ def test_full_size_batch_properties_device(hip):
     ok0 = (it0 <= 8).cpu().numpy()
     assert abs(ok0.mean() - ok.mean()) < 0.01
     assert int(out0[torch.from_numpy(ok0).cuda()][:, :K // 8].max()) == 0
+
+
+def test_ldpctest_acceptance_and_seed_identical_bler(hip):
+    """The reference CI's acceptance criterion for the library (`ldpctest -l{3872..8448} -s10 -n100` must print
+    `BLER 0.000000`, cmake_targets/autotests/test_case_list.xml:68-94) on a subset, and -- on identical AWGN seeds --
+    the very same per-block pass counts and BLER as the CPU oracle at a low SNR where blocks do fail."""
+    import io
+    import ldpctest_hip as T
+    for length in (3872, 5632, 8448):
+        buf = io.StringIO()
+        res = T.run(T.parser().parse_args(["-l", str(length), "-s", "10", "-n", "25"]), out=buf)
+        assert "BLER 0.000000" in buf.getvalue() and res[-1]["errors"] == 0
+    args = ["-l", "8448", "-s", "0.0", "-t", "5", "-n", "12", "-i", "8", "-S", "2", "--seed", "77"]
+    gpu = T.run(T.parser().parse_args(args), out=io.StringIO())
+    cpu = T.run(T.parser().parse_args(args + ["--oracle"]), out=io.StringIO())
+    assert gpu == cpu and gpu[0]["errors"] > 0

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Supplementary measurements for BASELINE.json configs[2..4] and the per-segment ABI (not the driver's bench line).
+
+  python tools/bench_extra.py > gpurun_out/bench_extra.json
+"""
+import json
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+import openairinterface5g_amd as pkg  # noqa: E402
+
+m = pkg.ldpc
+pkg.LDPCinit()
+res = {}
+
+
+def timeit(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def noisy_llr(BG, Z, R, n, snr_db, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    K = (22 if BG == 1 else 10) * Z
+    N = (66 if BG == 1 else 50) * Z
+    info = torch.randint(0, 256, (n, K // 8), dtype=torch.uint8, device="cuda", generator=g)
+    coded = torch.empty((n, N), dtype=torch.uint8, device="cuda")
+    pkg.encode_batch_device(BG, Z, info, coded)
+    ntx = (m.NCOLS[(BG, R)] - 2) * Z
+    sigma = 1.0 / np.sqrt(2.0 * 10.0 ** (snr_db / 10.0))
+    y = 1.0 - 2.0 * coded[:, :ntx].float() + sigma * torch.randn((n, ntx), device="cuda", generator=g)
+    llr = torch.zeros((n, (m.NCOLS[(BG, R)] * Z + 15) // 16 * 16), dtype=torch.int8, device="cuda")
+    llr[:, 2 * Z:2 * Z + ntx] = torch.clamp(torch.floor(y / (sigma / 16.0)), -128, 127).to(torch.int8)
+    return info, llr
+
+
+# ---- config 3: BG2 Zc=64 / Zc=208 short-block mixed batch (URLLC style): 4 launches on one stream -------------------
+groups = [(2, 64, 15, 256), (2, 64, 13, 256), (2, 208, 15, 256), (2, 208, 13, 256)]
+for regime, snr in (("fixed_work", -12.0), ("operating_point", 1.0)):
+    bufs = []
+    for (BG, Z, R, n) in groups:
+        _, llr = noisy_llr(BG, Z, R, n, snr, 7 * Z + R)
+        out = torch.zeros((n, m.out_bytes(BG, Z, R)), dtype=torch.uint8, device="cuda")
+        it = torch.zeros(n, dtype=torch.int32, device="cuda")
+        bufs.append((BG, Z, R, llr, out, it))
+
+    def run():
+        for (BG, Z, R, llr, out, it) in bufs:
+            pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+    dt = timeit(run, 50)
+    bits = sum(n * 50 * Z for (_, Z, _, n) in groups)
+    res[f"config3_mixed_bg2_z64_z208_{regime}"] = {
+        "blocks": sum(g[3] for g in groups), "ms": dt * 1e3, "coded_gbps": bits / dt / 1e9,
+        "mean_passes": float(np.mean([b[5].float().mean().item() for b in bufs]))}
+
+# ---- config 4/5: 64 transport blocks of 273 PRB x 13 symbols, 64QAM, 1 layer (TBS ~213 kbit) through the TB chain ----
+A = 213176
+while True:
+    B = A + 24
+    s = m.nr_segmentation(B, 1)
+    if s is not None:
+        break
+    A += 8
+G = (12 * 13 - 6) * 273 * 6
+n_tb = 64
+tbs = [dict(A=A, G=G, BG=1, Qm=6, Nl=1, rv=0, tbslbrm=0, round=0) for _ in range(n_tb)]
+po, co, ho, segs = m.tb_layout(tbs)
+payload = torch.randint(0, 256, (int(po[-1]) + 16,), dtype=torch.uint8, device="cuda")
+coded = torch.zeros(int(co[-1]) + 16, dtype=torch.uint8, device="cuda")
+dt_enc = timeit(lambda: m.dlsch_encode_device(tbs, payload, coded), 20)
+res["config4_dlsch_encode_64tb_273prb_64qam"] = {
+    "tb_bits": A, "G": G, "segments_per_tb": segs[0], "ms": dt_enc * 1e3,
+    "info_gbps": n_tb * A / dt_enc / 1e9, "coded_gbps": n_tb * G / dt_enc / 1e9}
+sigma = 0.18
+llr = ((1.0 - 2.0 * coded.float()) * 10 + sigma * 10 * torch.randn(coded.numel(), device="cuda")).round().clamp(-127, 127).to(torch.int16)
+harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
+pay_out = torch.zeros_like(payload)
+ack = torch.zeros(n_tb, dtype=torch.uint8, device="cuda")
+itm = torch.zeros(n_tb, dtype=torch.int32, device="cuda")
+dt_dec = timeit(lambda: m.ulsch_decode_device(tbs, llr, harq, pay_out, ack, itm), 20)
+ok = bool(ack.all().item()) and all(torch.equal(pay_out[po[i]:po[i] + A // 8], payload[po[i]:po[i] + A // 8]) for i in range(n_tb))
+res["config5_ulsch_decode_64tb_273prb_64qam"] = {
+    "tb_bits": A, "G": G, "segments": int(sum(segs)), "ms": dt_dec * 1e3, "info_gbps": n_tb * A / dt_dec / 1e9,
+    "coded_gbps": n_tb * G / dt_dec / 1e9, "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
+
+# ---- per-segment reference ABI (LDPCdecoder, host buffers): latency and multi-thread throughput ------------------------
+BG, Z, R = 1, 384, 13
+_, llr_d = noisy_llr(BG, Z, R, 64, 1.0, 99)
+llr_h = llr_d.cpu().numpy()
+p = pkg.make_dec_params(BG, Z, R, 8)
+
+
+def one(i):
+    return pkg.LDPCdecoder(p, llr_h[i % 64])[0]
+
+
+one(0)
+t0 = time.perf_counter()
+for i in range(200):
+    one(i)
+lat = (time.perf_counter() - t0) / 200
+res["abi_LDPCdecoder_single_thread"] = {"us_per_call": lat * 1e6, "coded_gbps": 66 * Z / lat / 1e9}
+for T in (4, 16, 64):
+    per = 100
+
+    def worker(k):
+        pp = pkg.make_dec_params(BG, Z, R, 8)
+        for i in range(per):
+            pkg.LDPCdecoder(pp, llr_h[(k + i) % 64])
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    res[f"abi_LDPCdecoder_{T}_threads"] = {"blocks_per_s": T * per / dt, "coded_gbps": T * per * 66 * Z / dt / 1e9}
+print(json.dumps(res, indent=1))
