@@ -22,6 +22,9 @@
 #define LDPC_DEC_FAST_CORE_H
 #include "ldpc_dec_core.h"
 
+#if !defined(__HIPCC__)
+struct uint2 { uint32_t x, y; };
+#endif
 typedef short ldpc_v2i __attribute__((ext_vector_type(2)));
 typedef unsigned short ldpc_v2u __attribute__((ext_vector_type(2)));
 
@@ -205,16 +208,33 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
   const int u = 4 * j;
   const int c = (int)(colrec & 0xffu), deg = (int)((colrec >> 8) & 0xffu), start = (int)(colrec >> 16);
   uint32_t acc_e = 0, acc_o = 0; /* packed 16-bit sums of the biased bytes: lanes (0,2) and (1,3) */
-  for (int k = 0; k < maxdeg; k++) {
-    if (k < deg) {
-      const uint32_t ce = L.ctbl[start + k];
-      const int s = (int)(ce & 0x1ffu), roff = (int)(ce >> 9);
-      int p = u - s;
-      p = p < 0 ? p + Z : p;
-      const uint32_t w = ldpc_window(L.r + roff, p);
-      acc_e += w & 0x00ff00ffu;
-      acc_o += (w >> 8) & 0x00ff00ffu;
+  /* The gather is a chain table entry -> address -> window per edge; four edges are kept in flight.  Table entry =
+   * {Z - shift, row offset}; columns with fewer than maxdeg edges are padded with entries that point at a row of
+   * zero bytes (contribution 0), so there is no predication. */
+  const uint2 *tbl = reinterpret_cast<const uint2 *>(L.ctbl) + start;
+  int k = 0;
+  for (; k + 4 <= maxdeg; k += 4) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint2 ce = tbl[k + i];
+      const uint32_t q = (uint32_t)u + ce.x;            /* u + Z - shift in [1, 2Z) */
+      const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z; /* mod Z: q - Z wraps to a huge value when q < Z */
+      w[i] = ldpc_window(L.base, (int)(ce.y + p));
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc_e += w[i] & 0x00ff00ffu;
+      acc_o += (w[i] >> 8) & 0x00ff00ffu;
+    }
+  }
+  for (; k < maxdeg; k++) {
+    const uint2 ce = tbl[k];
+    const uint32_t q = (uint32_t)u + ce.x;
+    const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z;
+    const uint32_t v = ldpc_window(L.base, (int)(ce.y + p));
+    acc_e += v & 0x00ff00ffu;
+    acc_o += (v >> 8) & 0x00ff00ffu;
   }
   const uint32_t lw = llr_word ^ 0x80808080u;
   acc_e += lw & 0x00ff00ffu;

@@ -17,7 +17,10 @@
 __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-  const ldpc_dec_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  /* job records and descriptors are read through the constant address space: uniform address -> scalar loads,
+   * so everything derived from them stays in SGPRs */
+  typedef const ldpc_dec_job LDPC_CONST_AS *job_ptr_t;
+  const job_ptr_t job = a.jobs ? (job_ptr_t)a.jobs + blockIdx.x : (job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code); /* never written while a kernel runs */
   const int Z = code->Z;
   int8_t *r = smem + code->lds_r;

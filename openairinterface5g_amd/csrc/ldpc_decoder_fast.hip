@@ -16,7 +16,10 @@ template <int MAX_THREADS>
 __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  const ldpc_dec_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  /* job records and descriptors are read through the constant address space: uniform address -> scalar loads,
+   * so everything derived from them stays in SGPRs */
+  typedef const ldpc_dec_job LDPC_CONST_AS *job_ptr_t;
+  const job_ptr_t job = a.jobs ? (job_ptr_t)a.jobs + blockIdx.x : (job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
   const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
   const uint32_t zq_magic = code->f_zq_magic;
@@ -42,8 +45,10 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
   for (int i = tid; i < nedges; i += nt)
     etbl[i] = code->f_etbl[i];
-  for (int i = tid; i < code->col_ptr[ncore]; i += nt)
+  for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
     ctbl[i] = code->f_ctbl[i];
+  for (int i = tid; i < (Z + 4) >> 2; i += nt)
+    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   for (int i = tid; i < code->nrows; i += nt)
     rowtbl[i] = code->f_rowtbl[i];
   for (int i = tid; i < ncore; i += nt)
@@ -79,6 +84,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const int bn0 = code->f_bn_ptr[wave], bn1 = code->f_bn_ptr[wave + 1];
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
+#ifdef LDPC_ABLATE_CN
+    syn = 1;
+#else
     for (int ti = cn0; ti < cn1; ti++) {
       const int task = LDPC_UNIFORM(code->f_cn_list[ti]);
       const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
@@ -94,6 +102,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
         syn |= m & mask;
       }
     }
+#endif
     if (__any(syn != 0) && lane == 0)
       flags[p & 1] = 1;
     if (tid == 0)
@@ -103,6 +112,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
       n_iter = p - 1;
       break;
     }
+#ifndef LDPC_ABLATE_BN
     for (int ti = bn0; ti < bn1; ti++) {
       const int task = LDPC_UNIFORM(code->f_bn_list[ti]);
       const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
@@ -114,6 +124,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
         ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
       }
     }
+#endif
     if (tid == 0)
       flags[(p + 1) & 1] = 0;
     __syncthreads();

@@ -10,7 +10,8 @@
 __global__ void __launch_bounds__(1024) ldpc_enc_kernel(const ldpc_enc_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t esm[];
-  const ldpc_enc_job *job = a.jobs ? a.jobs + blockIdx.x : nullptr;
+  typedef const ldpc_enc_job LDPC_CONST_AS *job_ptr_t;
+  const job_ptr_t job = a.jobs ? (job_ptr_t)a.jobs + blockIdx.x : (job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
   uint8_t *x = esm;
   uint8_t *lam = esm + ((code->ncols * code->Z + 15) & ~15);

@@ -80,7 +80,6 @@ static void build_fast_section(ldpc_code_desc_t *d)
   d->f_zq_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq - 1) / (uint64_t)zq);
   d->f_rstride = Z + 4;
   d->f_astride = 2 * Z;
-  int ncore_edges = d->col_ptr[d->ncore];
 
   /* rows sorted by degree (descending, stable) */
   sort_item_t rows[LDPC_MAX_ROWS];
@@ -135,15 +134,29 @@ static void build_fast_section(ldpc_code_desc_t *d)
     cols[c].id = c;
   }
   qsort(cols, d->ncore, sizeof(cols[0]), by_key_desc);
+  /* adjacency lists in sorted-column order, padded (see ldpc_graph.h); the row offsets are filled in below once the
+   * LDS layout is known */
+  const int span = (63 + zq - 1) / zq; /* how many earlier columns can share a 64-item task with a column */
   int n = 0;
   for (int i = 0; i < d->ncore; i++) {
     const int c = cols[i].id;
+    const int padded = cols[i - span > 0 ? i - span : 0].key;
+    if (n + padded > LDPC_F_MAX_CTBL)
+      return;
     d->f_coltbl[i] = (uint32_t)c | ((uint32_t)cols[i].key << 8) | ((uint32_t)n << 16);
-    for (int k = d->col_ptr[c]; k < d->col_ptr[c + 1]; k++) {
-      const uint32_t ce = d->col_edge[k];
-      d->f_ctbl[n++] = (((ce >> 16) * (uint32_t)d->f_rstride) << 9) | (ce & 0xffffu);
+    int k = 0;
+    for (int e = d->col_ptr[c]; e < d->col_ptr[c + 1]; e++, k++) {
+      const uint32_t ce = d->col_edge[e];
+      d->f_ctbl[2 * (n + k)] = (uint32_t)Z - (ce & 0xffffu);
+      d->f_ctbl[2 * (n + k) + 1] = (ce >> 16) * (uint32_t)d->f_rstride; /* + f_lds_r below */
     }
+    for (; k < padded; k++) {
+      d->f_ctbl[2 * (n + k)] = (uint32_t)Z;
+      d->f_ctbl[2 * (n + k) + 1] = 0xffffffffu; /* -> f_lds_zero below */
+    }
+    n += padded;
   }
+  d->f_n_ctbl = n;
   const int nitems = d->ncore * zq;
   int nb = 0, bcost[LDPC_F_MAX_CN_TASKS];
   for (int b = 0; b < nitems; b += 64) {
@@ -169,12 +182,15 @@ static void build_fast_section(ldpc_code_desc_t *d)
   d->f_lds_ext = d->f_lds_app + align16(d->ncore * d->f_astride);
   d->f_lds_etbl = d->f_lds_ext + align16((d->ncols - d->ncore) * Z);
   d->f_lds_ctbl = d->f_lds_etbl + align16(d->nedges * 4);
-  d->f_lds_rowtbl = d->f_lds_ctbl + align16(ncore_edges * 4);
+  d->f_lds_rowtbl = d->f_lds_ctbl + align16(d->f_n_ctbl * 8);
   d->f_lds_coltbl = d->f_lds_rowtbl + align16(d->nrows * 4);
-  d->f_lds_misc = d->f_lds_coltbl + align16(d->ncore * 4);
+  d->f_lds_zero = d->f_lds_coltbl + align16(d->ncore * 4);
+  d->f_lds_misc = d->f_lds_zero + align16(Z + 4);
   d->f_lds_total = d->f_lds_misc + 64;
   if (d->f_lds_total > 160 * 1024)
     return;
+  for (int i = 0; i < d->f_n_ctbl; i++)
+    d->f_ctbl[2 * i + 1] = d->f_ctbl[2 * i + 1] == 0xffffffffu ? (uint32_t)d->f_lds_zero : d->f_ctbl[2 * i + 1] + (uint32_t)d->f_lds_r;
   /* edge table: absolute LDS byte offset of the neighbour's row start + shift */
   for (int e = 0; e < d->nedges; e++) {
     const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);

@@ -23,6 +23,7 @@
 #define LDPC_F_DEFAULT_WAVES 16 /* waves per workgroup the fast kernel uses for large codes */
 #define LDPC_F_MAX_CN_TASKS 96
 #define LDPC_F_MAX_BN_TASKS 48
+#define LDPC_F_MAX_CTBL 800 /* <= 26 columns x degree 30 when every list is padded to the maximum */
 
 typedef struct ldpc_code_desc {
   int32_t BG, Z, R, ils;
@@ -87,7 +88,12 @@ typedef struct ldpc_code_desc {
   uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;
                                             extension column: f_lds_ext + (col-ncore)*Z */
   uint32_t f_coltbl[LDPC_MAX_CORE + 2];  /* per sorted column: col | degree << 8 | first entry in f_ctbl << 16 */
-  uint32_t f_ctbl[LDPC_MAX_EDGES + 4];   /* per (sorted column, edge): (edge*rstride) << 9 | shift */
+  /* per (sorted column, k): two dwords {Z - shift, LDS byte offset of the edge's message row}.  A column's list is
+   * padded up to the degree of the earliest column it can share a task with; padding entries {Z, f_lds_zero} point
+   * at a row of zero bytes, so short columns need no predication in the gather loop. */
+  uint32_t f_ctbl[2 * LDPC_F_MAX_CTBL];
+  int32_t f_n_ctbl;   /* entries (pairs) used */
+  int32_t f_lds_zero; /* Z + 4 zero bytes */
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus

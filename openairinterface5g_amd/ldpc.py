@@ -77,7 +77,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("NRLDPC_HIP_LIB", LIB_PATH))   # (env: A/B builds of the library)
     if not p.exists():
         raise RuntimeError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"or `make -C {_PKG / 'csrc'}` -- there is no CPU fallback")

@@ -156,7 +156,8 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
     crc_pow_table(polys[crc_type], crc_pow, 8448);
 
   for (int i = 0; i < nedges; i++) etbl[i] = code->f_etbl[i];
-  for (int i = 0; i < code->col_ptr[ncore]; i++) ctbl[i] = code->f_ctbl[i];
+  for (int i = 0; i < 2 * code->f_n_ctbl; i++) ctbl[i] = code->f_ctbl[i];
+  for (int i = 0; i < (Z + 4) >> 2; i++) reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   for (int i = 0; i < code->nrows; i++) rowtbl[i] = code->f_rowtbl[i];
   for (int i = 0; i < ncore; i++) coltbl[i] = code->f_coltbl[i];
   for (int i = 0; i < ncore * zq; i++) {
