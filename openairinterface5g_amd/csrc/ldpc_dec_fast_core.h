@@ -98,11 +98,45 @@ LDPC_HD uint32_t ldpc_window(const uint8_t *base, int off)
  *            flipped when D-1 is odd (bit 15 counts the NON-negative ones)
  * Only the packed min/max/shift/negate run on the half-rate packed-16 pipe; the rest are full-rate
  * 32-bit ALU ops that cannot carry between the halves by construction. */
-template <int D, bool EXT, bool KEEP>
+/* D1 pairs of one edge (see above) from the LDS words; `first` additionally folds the edge into the syndrome
+ * accumulators (only wanted once per edge). */
+template <bool IS_EXT>
+LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uint32_t rw, bool first, uint32_t &dl, uint32_t &dh,
+                               uint32_t &parw, uint32_t &extl, uint32_t &exth)
+{
+  uint32_t al, ah, rl, rh;
+  if (IS_EXT) {
+    const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.base + info + t);
+    al = ldpc_perm(0x80808080u, lw, 0x05010400u);
+    ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
+    if (first) { /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
+      extl = al + ldpc_perm(0u, rw, 0x0c010c00u);
+      exth = ah + ldpc_perm(0u, rw, 0x0c030c02u);
+    }
+    rl = 0x00800080u; /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
+    rh = 0x00800080u;
+  } else {
+    const uint32_t aw = ldpc_window(L.base, (int)info + t);
+    if (first)
+      parw ^= aw;
+    al = ldpc_perm(0x80808080u, aw, 0x05010400u); /* (0x8000 | byte 0), (0x8000 | byte 1) */
+    ah = ldpc_perm(0x80808080u, aw, 0x05030402u);
+    rl = ldpc_perm(0u, rw, 0x0c010c00u);
+    rh = ldpc_perm(0u, rw, 0x0c030c02u);
+  }
+  dl = al - rl;
+  dh = ah - rh;
+}
+
+/* MODE 0: D1 and the magnitudes of every edge stay in registers between the two sweeps; 1: D1 only (magnitudes
+ * recomputed); 2: nothing (the second sweep re-reads LDS and recomputes D1) -- for the degree-19 rows, whose 38+
+ * live registers would otherwise spill at 16 waves per workgroup. */
+template <int D, bool EXT, int MODE>
 LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
 {
   const int t = 4 * j;
-  uint32_t d_lo[D], d_hi[D], g_lo[KEEP ? D : 1], g_hi[KEEP ? D : 1];
+  constexpr bool KEEP = MODE == 0;
+  uint32_t d_lo[MODE <= 1 ? D : 1], d_hi[MODE <= 1 ? D : 1], g_lo[KEEP ? D : 1], g_hi[KEEP ? D : 1];
   ldpc_v2u m1l = ldpc_splatu(0xffff), m2l = m1l, m1h = m1l, m2h = m1l;
   uint32_t sxl = 0, sxh = 0, parw = 0, extl = 0, exth = 0;
   uint8_t *rrow = L.r + e0 * rstride + t;
@@ -111,27 +145,15 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   for (int k = 0; k < D; k++) {
     const uint32_t info = L.etbl[e0 + k];
     const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
-    uint32_t al, ah, rl, rh;
-    if (EXT && k == D - 1) {
-      const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.base + info + t);
-      al = ldpc_perm(0x80808080u, lw, 0x05010400u);
-      ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
-      /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
-      extl = al + ldpc_perm(0u, rw, 0x0c010c00u);
-      exth = ah + ldpc_perm(0u, rw, 0x0c030c02u);
-      rl = 0x00800080u; /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
-      rh = 0x00800080u;
-    } else {
-      const uint32_t aw = ldpc_window(L.base, (int)info + t);
-      parw ^= aw;
-      al = ldpc_perm(0x80808080u, aw, 0x05010400u); /* (0x8000 | byte 0), (0x8000 | byte 1) */
-      ah = ldpc_perm(0x80808080u, aw, 0x05030402u);
-      rl = ldpc_perm(0u, rw, 0x0c010c00u);
-      rh = ldpc_perm(0u, rw, 0x0c030c02u);
+    uint32_t dl, dh;
+    if (EXT && k == D - 1)
+      ldpc_fast_cn_edge<true>(L, info, t, rw, true, dl, dh, parw, extl, exth);
+    else
+      ldpc_fast_cn_edge<false>(L, info, t, rw, true, dl, dh, parw, extl, exth);
+    if (MODE <= 1) {
+      d_lo[k] = dl;
+      d_hi[k] = dh;
     }
-    const uint32_t dl = al - rl, dh = ah - rh;
-    d_lo[k] = dl;
-    d_hi[k] = dh;
     const ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     const ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
     if (KEEP) {
@@ -155,7 +177,18 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   }
 #pragma unroll
   for (int k = 0; k < D; k++) {
-    const uint32_t dl = d_lo[k], dh = d_hi[k];
+    uint32_t dl, dh;
+    if (MODE <= 1) {
+      dl = d_lo[k];
+      dh = d_hi[k];
+    } else {
+      const uint32_t info = L.etbl[e0 + k];
+      const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
+      if (EXT && k == D - 1)
+        ldpc_fast_cn_edge<true>(L, info, t, rw, false, dl, dh, parw, extl, exth);
+      else
+        ldpc_fast_cn_edge<false>(L, info, t, rw, false, dl, dh, parw, extl, exth);
+    }
     const ldpc_v2u ml = KEEP ? ldpc_as_v2u(g_lo[k]) : ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     const ldpc_v2u mh = KEEP ? ldpc_as_v2u(g_hi[k]) : ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
     const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h));
@@ -177,25 +210,28 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
+#ifndef LDPC_F_MODE_D19
+#define LDPC_F_MODE_D19 2
+#endif
 /* dispatch on the task's (wave-uniform) degree */
 LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
 {
   if (!ext) {
     switch (deg) {
-      case 19: return ldpc_fast_cn<19, false, false>(L, e0, j, Z, rstride);
-      case 10: return ldpc_fast_cn<10, false, true>(L, e0, j, Z, rstride);
-      default: return ldpc_fast_cn<8, false, true>(L, e0, j, Z, rstride);
+      case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19>(L, e0, j, Z, rstride);
+      case 10: return ldpc_fast_cn<10, false, 0>(L, e0, j, Z, rstride);
+      default: return ldpc_fast_cn<8, false, 0>(L, e0, j, Z, rstride);
     }
   }
   switch (deg) {
-    case 3: return ldpc_fast_cn<3, true, true>(L, e0, j, Z, rstride);
-    case 4: return ldpc_fast_cn<4, true, true>(L, e0, j, Z, rstride);
-    case 5: return ldpc_fast_cn<5, true, true>(L, e0, j, Z, rstride);
-    case 6: return ldpc_fast_cn<6, true, true>(L, e0, j, Z, rstride);
-    case 7: return ldpc_fast_cn<7, true, true>(L, e0, j, Z, rstride);
-    case 8: return ldpc_fast_cn<8, true, true>(L, e0, j, Z, rstride);
-    case 9: return ldpc_fast_cn<9, true, true>(L, e0, j, Z, rstride);
-    default: return ldpc_fast_cn<10, true, true>(L, e0, j, Z, rstride);
+    case 3: return ldpc_fast_cn<3, true, 0>(L, e0, j, Z, rstride);
+    case 4: return ldpc_fast_cn<4, true, 0>(L, e0, j, Z, rstride);
+    case 5: return ldpc_fast_cn<5, true, 0>(L, e0, j, Z, rstride);
+    case 6: return ldpc_fast_cn<6, true, 0>(L, e0, j, Z, rstride);
+    case 7: return ldpc_fast_cn<7, true, 0>(L, e0, j, Z, rstride);
+    case 8: return ldpc_fast_cn<8, true, 0>(L, e0, j, Z, rstride);
+    case 9: return ldpc_fast_cn<9, true, 0>(L, e0, j, Z, rstride);
+    default: return ldpc_fast_cn<10, true, 0>(L, e0, j, Z, rstride);
   }
 }
 

@@ -113,7 +113,7 @@ static void cn_pass(const oracle_graph_t *g, const int8_t *q, int8_t *r)
 static void bn_pass(const oracle_graph_t *g, const int8_t *llr, const int8_t *r, int8_t *app, int8_t *q)
 {
   const int Z = g->Z;
-  static __thread int16_t acc[26 * 384];
+  int16_t acc[26 * 384];
   for (int c = 0; c < g->ncore; c++)
     for (int u = 0; u < Z; u++)
       acc[c * Z + u] = llr[c * Z + u];
@@ -181,7 +181,7 @@ static uint32_t cn_parity_check(const oracle_graph_t *g, const int8_t *q, const 
 static void write_output(const oracle_graph_t *g, int outMode, const int8_t *app, int8_t *p_out)
 {
   const int Z = g->Z, numLLR = g->ncols * Z;
-  static __thread int8_t llrOut[68 * 384];
+  int8_t llrOut[68 * 384];
   memset(llrOut, 0, sizeof(llrOut));
   memcpy(llrOut, app, (size_t)g->ncore * Z); /* parity columns keep 0 [F5] */
   if (outMode != ORACLE_OUT_BIT) {
@@ -206,8 +206,7 @@ int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int us
   oracle_graph_t g;
   if (oracle_ldpc_graph(BG, Z, R, &g) != 0)
     return -1;
-  /* thread-local work buffers (no allocator traffic: the multi-threaded baseline driver calls this concurrently) */
-  static __thread int8_t q[316 * 384], r[316 * 384], app[26 * 384];
+  int8_t q[316 * 384], r[316 * 384], app[26 * 384]; /* stack, like the reference's 566 KB of per-call stack buffers (decoder.c:222-227) */
   memset(r, 0, (size_t)g.nedges * Z);
   memset(app, 0, (size_t)g.ncore * Z);
   /* [D1] nrLDPC_mPass.h:128-221 llr2CnProcBuf: CN inputs start as the channel LLRs */

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the rocprofv3 PMC passes of tools/gpu_pmc.sh (FETCH_SIZE / WRITE_SIZE, separate
+passes).  Units and the gfx950 correction follow MI355X_MICROARCH.md "HBM": both counters are in KiB per dispatch,
+and FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled."""
+import csv, glob, json, sys
+from pathlib import Path
+root = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
+def maxval(sub, counter):
+    vals = []
+    for f in glob.glob(str(root / sub / "**" / "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "ldpc_dec" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                vals.append(float(row["Counter_Value"]))
+    return max(vals)   # the fixed-work launches (9 passes) are the largest
+fetch_kib, write_kib = maxval("pmc_fetch", "FETCH_SIZE"), maxval("pmc_write", "WRITE_SIZE")
+out = {"ldpc_dec_bg1_z384_r13_b1024_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
+       "fetch_size_kib_raw": fetch_kib, "fetch_bytes_corrected_x2": int(2 * fetch_kib * 1024),
+       "write_size_kib": write_kib, "write_bytes": int(write_kib * 1024),
+       "compulsory_bytes_per_launch": 1024 * (68 * 384 + 22 * 384 // 8),
+       "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes on bench.py (1024 x BG1 Zc=384 R13, 9 passes)"}
+Path("profiles").mkdir(exist_ok=True)
+Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+print(out)
