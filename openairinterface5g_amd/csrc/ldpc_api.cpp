@@ -223,6 +223,8 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
 
 } // namespace
 
+#include "ldpc_aggregator.inc.cpp"
+
 extern "C" {
 
 const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
@@ -322,18 +324,28 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
   const CodeEntry *ce = get_code(p_decParams->BG, p_decParams->Z, p_decParams->R);
   if (!ce)
     return -1;
-  const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
-  nrLDPC_hip_dec_batch_t b;
-  memset(&b, 0, sizeof(b));
-  b.params = *p_decParams;
-  b.n_blocks = 1;
-  b.llr = p_llr; b.llr_stride = (uint32_t)ce->host.num_llr;
-  b.out = p_out; b.out_stride = (uint32_t)align_up(ob, 4);
   int32_t n_iter = 0;
-  b.n_iter = &n_iter;
-  b.mem = NRLDPC_HIP_MEM_HOST;
-  if (LDPCdecoder_batch(&b) != 0)
-    return -1;
+  {
+    std::lock_guard<std::mutex> lk(agg.mu);
+    agg_config_locked();
+  }
+  if (agg.enabled) {
+    /* concurrent callers (the reference's thread-pool workers) share launches: ldpc_aggregator.inc.cpp */
+    if (agg_decode(p_decParams, ce, p_llr, p_out, &n_iter) != 0)
+      return -1;
+  } else {
+    const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
+    nrLDPC_hip_dec_batch_t b;
+    memset(&b, 0, sizeof(b));
+    b.params = *p_decParams;
+    b.n_blocks = 1;
+    b.llr = p_llr; b.llr_stride = (uint32_t)ce->host.num_llr;
+    b.out = p_out; b.out_stride = (uint32_t)align_up(ob, 4);
+    b.n_iter = &n_iter;
+    b.mem = NRLDPC_HIP_MEM_HOST;
+    if (LDPCdecoder_batch(&b) != 0)
+      return -1;
+  }
   if (n_iter > p_decParams->numMaxIter && ab) { /* decoder.c:190-193 */
     pthread_mutex_lock(&ab->mutex_failure);
     ab->failed = true;

@@ -1,0 +1,95 @@
+/*
+ * abi_threads.c -- N pthreads hammering the reference's per-segment entry point LDPCdecoder() of libldpc_hip.so, the
+ * way the reference's thread-pool workers do (openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:435-468), each call with
+ * its own code / iteration cap / stop mode.  Checks that every concurrent call returns exactly what the same call
+ * returned single-threaded (outputs and pass counts), and reports calls per second.  Test infrastructure.
+ *
+ *   gcc -O2 -I include tests/abi_threads.c -o abi_threads -ldl -lpthread
+ *   ./abi_threads <path/libldpc_hip.so> <threads> <calls per thread>
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "nrLDPC_hip.h"
+
+typedef int32_t (*init_t)(void);
+typedef int32_t (*dec_t)(t_nrLDPC_dec_params *, uint8_t, uint8_t, uint8_t, int8_t *, int8_t *, t_nrLDPC_time_stats *, decode_abort_t *);
+
+#define NCASE 12
+static const int cases[NCASE][4] = { /* BG, Z, R, numMaxIter */
+  {1, 384, 13, 8}, {1, 384, 13, 8}, {1, 384, 23, 8}, {1, 352, 89, 5}, {2, 64, 15, 8}, {2, 208, 13, 8},
+  {1, 96, 13, 8},  {1, 384, 13, 2}, {2, 6, 15, 8},   {1, 18, 13, 8},  {2, 384, 23, 8}, {1, 384, 13, 8}};
+static int ncols(int BG, int R) { return BG == 1 ? (R == 13 ? 68 : R == 23 ? 35 : 27) : (R == 15 ? 52 : R == 13 ? 32 : 17); }
+static int crc_cb(uint8_t *b, uint32_t n, uint8_t t) { (void)b; (void)n; (void)t; return 0; } /* mode flag only */
+
+static dec_t dec;
+static int8_t *llr[NCASE];
+static uint8_t *expect[NCASE];
+static int expect_iter[NCASE], out_len[NCASE];
+static t_nrLDPC_dec_params prm[NCASE];
+static int calls_per_thread;
+static volatile int failures;
+
+static void *worker(void *arg)
+{
+  const int tid = (int)(long)arg;
+  uint8_t *out = malloc(68 * 384);
+  for (int i = 0; i < calls_per_thread; i++) {
+    const int c = (tid * 7 + i) % NCASE;
+    t_nrLDPC_dec_params p = prm[c];
+    memset(out, 0xA5, out_len[c]);
+    const int n = dec(&p, 0, 0, 0, llr[c], (int8_t *)out, NULL, NULL);
+    if (n != expect_iter[c] || memcmp(out, expect[c], out_len[c]) != 0) {
+      __sync_fetch_and_add(&failures, 1);
+      fprintf(stderr, "thread %d call %d case %d: n %d (expected %d)\n", tid, i, c, n, expect_iter[c]);
+    }
+  }
+  free(out);
+  return NULL;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 4) { fprintf(stderr, "usage: %s lib threads calls\n", argv[0]); return 2; }
+  void *h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  init_t init = (init_t)dlsym(h, "LDPCinit");
+  dec = (dec_t)dlsym(h, "LDPCdecoder");
+  if (!init || !dec || init() != 0) { fprintf(stderr, "LDPCinit failed\n"); return 2; }
+  const int T = atoi(argv[2]);
+  calls_per_thread = atoi(argv[3]);
+  unsigned s = 12345;
+  for (int c = 0; c < NCASE; c++) {
+    const int BG = cases[c][0], Z = cases[c][1], R = cases[c][2], n = ncols(BG, R) * Z;
+    llr[c] = aligned_alloc(64, (n + 63) / 64 * 64);
+    for (int i = 0; i < n; i++) {
+      s = s * 1664525u + 1013904223u;
+      const int r = (int)((s >> 16) % 41) - 20;            /* -20..20 */
+      llr[c][i] = (int8_t)(i < 2 * Z ? 0 : (c & 1) ? 14 + r / 2 : r); /* odd cases: noisy all-zero code word, even: noise */
+    }
+    memset(&prm[c], 0, sizeof(prm[c]));
+    prm[c].BG = BG; prm[c].Z = Z; prm[c].R = R; prm[c].numMaxIter = cases[c][3]; prm[c].outMode = nrLDPC_outMode_BIT;
+    if (c == 11) { prm[c].check_crc = crc_cb; prm[c].E = 22 * 384; prm[c].crc_type = 1; } /* CRC-stop mode in the mix */
+    out_len[c] = (n + 31) / 32 * 4;
+    expect[c] = malloc(out_len[c]);
+    memset(expect[c], 0xA5, out_len[c]);
+    t_nrLDPC_dec_params p = prm[c];
+    expect_iter[c] = dec(&p, 0, 0, 0, llr[c], (int8_t *)expect[c], NULL, NULL);
+    if (expect_iter[c] < 0) { fprintf(stderr, "case %d failed single-threaded\n", c); return 1; }
+  }
+  pthread_t th[256];
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (long t = 0; t < T; t++) pthread_create(&th[t], NULL, worker, (void *)t);
+  for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  const double dt = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1e9;
+  printf("{\"threads\": %d, \"calls\": %d, \"seconds\": %.4f, \"calls_per_s\": %.0f, \"failures\": %d, \"iters\": [", T,
+         T * calls_per_thread, dt, T * calls_per_thread / dt, failures);
+  for (int c = 0; c < NCASE; c++) printf("%d%s", expect_iter[c], c + 1 < NCASE ? ", " : "]}\n");
+  return failures ? 1 : 0;
+}

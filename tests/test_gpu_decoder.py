@@ -186,3 +186,23 @@ def test_ldpctest_acceptance_and_seed_identical_bler(hip):
     gpu = T.run(T.parser().parse_args(args), out=io.StringIO())
     cpu = T.run(T.parser().parse_args(args + ["--oracle"]), out=io.StringIO())
     assert gpu == cpu and gpu[0]["errors"] > 0
+
+
+def test_concurrent_callers_of_the_reference_entry_point(hip, tmp_path):
+    """16 pthreads calling LDPCdecoder() at once with different codes / caps / stop modes (the reference's thread-pool
+    usage): every concurrent call must return what it returned single-threaded -- with per-thread streams (default)
+    and with call aggregation (NRLDPC_HIP_AGGREGATE=1)."""
+    import json
+    import os
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_threads"
+    subprocess.run(["gcc", "-O2", "-I", str(root / "include"), str(root / "tests" / "abi_threads.c"), "-o", str(exe),
+                    "-ldl", "-lpthread"], check=True)
+    for agg in ("0", "1"):
+        env = dict(os.environ, NRLDPC_HIP_AGGREGATE=agg)
+        r = subprocess.run([str(exe), str(hip.ldpc.LIB_PATH), "16", "150"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["failures"] == 0 and d["calls"] == 2400
