@@ -106,7 +106,9 @@ static void build_fast_section(ldpc_code_desc_t *d)
       d->f_cn_task[nt][3] = gstart;
       d->f_cn_task[nt][4] = gend;
       d->f_cn_task[nt][5] = i;
-      cost[nt] = rows[i].key;
+      /* instruction-count model of a task: ~36 VALU per edge (47 for the degree-19 rows, which re-read LDS in their
+       * second sweep) + ~40 of prologue/epilogue */
+      cost[nt] = rows[i].key * (rows[i].key >= 16 ? 47 : 36) + 40;
       nt++;
     }
     /* a degree group must not mix core rows (no extension column) with extension rows */
@@ -165,7 +167,7 @@ static void build_fast_section(ldpc_code_desc_t *d)
     d->f_bn_task[nb][0] = b;
     d->f_bn_task[nb][1] = nitems;
     d->f_bn_task[nb][2] = cols[b / zq].key;
-    bcost[nb] = cols[b / zq].key + 3; /* + finalisation */
+    bcost[nb] = cols[b / zq].key * 11 + 45; /* ~11 VALU per gathered edge + finalisation */
     nb++;
   }
   d->f_n_bn_tasks = nb;
