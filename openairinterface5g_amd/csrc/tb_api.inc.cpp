@@ -129,6 +129,7 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   std::vector<tb_tx_tb_job> tbj(b->n_tb);
   std::vector<tb_tx_seg_job> sj;
   std::vector<ldpc_enc_job> ej;
+  std::vector<tb_crc_chunk_job> cj;
   Arena ar;
   int enc_threads = 64, enc_lds = 0;
   size_t payload_end = 0, coded_end = 0;
@@ -151,6 +152,8 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
     tbj[i].crc_type = t.A > NR_HIP_MAX_PDSCH_TBS ? NR_HIP_CRC24_A : NR_HIP_CRC16;
     payload_end = std::max(payload_end, (size_t)t.payload_off + t.A / 8);
     coded_end = std::max(coded_end, (size_t)t.coded_off + t.G);
+    for (uint32_t fb = 0; fb < t.A / 8; fb += TB_CRC_CHUNK)
+      cj.push_back(tb_crc_chunk_job{i, fb});
     const ldpc_code_desc_t &hc = ce->host;
     const int N = (hc.ncols - 2) * hc.Z;
     int waves = (hc.Z + 63) / 64 * 2;
@@ -181,9 +184,13 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   }
   const size_t n_seg = sj.size();
   const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_tx_tb_job), 16),
-               o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16), jobs_bytes = o_enc + n_seg * sizeof(ldpc_enc_job);
-  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || c.jobs_d.ensure(jobs_bytes) != 0)
+               o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
+               o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
+               jobs_bytes = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16), o_acc = jobs_bytes;
+  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
+      c.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
+  memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
   memcpy(c.jobs_h.p + o_enc, ej.data(), n_seg * sizeof(ldpc_enc_job));
@@ -200,7 +207,10 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   }
   const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(c.jobs_d.p + o_tb);
   const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(c.jobs_d.p + o_seg);
-  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, payload, c.scratch.p, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+  uint32_t *d_acc = reinterpret_cast<uint32_t *>(c.jobs_d.p + o_acc);
+  HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
+  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(c.jobs_d.p + o_chk), (uint32_t)cj.size(),
+                           payload, c.scratch.p, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
   HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, g.crc_pow[NR_HIP_CRC24_B], s));
   ldpc_enc_args ea;
   memset(&ea, 0, sizeof(ea));
@@ -282,6 +292,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
       j.E = E; j.Qm = t.Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
       j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
       j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
+      j.c_off = tj.c_off0 + (uint64_t)r * cstride;
+      j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
       ldpc_dec_job dj;
       dj.code = ce->dev;
       dj.llr_off = j.l_off;
@@ -311,9 +323,10 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
                o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
                o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
                o_iter = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16),
-               jobs_bytes = o_iter; /* n_iter lives behind the jobs in the same device buffer */
+               jobs_bytes = o_iter, /* n_iter and the CRC accumulators live behind the jobs in the same device buffer */
+               o_acc = o_iter + align_up(n_seg * sizeof(int32_t), 16);
   if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      c.jobs_d.ensure(jobs_bytes + n_seg * sizeof(int32_t)) != 0)
+      c.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
@@ -360,8 +373,11 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_gen);
     HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)gen_jobs.size(), s));
   }
-  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(c.jobs_d.p + o_tb), b->n_tb, d_iter, c.scratch.p,
-                                payload, ack, iter_max, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+  uint32_t *d_acc = reinterpret_cast<uint32_t *>(c.jobs_d.p + o_acc);
+  HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
+  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(c.jobs_d.p + o_tb), b->n_tb,
+                                reinterpret_cast<const tb_rx_seg_job *>(c.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
+                                c.scratch.p, payload, ack, iter_max, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
   if (host) {
     HIP_TRY(hipMemcpyAsync(b->payload, payload, payload_end, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(b->harq, harq, harq_end * 2, hipMemcpyDeviceToHost, s));

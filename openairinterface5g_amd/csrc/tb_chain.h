@@ -16,6 +16,11 @@ struct tb_tx_tb_job {      /* one per transport block */
   uint32_t A, B, crc_type; /* CRC24_A (0) or CRC16 (2) */
   uint32_t pad;
 };
+struct tb_crc_chunk_job {  /* one per TB_CRC_CHUNK bytes of a transport block: the TB CRC is computed by many workgroups */
+  uint32_t tb;             /* index into the per-TB job array */
+  uint32_t first_byte;     /* byte range [first_byte, first_byte + TB_CRC_CHUNK) of the TB */
+};
+#define TB_CRC_CHUNK 2048u
 struct tb_tx_seg_job {     /* one per code block */
   uint64_t b_off;          /* the TB's b */
   uint64_t c_off;          /* scratch: packed segment, K/8 bytes (encoder input) */
@@ -31,6 +36,10 @@ struct tb_rx_seg_job {
   uint64_t l_off;          /* scratch: decoder input, int8 */
   uint32_t E, Qm, Ncb, Foffset, Fin, V, rank0, clear;
   uint32_t K, F, Z, num_llr; /* num_llr = ncols(R)*Z bytes the decoder reads */
+  /* reassembly (tb_rx_assemble_kernel): */
+  uint64_t c_off;          /* scratch: this segment's decoded bits */
+  uint32_t tb, r;          /* transport block (index into the per-TB jobs) and segment number */
+  uint32_t iter_idx, pad;  /* where the decoder reported this segment's pass count */
 };
 struct tb_rx_tb_job {
   uint64_t payload_off;    /* A/8 bytes out */
@@ -43,13 +52,16 @@ struct tb_rx_tb_job {
   uint32_t pad;
 };
 
-hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n, const uint8_t *payload, uint8_t *scratch,
-                            const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);
+/* TB CRC attach in two steps: per-chunk partial CRCs XOR-ed into acc[tb] (zeroed by the caller), then the CRC bytes */
+hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_crc_chunk_job *chunks, uint32_t n_chunks,
+                            const uint8_t *payload, uint8_t *scratch, uint32_t *acc, const uint32_t *pow24a,
+                            const uint32_t *pow16, hipStream_t s);
 hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s);
 hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s);
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
                                 hipStream_t s);
-hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n, const int32_t *n_iter, uint8_t *scratch,
-                                 uint8_t *payload, uint8_t *ack, int32_t *iter_max, const uint32_t *pow24a,
-                                 const uint32_t *pow16, hipStream_t s);
+/* reassembly per segment (payload copy + partial TB CRC into acc[tb], zeroed by the caller), then per-TB verdict */
+hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
+                                 const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,
+                                 uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);
 #endif

@@ -50,29 +50,55 @@ __device__ __forceinline__ uint32_t tb_block_crc(const uint8_t *__restrict__ dat
   return tb_block_xor(x, red);
 }
 
-/* ---- TX 1: b = payload || CRC24A / CRC16 ------------------------------------------------------------------ */
-__global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_kernel(const tb_tx_tb_job *jobs, const uint8_t *payload,
-                                                               uint8_t *scratch, const uint32_t *pow24a, const uint32_t *pow16)
+/* Partial left-aligned CRC register of bytes [first, first+count) of an nbits-bit string (same linear form). */
+__device__ __forceinline__ uint32_t tb_partial_crc(const uint8_t *__restrict__ data, uint32_t nbits, uint32_t first, uint32_t count,
+                                                   const uint32_t *__restrict__ pow)
 {
-  __shared__ uint32_t red[2];
-  const tb_tx_tb_job j = jobs[blockIdx.x];
+  uint32_t x = 0;
+  for (uint32_t q = first + threadIdx.x; q < first + count; q += blockDim.x) {
+    uint32_t v = data[q];
+    const uint32_t top = nbits - 1 - 8 * q;
+    while (v) {
+      const int b = 31 - __clz(v);
+      x ^= pow[top - (7 - b)];
+      v &= ~(1u << b);
+    }
+  }
+  for (int off = 32; off; off >>= 1)
+    x ^= __shfl_xor(x, off);
+  return x; /* valid in lane 0 of every wave */
+}
+
+/* ---- TX 1: b = payload || CRC24A / CRC16 -- chunk-parallel: copy + partial CRC, then the CRC bytes ----------- */
+__global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_tx_tb_job *jobs, const tb_crc_chunk_job *chunks,
+                                                                       const uint8_t *payload, uint8_t *scratch, uint32_t *acc,
+                                                                       const uint32_t *pow24a, const uint32_t *pow16)
+{
+  const tb_crc_chunk_job ch = chunks[blockIdx.x];
+  const tb_tx_tb_job j = jobs[ch.tb];
   const uint8_t *a = payload + j.payload_off;
   uint8_t *b = scratch + j.b_off;
   const uint32_t nbytes = j.A >> 3;
-  for (uint32_t q = threadIdx.x; q < nbytes; q += blockDim.x)
+  const uint32_t count = ch.first_byte + TB_CRC_CHUNK <= nbytes ? TB_CRC_CHUNK : nbytes - ch.first_byte;
+  for (uint32_t q = ch.first_byte + threadIdx.x; q < ch.first_byte + count; q += blockDim.x)
     b[q] = a[q];
-  const bool is24 = j.crc_type == 0;
-  const uint32_t crc = tb_block_crc(a, j.A, is24 ? pow24a : pow16, red);
-  if (threadIdx.x == 0) {
-    if (is24) {
-      b[nbytes] = (uint8_t)(crc >> 24);
-      b[nbytes + 1] = (uint8_t)(crc >> 16);
-      b[nbytes + 2] = (uint8_t)(crc >> 8);
-    } else {
-      b[nbytes] = (uint8_t)(crc >> 24);
-      b[nbytes + 1] = (uint8_t)(crc >> 16);
-    }
-  }
+  const uint32_t x = tb_partial_crc(a, j.A, ch.first_byte, count, j.crc_type == 0 ? pow24a : pow16);
+  if ((threadIdx.x & 63) == 0 && x)
+    atomicXor(&acc[ch.tb], x);
+}
+__global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_final_kernel(const tb_tx_tb_job *jobs, uint32_t n_tb, uint8_t *scratch,
+                                                                     const uint32_t *acc)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tb)
+    return;
+  const tb_tx_tb_job j = jobs[i];
+  uint8_t *b = scratch + j.b_off + (j.A >> 3);
+  const uint32_t crc = acc[i];
+  b[0] = (uint8_t)(crc >> 24);
+  b[1] = (uint8_t)(crc >> 16);
+  if (j.crc_type == 0)
+    b[2] = (uint8_t)(crc >> 8);
 }
 
 /* ---- TX 2: code-block segmentation: c_r = b[r*(K'-L) ..] || CRC24B (C > 1) || zero fillers ---------------- */
@@ -156,40 +182,52 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_s
   }
 }
 
-/* ---- RX 2: reassemble b from the decoded segments, TB CRC, payload out ------------------------------------------ */
-__global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_tb_job *jobs, const int32_t *n_iter,
-                                                                    uint8_t *scratch, uint8_t *payload, uint8_t *ack,
-                                                                    int32_t *iter_max, const uint32_t *pow24a,
-                                                                    const uint32_t *pow16)
+/* ---- RX 2: reassemble b from the decoded segments, TB CRC, payload out --------------------------------------------
+ * per segment: copy its payload bytes into b and the payload buffer, partial TB CRC of those bytes into acc[tb];
+ * per TB: ACK = every segment decoded and (C == 1 or the CRC register of the whole b is zero). */
+__global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_tb_job *jobs, const tb_rx_seg_job *segs,
+                                                                    const int32_t *n_iter, uint8_t *scratch, uint8_t *payload,
+                                                                    uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16)
 {
-  __shared__ uint32_t red[2];
-  const tb_rx_tb_job j = jobs[blockIdx.x];
+  const tb_rx_seg_job sj = segs[blockIdx.x];
+  const tb_rx_tb_job j = jobs[sj.tb];
   uint8_t *b = scratch + j.b_off;
-  const uint32_t bbytes = j.B >> 3;
+  const uint32_t bbytes = j.B >> 3, abytes = j.A >> 3, first = sj.r * j.seg_bytes;
+  const bool ok = n_iter[sj.iter_idx] <= (int)j.num_max_iter;
+  const uint8_t *c = scratch + sj.c_off;
+  uint32_t count = 0;
+  if (first < bbytes)
+    count = first + j.seg_bytes <= bbytes ? j.seg_bytes : bbytes - first;
+  for (uint32_t q = threadIdx.x; q < count; q += blockDim.x) {
+    const uint8_t v = ok ? c[q] : (uint8_t)0; /* the reference leaves stale bytes for a failed segment; here: zeros */
+    b[first + q] = v;
+    if (first + q < abytes)
+      payload[j.payload_off + first + q] = v;
+  }
+  if (j.C > 1 && ok) {
+    __syncthreads(); /* the CRC below re-reads b */
+    const uint32_t x = tb_partial_crc(b, j.B, first, count, j.crc_type == 0 ? pow24a : pow16);
+    if ((threadIdx.x & 63) == 0 && x)
+      atomicXor(&acc[sj.tb], x);
+  }
+}
+__global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_tb_job *jobs, uint32_t n_tb, const int32_t *n_iter,
+                                                                   const uint32_t *acc, uint8_t *ack, int32_t *iter_max)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tb)
+    return;
+  const tb_rx_tb_job j = jobs[i];
   bool all_ok = true;
   int imax = 0;
   for (uint32_t r = 0; r < j.C; r++) {
     const int it = n_iter[j.seg0 + r];
     imax = it > imax ? it : imax;
-    const bool ok = it <= (int)j.num_max_iter;
-    all_ok &= ok;
-    const uint8_t *c = scratch + j.c_off0 + (size_t)r * j.c_stride;
-    for (uint32_t q = threadIdx.x; q < j.seg_bytes; q += blockDim.x) {
-      const uint32_t dst = r * j.seg_bytes + q;
-      if (dst < bbytes)
-        b[dst] = ok ? c[q] : (uint8_t)0;   /* the reference leaves stale bytes for a failed segment; here: zeros */
-    }
+    all_ok &= it <= (int)j.num_max_iter;
   }
-  __syncthreads();
-  bool crc_ok = true;
-  if (j.C > 1)  /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
-    crc_ok = tb_block_crc(b, j.B, j.crc_type == 0 ? pow24a : pow16, red) == 0;
-  for (uint32_t q = threadIdx.x; q < (j.A >> 3); q += blockDim.x)
-    payload[j.payload_off + q] = b[q];
-  if (threadIdx.x == 0) {
-    ack[blockIdx.x] = (uint8_t)(all_ok && crc_ok);
-    iter_max[blockIdx.x] = imax;
-  }
+  /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
+  ack[i] = (uint8_t)(all_ok && (j.C == 1 || acc[i] == 0));
+  iter_max[i] = imax;
 }
 
 #define TB_LAUNCH(kernel, n, s, ...)                                              \
@@ -200,10 +238,15 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
     return hipGetLastError();                                                     \
   } while (0)
 
-hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n, const uint8_t *payload, uint8_t *scratch,
-                            const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s)
+hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_crc_chunk_job *chunks, uint32_t n_chunks,
+                            const uint8_t *payload, uint8_t *scratch, uint32_t *acc, const uint32_t *pow24a,
+                            const uint32_t *pow16, hipStream_t s)
 {
-  TB_LAUNCH(tb_tx_crc_kernel, n, s, jobs, payload, scratch, pow24a, pow16);
+  if (n_tb == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(tb_tx_crc_partial_kernel, dim3(n_chunks), dim3(TB_THREADS), 0, s, jobs, chunks, payload, scratch, acc, pow24a, pow16);
+  hipLaunchKernelGGL(tb_tx_crc_final_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, scratch, acc);
+  return hipGetLastError();
 }
 hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s)
 {
@@ -218,9 +261,13 @@ hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int
 {
   TB_LAUNCH(tb_rx_dematch_kernel, n, s, jobs, llr, harq, scratch);
 }
-hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n, const int32_t *n_iter, uint8_t *scratch,
-                                 uint8_t *payload, uint8_t *ack, int32_t *iter_max, const uint32_t *pow24a,
-                                 const uint32_t *pow16, hipStream_t s)
+hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
+                                 const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,
+                                 uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s)
 {
-  TB_LAUNCH(tb_rx_assemble_kernel, n, s, jobs, n_iter, scratch, payload, ack, iter_max, pow24a, pow16);
+  if (n_tb == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(tb_rx_assemble_kernel, dim3(n_seg), dim3(TB_THREADS), 0, s, jobs, segs, n_iter, scratch, payload, acc, pow24a, pow16);
+  hipLaunchKernelGGL(tb_rx_verdict_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, n_iter, acc, ack, iter_max);
+  return hipGetLastError();
 }
