@@ -76,12 +76,23 @@ struct ldpc_fast_lds {
   const uint32_t *etbl, *ctbl, *rowtbl, *coltbl;
 };
 
-/* unaligned 4-byte window starting at byte offset `off` of `base` (base 4-aligned) */
-LDPC_HD uint32_t ldpc_window(const uint8_t *base, int off)
+/* LDS offsets held in the LDS-resident tables are ABSOLUTE LDS addresses on the device (the kernel adds the address
+ * of its LDS block when it loads the tables), so a neighbour access is `ds_read(entry + lane offset)` with no base add;
+ * the host emulation keeps them relative to `base`. */
+#if defined(__HIP_DEVICE_COMPILE__)
+LDPC_HD uint32_t ldpc_lds_addr(const uint8_t *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p; }
+LDPC_HD uint32_t ldpc_lds_ld32(const uint8_t *, uint32_t a) { return *(const __attribute__((address_space(3))) uint32_t *)a; }
+#else
+LDPC_HD uint32_t ldpc_lds_addr(const uint8_t *) { return 0u; }
+LDPC_HD uint32_t ldpc_lds_ld32(const uint8_t *base, uint32_t a) { return *reinterpret_cast<const uint32_t *>(base + a); }
+#endif
+/* 4-byte window whose first byte is `sh & 3` bytes into the aligned dword at LDS address `a` */
+LDPC_HD uint32_t ldpc_window_al(const uint8_t *base, uint32_t a, uint32_t sh)
 {
-  const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (off & ~3));
-  return ldpc_alignbyte(p[1], p[0], (uint32_t)off);
+  return ldpc_alignbyte(ldpc_lds_ld32(base, a + 4u), ldpc_lds_ld32(base, a), sh);
 }
+/* unaligned 4-byte window starting at LDS address `off` */
+LDPC_HD uint32_t ldpc_window(const uint8_t *base, uint32_t off) { return ldpc_window_al(base, off & ~3u, off); }
 
 /* One check-node item: lifted row with first edge e0, lanes t..t+3 (t = 4j).  D = row degree; EXT = the
  * last edge goes to the row's degree-1 column; KEEP = keep the per-edge magnitudes in registers between
@@ -106,7 +117,7 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
 {
   uint32_t al, ah, rl, rh;
   if (IS_EXT) {
-    const uint32_t lw = *reinterpret_cast<const uint32_t *>(L.base + info + t);
+    const uint32_t lw = ldpc_lds_ld32(L.base, info + (uint32_t)t);
     al = ldpc_perm(0x80808080u, lw, 0x05010400u);
     ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
     if (first) { /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
@@ -116,7 +127,7 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
     rl = 0x00800080u; /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
     rh = 0x00800080u;
   } else {
-    const uint32_t aw = ldpc_window(L.base, (int)info + t);
+    const uint32_t aw = ldpc_window(L.base, info + (uint32_t)t);
     if (first)
       parw ^= aw;
     al = ldpc_perm(0x80808080u, aw, 0x05010400u); /* (0x8000 | byte 0), (0x8000 | byte 1) */
@@ -245,8 +256,9 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
   const int c = (int)(colrec & 0xffu), deg = (int)((colrec >> 8) & 0xffu), start = (int)(colrec >> 16);
   uint32_t acc_e = 0, acc_o = 0; /* packed 16-bit sums of the biased bytes: lanes (0,2) and (1,3) */
   /* The gather is a chain table entry -> address -> window per edge; four edges are kept in flight.  Table entry =
-   * {Z - shift, row offset}; columns with fewer than maxdeg edges are padded with entries that point at a row of
-   * zero bytes (contribution 0), so there is no predication. */
+   * {x = Z - shift, y = LDS address of the message row - (x & 3)}: u and Z are multiples of 4, so the window's byte
+   * phase is x & 3 for every item and y + p is the aligned dword that holds its first byte.  Columns with fewer than
+   * maxdeg edges are padded with entries that point at a row of zero bytes (contribution 0): no predication. */
   const uint2 *tbl = reinterpret_cast<const uint2 *>(L.ctbl) + start;
   int k = 0;
   for (; k + 4 <= maxdeg; k += 4) {
@@ -256,7 +268,7 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
       const uint2 ce = tbl[k + i];
       const uint32_t q = (uint32_t)u + ce.x;            /* u + Z - shift in [1, 2Z) */
       const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z; /* mod Z: q - Z wraps to a huge value when q < Z */
-      w[i] = ldpc_window(L.base, (int)(ce.y + p));
+      w[i] = ldpc_window_al(L.base, ce.y + p, q);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -268,7 +280,7 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
     const uint2 ce = tbl[k];
     const uint32_t q = (uint32_t)u + ce.x;
     const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z;
-    const uint32_t v = ldpc_window(L.base, (int)(ce.y + p));
+    const uint32_t v = ldpc_window_al(L.base, ce.y + p, q);
     acc_e += v & 0x00ff00ffu;
     acc_o += (v >> 8) & 0x00ff00ffu;
   }

@@ -43,10 +43,11 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (job ? (size_t)job->llr_off : (size_t)blk * a.llr_stride));
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
+  const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
   for (int i = tid; i < nedges; i += nt)
-    etbl[i] = code->f_etbl[i];
+    etbl[i] = code->f_etbl[i] + lds0;
   for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
-    ctbl[i] = code->f_ctbl[i];
+    ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
   for (int i = tid; i < (Z + 4) >> 2; i += nt)
     reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   for (int i = tid; i < code->nrows; i += nt)

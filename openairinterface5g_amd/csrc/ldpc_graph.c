@@ -191,8 +191,9 @@ static void build_fast_section(ldpc_code_desc_t *d)
   d->f_lds_total = d->f_lds_misc + 64;
   if (d->f_lds_total > 160 * 1024)
     return;
-  for (int i = 0; i < d->f_n_ctbl; i++)
-    d->f_ctbl[2 * i + 1] = d->f_ctbl[2 * i + 1] == 0xffffffffu ? (uint32_t)d->f_lds_zero : d->f_ctbl[2 * i + 1] + (uint32_t)d->f_lds_r;
+  for (int i = 0; i < d->f_n_ctbl; i++) /* minus the window's byte phase (ldpc_fast_bn); may wrap below 0, mod 2^32 */
+    d->f_ctbl[2 * i + 1] = (d->f_ctbl[2 * i + 1] == 0xffffffffu ? (uint32_t)d->f_lds_zero : d->f_ctbl[2 * i + 1] + (uint32_t)d->f_lds_r) -
+                           (d->f_ctbl[2 * i] & 3u);
   /* edge table: absolute LDS byte offset of the neighbour's row start + shift */
   for (int e = 0; e < d->nedges; e++) {
     const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);

@@ -88,7 +88,7 @@ typedef struct ldpc_code_desc {
   uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;
                                             extension column: f_lds_ext + (col-ncore)*Z */
   uint32_t f_coltbl[LDPC_MAX_CORE + 2];  /* per sorted column: col | degree << 8 | first entry in f_ctbl << 16 */
-  /* per (sorted column, k): two dwords {Z - shift, LDS byte offset of the edge's message row}.  A column's list is
+  /* per (sorted column, k): two dwords {x = Z - shift, LDS byte offset of the edge's message row - (x & 3)}.  A column's list is
    * padded up to the degree of the earliest column it can share a task with; padding entries {Z, f_lds_zero} point
    * at a row of zero bytes, so short columns need no predication in the gather loop. */
   uint32_t f_ctbl[2 * LDPC_F_MAX_CTBL];
