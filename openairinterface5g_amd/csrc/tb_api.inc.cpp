@@ -156,10 +156,10 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
       cj.push_back(tb_crc_chunk_job{i, fb});
     const ldpc_code_desc_t &hc = ce->host;
     const int N = (hc.ncols - 2) * hc.Z;
-    int waves = (hc.Z + 63) / 64 * 2;
-    if (waves > 16) waves = 16;
-    enc_threads = std::max(enc_threads, waves * 64);
-    enc_lds = std::max(enc_lds, (int)(align_up(hc.ncols * hc.Z, 16) + align_up(4 * hc.Z, 16)));
+    int nthr, nlds;
+    ldpc_enc_launch_shape(hc, &nthr, &nlds);
+    enc_threads = std::max(enc_threads, nthr);
+    enc_lds = std::max(enc_lds, nlds);
     uint32_t r_offset = 0;
     for (uint32_t r = 0; r < sg.C; r++) {
       tb_tx_seg_job j;

@@ -365,6 +365,31 @@ def dlsch_encode_device(tbs, payload, coded, stream=None):
     _check(L.nrLDPC_hip_dlsch_encode(C.byref(b)), "nrLDPC_hip_dlsch_encode")
 
 
+class PreparedTbBatch:
+    """A transport-block batch descriptor built once and submitted many times (slot after slot with the same
+    allocation): keeps the ctypes marshalling out of the caller's per-slot path.  `encode()` / `decode()` are the bare
+    C calls nrLDPC_hip_dlsch_encode / nrLDPC_hip_ulsch_decode (asynchronous on the batch's stream)."""
+
+    def __init__(self, tbs, payload, coded_or_llr, harq=None, ack=None, iter_max=None, numMaxIter=8, stream=None):
+        import torch
+        self._lib = _tb_lib()
+        po, co, ho, _ = tb_layout(tbs)
+        self._keep = (payload, coded_or_llr, harq, ack, iter_max)
+        self.arr = _tb_array(tbs, po, co, ho if harq is not None else None, numMaxIter)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.batch = nrLDPC_hip_tb_batch_t(
+            n_tb=len(tbs), tb=self.arr, payload=payload.data_ptr(), coded=coded_or_llr.data_ptr(),
+            harq=None if harq is None else harq.data_ptr(), harq_stride=0 if harq is None else HARQ_STRIDE,
+            ack=None if ack is None else ack.data_ptr(), iter_max=None if iter_max is None else iter_max.data_ptr(),
+            mem=MEM_DEVICE, stream=s)
+
+    def encode(self):
+        _check(self._lib.nrLDPC_hip_dlsch_encode(C.byref(self.batch)), "nrLDPC_hip_dlsch_encode")
+
+    def decode(self):
+        _check(self._lib.nrLDPC_hip_ulsch_decode(C.byref(self.batch)), "nrLDPC_hip_ulsch_decode")
+
+
 def ulsch_decode_device(tbs, llr, harq, payload, ack, iter_max, numMaxIter=8, stream=None):
     """llr: torch int16 [>= co[-1]], harq: torch int16 [>= ho[-1]], payload: torch uint8 [>= po[-1]] (out),
     ack: torch uint8 [n], iter_max: torch int32 [n].  Asynchronous; tb dicts get their llrLen updated."""

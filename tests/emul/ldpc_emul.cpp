@@ -117,6 +117,25 @@ extern "C" int ldpc_emul_encode(int BG, int Zc, int Kb, const uint8_t *in, uint8
   return (code->ncols - 2) * Zc;
 }
 
+/* ---- bit-packed encoder kernel (ldpc_enc_packed_kernel) ------------------------------------------------------- */
+#include "../../openairinterface5g_amd/csrc/ldpc_enc_packed_core.h"
+
+extern "C" int ldpc_emul_encode_packed(int BG, int Zc, int Kb, const uint8_t *in, uint8_t *out)
+{
+  ldpc_code_desc_t code_s;
+  if (ldpc_build_code_desc(BG, Zc, BG == 1 ? 13 : 15, &code_s) != 0)
+    return -1;
+  const ldpc_code_desc_t *code = &code_s;
+  std::vector<uint32_t> lds(ldpc_encp_lds_words(code->ncols, code->kb_full, Zc), 0x5a5a5a5au);
+  ldpc_encp_lds L;
+  ldpc_encp_carve(lds.data(), code->ncols, code->kb_full, Zc, L);
+  const int nt = ldpc_encp_threads(code->nrows, Zc);
+  for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++)
+    for (int tid = 0; tid < nt; tid++)
+      ldpc_encp_phase(ph, code, Kb, in, L, out, tid, nt);
+  return (code->ncols - 2) * Zc;
+}
+
 extern "C" int ldpc_emul_desc(int BG, int Z, int R, ldpc_code_desc_t *d) { return ldpc_build_code_desc(BG, Z, R, d); }
 
 /* ---- fast kernel (ldpc_decoder_fast.hip) ---------------------------------------------------------------- */

@@ -18,6 +18,7 @@ def emul(built):
     for f in (L.ldpc_emul_decode, L.ldpc_emul_decode_fast):
         f.argtypes = [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
     L.ldpc_emul_encode.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
+    L.ldpc_emul_encode_packed.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
     return L
 
 
@@ -69,6 +70,8 @@ def test_encoder_every_code(emul):
                     bits[Kb * Z:] = 0
                 info = np.packbits(np.concatenate([bits, np.zeros((-bits.size) % 8, np.uint8)]))
                 out = np.full(68 * 384 + 8, 7, np.uint8)
-                n = emul.ldpc_emul_encode(BG, Z, Kb, info.ctypes.data, out.ctypes.data)
                 ref = O.encode(BG, Z, info, Kb)
-                assert n == ref.size and np.array_equal(out[:n], ref), (BG, Z, Kb)
+                for fn in (emul.ldpc_emul_encode, emul.ldpc_emul_encode_packed):  # byte-per-lane and bit-packed kernels
+                    out[:] = 7
+                    n = fn(BG, Z, Kb, info.ctypes.data, out.ctypes.data)
+                    assert n == ref.size and np.array_equal(out[:n], ref), (BG, Z, Kb, fn.__name__)

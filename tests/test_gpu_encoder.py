@@ -64,3 +64,17 @@ def test_linearity_full_batch_device(hip):
     torch.cuda.synchronize()
     assert torch.equal(ea ^ eb, eab)
     assert int(eab.max()) <= 1
+
+
+def test_byte_per_lane_kernel_too():
+    """The default encoder kernel is the bit-packed one; re-run the every-code test with the byte-per-lane kernel."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NRLDPC_HIP_ENC_KERNEL") == "bytes":
+        pytest.skip("already the byte-per-lane run")
+    env = dict(os.environ, NRLDPC_HIP_ENC_KERNEL="bytes")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_encoder.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "every_lifting_size or survey_stage"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
