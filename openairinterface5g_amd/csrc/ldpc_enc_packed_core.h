@@ -11,7 +11,9 @@
  *
  * LDS (words): B[ncols][W+1]  masked columns (bits >= Zc zero, one zero word behind) -- the result;
  *              X[kbf+4][cw]   periodic strings of the information and core parity columns;
- *              LB[4][W+1], LX[4][cw]  the same for the four core-row partial sums lambda.
+ *              LB[4][W+1], LX[4][cw]  the same for the four core-row partial sums lambda;
+ *              ET[nedges] = column << 16 | shift, RP[nrows+1] = first edge of each row (staged from the descriptor:
+ *              the per-edge loops are chains of dependent table reads, LDS latency instead of global latency).
  * Phases are separated by workgroup barriers; phases 0 .. LDPC_ENCP_SOLVE_PHASES-1 leave the code word in B, the
  * last phase writes the reference's byte-per-bit output (a fused caller reads B instead).
  */
@@ -23,7 +25,7 @@
 #define LDPC_ENCP_NUM_PHASES 14
 
 struct ldpc_encp_lds {
-  uint32_t *B, *X, *LB, *LX;
+  uint32_t *B, *X, *LB, *LX, *ET, *RP;
 };
 
 #if defined(__HIPCC__)
@@ -33,18 +35,20 @@ struct ldpc_encp_lds {
 #endif
 LDPC_ENCP_HOSTDEV int ldpc_encp_W(int Z) { return (Z + 31) >> 5; }
 LDPC_ENCP_HOSTDEV int ldpc_encp_cw(int Z) { return 2 * ldpc_encp_W(Z) + 1; }
-LDPC_ENCP_HOSTDEV int ldpc_encp_lds_words(int ncols, int kbf, int Z)
+LDPC_ENCP_HOSTDEV int ldpc_encp_lds_words(int ncols, int kbf, int Z, int nrows, int nedges)
 {
   const int W = ldpc_encp_W(Z), cw = ldpc_encp_cw(Z);
-  return ncols * (W + 1) + (kbf + 4) * cw + 4 * (W + 1) + 4 * cw;
+  return ncols * (W + 1) + (kbf + 4) * cw + 4 * (W + 1) + 4 * cw + nedges + nrows + 1;
 }
-LDPC_HD void ldpc_encp_carve(uint32_t *lds, int ncols, int kbf, int Z, ldpc_encp_lds &L)
+LDPC_HD void ldpc_encp_carve(uint32_t *lds, ldpc_code_ptr_t code, ldpc_encp_lds &L)
 {
-  const int W = ldpc_encp_W(Z), cw = ldpc_encp_cw(Z);
+  const int Z = code->Z, W = ldpc_encp_W(Z), cw = ldpc_encp_cw(Z);
   L.B = lds;
-  L.X = L.B + ncols * (W + 1);
-  L.LB = L.X + (kbf + 4) * cw;
+  L.X = L.B + code->ncols * (W + 1);
+  L.LB = L.X + (code->kb_full + 4) * cw;
   L.LX = L.LB + 4 * (W + 1);
+  L.ET = L.LX + 4 * cw;
+  L.RP = L.ET + code->nedges;
 }
 /* threads that keep every phase busy: the extension rows give (nrows-4)*W items */
 LDPC_ENCP_HOSTDEV int ldpc_encp_threads(int nrows, int Z)
@@ -113,18 +117,23 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
       L.B[c * bs + W] = 0u;
     if (tid < 4)
       L.LB[tid * bs + W] = 0u;
+    for (int e = tid; e < code->nedges; e += nt)
+      L.ET[e] = ((uint32_t)code->e_col[e] << 16) | (code->e_info[e] & 0xffffu);
+    for (int r = tid; r <= code->nrows; r += nt)
+      L.RP[r] = (uint32_t)code->row_ptr[r];
   } else if (phase == 1) {
     ldpc_encp_extend(L.B, L.X, kbf, Z, tid, nt);
   } else if (phase == 2) {
     /* lambda_row = XOR over the information edges of core row `row` */
     for (int i = tid; i < 4 * W; i += nt) {
       const int row = i / W, w = i - row * W;
-      const int e0 = code->row_ptr[row], e1 = code->row_ptr[row + 1];
+      const int e0 = (int)L.RP[row], e1 = (int)L.RP[row + 1];
       uint32_t acc = 0;
       for (int e = e0; e < e1; e++) {
-        const int c = code->e_col[e];
+        const uint32_t et = L.ET[e];
+        const int c = (int)(et >> 16);
         if (c < Kb)
-          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (code->e_info[e] & 0xffffu));
+          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (et & 0xffffu));
       }
       L.LB[row * bs + w] = acc & ldpc_encp_mask(Z, w);
     }
@@ -163,14 +172,15 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
     const int nitems = (code->nrows - 4) * W;
     for (int i = tid; i < nitems; i += nt) {
       const int rr = i / W, w = i - rr * W, row = 4 + rr;
-      const int e0 = code->row_ptr[row], e1 = code->row_ptr[row + 1] - 1;
+      const int e0 = (int)L.RP[row], e1 = (int)L.RP[row + 1] - 1;
       uint32_t acc = 0;
       for (int e = e0; e < e1; e++) {
-        const int c = code->e_col[e];
+        const uint32_t et = L.ET[e];
+        const int c = (int)(et >> 16);
         if (c < Kb || c >= kbf)
-          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (code->e_info[e] & 0xffffu));
+          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (et & 0xffffu));
       }
-      L.B[code->e_col[e1] * bs + w] = acc & ldpc_encp_mask(Z, w);
+      L.B[(L.ET[e1] >> 16) * bs + w] = acc & ldpc_encp_mask(Z, w);
     }
   } else {
     /* out[i] = bit i of the code word without its first two columns */

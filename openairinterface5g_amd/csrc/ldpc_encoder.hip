@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(512) ldpc_enc_packed_kernel(const ldpc_enc_arg
   const job_ptr_t job = a.jobs ? (job_ptr_t)a.jobs + blockIdx.x : (job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
   ldpc_encp_lds L;
-  ldpc_encp_carve(reinterpret_cast<uint32_t *>(esm), code->ncols, code->kb_full, code->Z, L);
+  ldpc_encp_carve(reinterpret_cast<uint32_t *>(esm), code, L);
   const uint32_t blk = blockIdx.x;
   const uint8_t *in = a.in + (job ? (size_t)job->in_off : (size_t)blk * a.in_stride);
   uint8_t *out = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
@@ -60,11 +60,13 @@ static int enc_packed(void)
   return v;
 }
 
+int ldpc_enc_is_packed(void) { return enc_packed(); }
+
 void ldpc_enc_launch_shape(const ldpc_code_desc_t &hc, int *n_threads, int *lds_bytes)
 {
   if (enc_packed()) {
     *n_threads = ldpc_encp_threads(hc.nrows, hc.Z);
-    *lds_bytes = 4 * ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z);
+    *lds_bytes = 4 * ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z, hc.nrows, hc.nedges);
   } else {
     int waves = (hc.Z + 63) / 64 * 2;
     *n_threads = (waves > 16 ? 16 : waves) * 64;

@@ -66,6 +66,7 @@ hipError_t ldpc_fast_kernel_init(void);
 hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                 hipStream_t stream);
 /* encoder: one workgroup per code block; workgroup size and dynamic LDS of the selected encoder kernel for a code */
+int ldpc_enc_is_packed(void); /* 1: bit-packed kernel selected (default), 0: NRLDPC_HIP_ENC_KERNEL=bytes */
 void ldpc_enc_launch_shape(const ldpc_code_desc_t &host_code, int *n_threads, int *lds_bytes);
 hipError_t ldpc_launch_enc(const ldpc_enc_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                            hipStream_t stream);

@@ -132,6 +132,7 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   std::vector<tb_crc_chunk_job> cj;
   Arena ar;
   int enc_threads = 64, enc_lds = 0;
+  const bool fused = ldpc_enc_is_packed() != 0;
   size_t payload_end = 0, coded_end = 0;
   for (uint32_t i = 0; i < b->n_tb; i++) {
     const nrLDPC_hip_tb_t &t = b->tb[i];
@@ -165,8 +166,10 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
       tb_tx_seg_job j;
       memset(&j, 0, sizeof(j));
       j.b_off = tbj[i].b_off;
-      j.c_off = ar.take(sg.K / 8 + 4);
-      j.d_off = ar.take(N);
+      if (!fused) { /* the fused kernel keeps c and d in LDS */
+        j.c_off = ar.take(sg.K / 8 + 4);
+        j.d_off = ar.take(N);
+      }
       j.out_off = t.coded_off + r_offset;
       j.r = r; j.C = sg.C; j.Kprime = sg.Kprime; j.L = sg.L; j.K = sg.K;
       j.E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
@@ -211,14 +214,20 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
   HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(c.jobs_d.p + o_chk), (uint32_t)cj.size(),
                            payload, c.scratch.p, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
-  HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, g.crc_pow[NR_HIP_CRC24_B], s));
-  ldpc_enc_args ea;
-  memset(&ea, 0, sizeof(ea));
-  ea.in = c.scratch.p;
-  ea.out = c.scratch.p;
-  ea.jobs = reinterpret_cast<const ldpc_enc_job *>(c.jobs_d.p + o_enc);
-  HIP_TRY(ldpc_launch_enc_jobs(ea, enc_threads, enc_lds, (uint32_t)n_seg, s));
-  HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
+  const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(c.jobs_d.p + o_enc);
+  if (fused) {
+    HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, enc_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
+                               g.crc_pow[NR_HIP_CRC24_B], s));
+  } else {
+    HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, g.crc_pow[NR_HIP_CRC24_B], s));
+    ldpc_enc_args ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.in = c.scratch.p;
+    ea.out = c.scratch.p;
+    ea.jobs = d_enc;
+    HIP_TRY(ldpc_launch_enc_jobs(ea, enc_threads, enc_lds, (uint32_t)n_seg, s));
+    HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
+  }
   if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
     HIP_TRY(hipMemcpyAsync(b->coded, coded, coded_end, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -58,6 +58,12 @@ hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_cr
                             const uint32_t *pow16, hipStream_t s);
 hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s);
 hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s);
+/* segmentation + CB CRC + encoding + rate matching + interleaving in one kernel (bit-packed encoder); lds_bytes =
+ * the encoder's LDS (ldpc_enc_launch_shape) + TB_TX_FUSED_EXTRA_LDS */
+#define TB_TX_FUSED_EXTRA_LDS (8 + 1056 + 16)
+struct ldpc_enc_job;
+hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
+                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s);
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
                                 hipStream_t s);
 /* reassembly per segment (payload copy + partial TB CRC into acc[tb], zeroed by the caller), then per-TB verdict */

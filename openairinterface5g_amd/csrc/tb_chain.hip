@@ -12,6 +12,8 @@
  */
 #include <hip/hip_runtime.h>
 #include "tb_chain.h"
+#include "ldpc_kernels.h"
+#include "ldpc_enc_packed_core.h"
 
 #define TB_THREADS 256
 
@@ -143,6 +145,62 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_ratematch_kernel(const tb_tx
   }
 }
 
+/* ---- TX 2+3 fused: segmentation + CB CRC + bit-packed LDPC encoding + rate matching + interleaving --------------
+ * One workgroup per code block; the segment bytes, the code word (ldpc_enc_packed_core.h) and the selection all stay
+ * in LDS: HBM traffic = the segment's payload bytes in, E output bytes out (no c / d round trip through scratch). */
+__global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, const uint8_t *scratch,
+                                                          uint8_t *coded, const uint32_t *pow24b)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  typedef const tb_tx_seg_job LDPC_CONST_AS *seg_ptr_t;
+  typedef const ldpc_enc_job LDPC_CONST_AS *enc_ptr_t;
+  const seg_ptr_t j = (seg_ptr_t)jobs + blockIdx.x;
+  const enc_ptr_t ej = (enc_ptr_t)ejobs + blockIdx.x;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)ej->code;
+  const int Z = code->Z, tid = threadIdx.x, nt = blockDim.x;
+  ldpc_encp_lds L;
+  ldpc_encp_carve(reinterpret_cast<uint32_t *>(fsm), code, L);
+  uint32_t *red = L.RP + code->nrows + 1;
+  uint8_t *c = reinterpret_cast<uint8_t *>(red + 2);
+
+  /* c_r = b[r*(K'-L) ..] || CRC24B (C > 1) || zero fillers (nr_segmentation.c:147-175) */
+  const uint32_t Kprime = j->Kprime, Lcrc = j->L, segbytes = (Kprime - Lcrc) >> 3, kbytes = (j->K + 7) >> 3;
+  const uint8_t *src = scratch + j->b_off + (size_t)j->r * segbytes;
+  for (uint32_t q = tid; q < segbytes; q += nt)
+    c[q] = src[q];
+  for (uint32_t q = (Kprime >> 3) + tid; q < kbytes + 8; q += nt)
+    c[q] = 0;
+  if (j->C > 1) {
+    const uint32_t crc = tb_block_crc(src, Kprime - Lcrc, pow24b, red);
+    if (tid == 0) {
+      c[segbytes] = (uint8_t)(crc >> 24);
+      c[segbytes + 1] = (uint8_t)(crc >> 16);
+      c[segbytes + 2] = (uint8_t)(crc >> 8);
+    }
+  }
+  __syncthreads();
+  for (int ph = 0; ph < LDPC_ENCP_SOLVE_PHASES; ph++) {
+    ldpc_encp_phase(ph, code, ej->Kb, c, L, nullptr, tid, nt);
+    __syncthreads();
+  }
+  /* f[i + jj*Qm] = e[i*E/Qm + jj], e[k] = d[position of rank (rank0 + k) mod V], d[p] = code word bit p + 2Z */
+  uint8_t *__restrict__ f = coded + j->out_off;
+  const uint32_t E = j->E, Qm = j->Qm, EQ = E / Qm, V = j->V, rank0 = j->rank0, Foffset = j->Foffset, Fin = j->Fin;
+  const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u, bs = (uint32_t)ldpc_encp_W(Z) + 1u, twoZ = 2u * (uint32_t)Z;
+  for (uint32_t jj = tid; jj < EQ; jj += nt) {
+    uint32_t rank = (rank0 + jj) % V;
+    const uint32_t step = EQ % V;
+    for (uint32_t i = 0; i < Qm; i++) {
+      const uint32_t p = (rank < Foffset ? rank : rank + Fin) + twoZ;
+      const uint32_t col = __umulhi(p, z_magic), t = p - col * (uint32_t)Z;
+      f[jj * Qm + i] = (uint8_t)((L.B[col * bs + (t >> 5)] >> (t & 31u)) & 1u);
+      rank += step;
+      if (rank >= V)
+        rank -= V;
+    }
+  }
+}
+
 /* ---- RX 1: de-interleave + rate de-match (HARQ combining) + decoder input pack -------------------------------- */
 __global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
                                                                    int16_t *harq, int8_t *scratch)
@@ -255,6 +313,14 @@ hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *
 hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s)
 {
   TB_LAUNCH(tb_tx_ratematch_kernel, n, s, jobs, scratch, coded);
+}
+hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
+                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s)
+{
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(tb_tx_fused_kernel, dim3(n), dim3(n_threads), lds_bytes, s, jobs, ejobs, scratch, coded, pow24b);
+  return hipGetLastError();
 }
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
                                 hipStream_t s)

@@ -126,9 +126,9 @@ extern "C" int ldpc_emul_encode_packed(int BG, int Zc, int Kb, const uint8_t *in
   if (ldpc_build_code_desc(BG, Zc, BG == 1 ? 13 : 15, &code_s) != 0)
     return -1;
   const ldpc_code_desc_t *code = &code_s;
-  std::vector<uint32_t> lds(ldpc_encp_lds_words(code->ncols, code->kb_full, Zc), 0x5a5a5a5au);
+  std::vector<uint32_t> lds(ldpc_encp_lds_words(code->ncols, code->kb_full, Zc, code->nrows, code->nedges), 0x5a5a5a5au);
   ldpc_encp_lds L;
-  ldpc_encp_carve(lds.data(), code->ncols, code->kb_full, Zc, L);
+  ldpc_encp_carve(lds.data(), code, L);
   const int nt = ldpc_encp_threads(code->nrows, Zc);
   for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++)
     for (int tid = 0; tid < nt; tid++)

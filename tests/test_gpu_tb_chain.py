@@ -111,3 +111,17 @@ def test_invalid_parameters(hip):
         hip.ldpc.dlsch_encode_host([dict(A=1000, G=4001, BG=1, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])     # G % (Nl*Qm)
     with pytest.raises(RuntimeError):
         hip.ldpc.dlsch_encode_host([dict(A=1000, G=4000, BG=3, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])
+
+
+def test_unfused_tx_path_too():
+    """Default TX path = fused segment/encode/rate-match kernel; re-run the DL-SCH tests with the three-kernel path."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NRLDPC_HIP_ENC_KERNEL") == "bytes":
+        pytest.skip("already the three-kernel run")
+    env = dict(os.environ, NRLDPC_HIP_ENC_KERNEL="bytes")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_tb_chain.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "dlsch"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
