@@ -20,7 +20,7 @@ struct tb_crc_chunk_job {  /* one per TB_CRC_CHUNK bytes of a transport block: t
   uint32_t tb;             /* index into the per-TB job array */
   uint32_t first_byte;     /* byte range [first_byte, first_byte + TB_CRC_CHUNK) of the TB */
 };
-#define TB_CRC_CHUNK 2048u
+#define TB_CRC_CHUNK 8192u
 struct tb_tx_seg_job {     /* one per code block */
   uint64_t b_off;          /* the TB's b */
   uint64_t c_off;          /* scratch: packed segment, K/8 bytes (encoder input) */

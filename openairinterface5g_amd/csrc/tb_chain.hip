@@ -52,23 +52,57 @@ __device__ __forceinline__ uint32_t tb_block_crc(const uint8_t *__restrict__ dat
   return tb_block_xor(x, red);
 }
 
-/* Partial left-aligned CRC register of bytes [first, first+count) of an nbits-bit string (same linear form). */
+/* Byte table of a CRC from its power table: tab[v] = register after the single byte v = XOR of pow[m] over the set
+ * bits m of v (bit m is followed by m more bits).  256 entries of LDS; the caller synchronises. */
+__device__ __forceinline__ void tb_build_crc_tab(const uint32_t *__restrict__ pow, uint32_t *tab)
+{
+  for (uint32_t v = threadIdx.x; v < 256; v += blockDim.x) {
+    uint32_t x = 0;
+    for (int m = 0; m < 8; m++)
+      if (v & (1u << m))
+        x ^= pow[m];
+    tab[v] = x;
+  }
+}
+
+/* Partial left-aligned CRC register of bytes [first, first+count) of an nbits-bit string (same linear form as
+ * tb_block_crc).  Every thread runs the byte-table recurrence of crc_byte.c:148-182 over its own SPAN-byte piece
+ * (reg = (reg << 8) ^ tab[(reg >> 24) ^ byte], LDS look-ups), then moves the piece's register R to the end of the
+ * string: R(x) * x^n_after mod g = XOR over the set bits b of R of pow[b - 32 + n_after] (or the bit itself, shifted,
+ * while it still fits under the generator's degree).  Valid in lane 0 of every wave. */
+template <int SPAN>
 __device__ __forceinline__ uint32_t tb_partial_crc(const uint8_t *__restrict__ data, uint32_t nbits, uint32_t first, uint32_t count,
-                                                   const uint32_t *__restrict__ pow)
+                                                   const uint32_t *__restrict__ pow, const uint32_t *tab)
 {
   uint32_t x = 0;
-  for (uint32_t q = first + threadIdx.x; q < first + count; q += blockDim.x) {
-    uint32_t v = data[q];
-    const uint32_t top = nbits - 1 - 8 * q;
-    while (v) {
-      const int b = 31 - __clz(v);
-      x ^= pow[top - (7 - b)];
-      v &= ~(1u << b);
+  const uint32_t end = first + count;
+  for (uint32_t q0 = first + threadIdx.x * SPAN; q0 < end; q0 += blockDim.x * SPAN) {
+    const uint32_t n = end - q0 < (uint32_t)SPAN ? end - q0 : (uint32_t)SPAN;
+    uint32_t reg = 0;
+    if (n == (uint32_t)SPAN && ((reinterpret_cast<uintptr_t>(data + q0) & 3) == 0)) {
+#pragma unroll
+      for (int w = 0; w < SPAN / 4; w++) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(data + q0)[w];
+        reg = (reg << 8) ^ tab[(reg >> 24) ^ (v & 0xffu)];
+        reg = (reg << 8) ^ tab[(reg >> 24) ^ ((v >> 8) & 0xffu)];
+        reg = (reg << 8) ^ tab[(reg >> 24) ^ ((v >> 16) & 0xffu)];
+        reg = (reg << 8) ^ tab[(reg >> 24) ^ (v >> 24)];
+      }
+    } else {
+      for (uint32_t i = 0; i < n; i++)
+        reg = (reg << 8) ^ tab[(reg >> 24) ^ data[q0 + i]];
+    }
+    const int n_after = (int)(nbits - 8 * (q0 + n));
+    while (reg) {
+      const int b = 31 - __clz(reg);
+      const int jx = b - 32 + n_after;
+      x ^= jx >= 0 ? pow[jx] : (1u << (32 + jx));
+      reg &= ~(1u << b);
     }
   }
   for (int off = 32; off; off >>= 1)
     x ^= __shfl_xor(x, off);
-  return x; /* valid in lane 0 of every wave */
+  return x;
 }
 
 /* ---- TX 1: b = payload || CRC24A / CRC16 -- chunk-parallel: copy + partial CRC, then the CRC bytes ----------- */
@@ -76,15 +110,19 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_
                                                                        const uint8_t *payload, uint8_t *scratch, uint32_t *acc,
                                                                        const uint32_t *pow24a, const uint32_t *pow16)
 {
+  __shared__ uint32_t tab[256];
   const tb_crc_chunk_job ch = chunks[blockIdx.x];
   const tb_tx_tb_job j = jobs[ch.tb];
+  const uint32_t *pow = j.crc_type == 0 ? pow24a : pow16;
+  tb_build_crc_tab(pow, tab);
   const uint8_t *a = payload + j.payload_off;
   uint8_t *b = scratch + j.b_off;
   const uint32_t nbytes = j.A >> 3;
   const uint32_t count = ch.first_byte + TB_CRC_CHUNK <= nbytes ? TB_CRC_CHUNK : nbytes - ch.first_byte;
   for (uint32_t q = ch.first_byte + threadIdx.x; q < ch.first_byte + count; q += blockDim.x)
     b[q] = a[q];
-  const uint32_t x = tb_partial_crc(a, j.A, ch.first_byte, count, j.crc_type == 0 ? pow24a : pow16);
+  __syncthreads();
+  const uint32_t x = tb_partial_crc<32>(a, j.A, ch.first_byte, count, pow, tab);
   if ((threadIdx.x & 63) == 0 && x)
     atomicXor(&acc[ch.tb], x);
 }
@@ -247,8 +285,11 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
                                                                     const int32_t *n_iter, uint8_t *scratch, uint8_t *payload,
                                                                     uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16)
 {
+  __shared__ uint32_t tab[256];
   const tb_rx_seg_job sj = segs[blockIdx.x];
   const tb_rx_tb_job j = jobs[sj.tb];
+  const uint32_t *pow = j.crc_type == 0 ? pow24a : pow16;
+  tb_build_crc_tab(pow, tab);
   uint8_t *b = scratch + j.b_off;
   const uint32_t bbytes = j.B >> 3, abytes = j.A >> 3, first = sj.r * j.seg_bytes;
   const bool ok = n_iter[sj.iter_idx] <= (int)j.num_max_iter;
@@ -264,7 +305,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   }
   if (j.C > 1 && ok) {
     __syncthreads(); /* the CRC below re-reads b */
-    const uint32_t x = tb_partial_crc(b, j.B, first, count, j.crc_type == 0 ? pow24a : pow16);
+    const uint32_t x = tb_partial_crc<8>(b, j.B, first, count, pow, tab);
     if ((threadIdx.x & 63) == 0 && x)
       atomicXor(&acc[sj.tb], x);
   }
