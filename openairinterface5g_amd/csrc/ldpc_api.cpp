@@ -149,7 +149,7 @@ int out_bytes_of(const ldpc_code_desc_t &c, int outMode)
 /* per-thread staging for the synchronous host-buffer entry points (callers are thread-pool workers:
  * reference nr_ulsch_decoding.c:435-468, nr_dlsch_coding.c:389-403) */
 struct ThreadCtx {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr; /* stream2: second lane of the chunked host-buffer pipeline */
   uint8_t *h_in = nullptr, *h_out = nullptr; /* pinned */
   uint8_t *d_in = nullptr, *d_out = nullptr;
   int32_t *h_iter = nullptr, *d_iter = nullptr;
@@ -157,8 +157,10 @@ struct ThreadCtx {
   int ensure(size_t in_bytes, size_t out_bytes, size_t n_iter)
   {
     HIP_TRY(hipSetDevice(g.device));
-    if (!stream)
+    if (!stream) {
       HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    }
     if (in_bytes > cap_in) {
       if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
       cap_in = in_bytes + in_bytes / 2 + 4096;
@@ -183,6 +185,16 @@ struct ThreadCtx {
 thread_local ThreadCtx tls_ctx;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+bool host_ptr_is_pinned(const void *p)
+{
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError(); /* plain malloc memory: not an error for us */
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
 
 /* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it) */
 int launch_decoder(int kernel, const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t s)
@@ -282,22 +294,40 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
     return launch_decoder(b->kernel, a, hc, b->n_blocks, s);
   }
-  /* host buffers: stage through this thread's pinned buffers, synchronous */
+  /* host buffers: stage through this thread's pinned buffers, synchronous.  Large batches go in chunks of ~2 MiB of
+   * LLRs alternating between two streams: the CPU copy of chunk k+1 into pinned memory, the PCIe transfer of chunk k
+   * and the kernel of chunk k-1 overlap (every chunk has its own staging region, so no intermediate waits). */
   ThreadCtx &c = tls_ctx;
   const size_t in_stride = align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
   if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks, b->n_blocks) != 0)
     return -1;
-  for (uint32_t i = 0; i < b->n_blocks; i++)
-    memcpy(c.h_in + i * in_stride, b->llr + (size_t)i * b->llr_stride, hc.num_llr);
-  HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * b->n_blocks, hipMemcpyHostToDevice, c.stream));
-  a.llr = reinterpret_cast<const int8_t *>(c.d_in); a.llr_stride = (uint32_t)in_stride;
-  a.out = reinterpret_cast<int8_t *>(c.d_out); a.out_stride = (uint32_t)out_stride;
-  a.n_iter = c.d_iter;
-  if (launch_decoder(b->kernel, a, hc, b->n_blocks, c.stream) != 0)
-    return -1;
-  HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
-  HIP_TRY(hipMemcpyAsync(c.h_iter, c.d_iter, sizeof(int32_t) * b->n_blocks, hipMemcpyDeviceToHost, c.stream));
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)2 << 20) / in_stride);
+  /* LLRs that already live in page-locked memory (hipHostMalloc / hipHostRegister) are fetched by the copy engine
+   * directly; the CPU staging copy, which bounds the pageable case at memcpy speed, disappears */
+  const bool direct = b->n_blocks >= 16 && host_ptr_is_pinned(b->llr);
+  int lane = 0;
+  for (uint32_t i0 = 0; i0 < b->n_blocks; i0 += chunk, lane ^= 1) {
+    const uint32_t n = std::min(chunk, b->n_blocks - i0);
+    hipStream_t s = lane ? c.stream2 : c.stream;
+    if (direct) {
+      HIP_TRY(hipMemcpy2DAsync(c.d_in + i0 * in_stride, in_stride, b->llr + (size_t)i0 * b->llr_stride, b->llr_stride,
+                               (size_t)hc.num_llr, n, hipMemcpyHostToDevice, s));
+    } else {
+      for (uint32_t i = i0; i < i0 + n; i++)
+        memcpy(c.h_in + i * in_stride, b->llr + (size_t)i * b->llr_stride, hc.num_llr);
+      HIP_TRY(hipMemcpyAsync(c.d_in + i0 * in_stride, c.h_in + i0 * in_stride, in_stride * n, hipMemcpyHostToDevice, s));
+    }
+    a.llr = reinterpret_cast<const int8_t *>(c.d_in + i0 * in_stride); a.llr_stride = (uint32_t)in_stride;
+    a.out = reinterpret_cast<int8_t *>(c.d_out + i0 * out_stride); a.out_stride = (uint32_t)out_stride;
+    a.n_iter = c.d_iter + i0;
+    if (launch_decoder(b->kernel, a, hc, n, s) != 0)
+      return -1;
+    HIP_TRY(hipMemcpyAsync(c.h_out + i0 * out_stride, c.d_out + i0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c.h_iter + i0, c.d_iter + i0, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(c.stream));
+  if (b->n_blocks > chunk)
+    HIP_TRY(hipStreamSynchronize(c.stream2));
   for (uint32_t i = 0; i < b->n_blocks; i++) {
     const int32_t n = c.h_iter[i];
     b->n_iter[i] = n;

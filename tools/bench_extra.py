@@ -65,6 +65,33 @@ for regime, snr in (("fixed_work", -12.0), ("operating_point", 1.0)):
     res[f"config3_mixed_bg2_z64_z208_{regime}"] = {
         "blocks": sum(g[3] for g in groups), "ms": dt * 1e3, "coded_gbps": bits / dt / 1e9,
         "mean_passes": float(np.mean([b[5].float().mean().item() for b in bufs]))}
+    # the same four launches captured once in a HIP graph and replayed (device-memory calls are pure kernel launches)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    dtg = timeit(graph.replay, 50)
+    res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_replay_ms"] = dtg * 1e3
+    res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_coded_gbps"] = bits / dtg / 1e9
+
+# ---- config 2 through HOST buffers (PCIe-inclusive): pinned staging inside the library, 1024 blocks per call ---------
+_, llr_c2 = noisy_llr(1, 384, 13, 1024, 1.0, 5)
+llr_c2_h = llr_c2.cpu().numpy()
+out_c2_h = np.zeros((1024, 3264), np.uint8)
+dt = timeit(lambda: pkg.decode_batch_host(1, 384, 13, llr_c2_h, numMaxIter=8, out=out_c2_h), 10, warm=2)
+res["config2_host_buffers_pcie_inclusive_1dB"] = {"blocks": 1024, "ms": dt * 1e3, "coded_gbps": 1024 * 66 * 384 / dt / 1e9,
+                                                  "h2d_bytes": int(llr_c2_h.nbytes), "d2h_bytes": int(out_c2_h.nbytes)}
+llr_c2_p = torch.empty(llr_c2.shape, dtype=torch.int8, pin_memory=True)
+llr_c2_p.copy_(llr_c2)
+llr_c2_pn = llr_c2_p.numpy()
+it_ref, out_ref = pkg.decode_batch_host(1, 384, 13, llr_c2_h, numMaxIter=8)
+it_pin, out_pin = pkg.decode_batch_host(1, 384, 13, llr_c2_pn, numMaxIter=8)
+assert np.array_equal(it_ref, it_pin) and np.array_equal(out_ref, out_pin)
+dt = timeit(lambda: pkg.decode_batch_host(1, 384, 13, llr_c2_pn, numMaxIter=8, out=out_c2_h), 10, warm=2)
+res["config2_host_buffers_pinned_llr_1dB"] = {"blocks": 1024, "ms": dt * 1e3, "coded_gbps": 1024 * 66 * 384 / dt / 1e9}
 
 # ---- encoder alone: 1024 x BG1 Zc=384, device buffers ---------------------------------------------------------------
 info_e = torch.randint(0, 256, (1024, 22 * 384 // 8), dtype=torch.uint8, device="cuda")
