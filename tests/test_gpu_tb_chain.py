@@ -51,6 +51,29 @@ def test_dlsch_encode_matches_reference_chain(hip):
         assert np.array_equal(f, ref), t
 
 
+def test_dlsch_encode_random_sweep(hip):
+    """Seeded random transport blocks (size, base graph, modulation, layers, rv, LBRM, code rate from 0.15 to 0.95 incl.
+    repetition) in ONE heterogeneous call: every output bit equals the oracle chain's."""
+    rng = np.random.default_rng(20260927)
+    tbs = []
+    for _ in range(48):
+        bits = int(np.exp(rng.uniform(np.log(24), np.log(120000))))
+        BG = 2 if bits <= 292 else (int(rng.integers(1, 3)) if bits <= 30000 else 1)
+        Qm, Nl = int(rng.choice([2, 4, 6, 8])), int(rng.integers(1, 5))
+        A = valid_tbs(bits, BG)
+        rate = rng.uniform(0.15, 0.95)
+        G = max(1, int(A / rate) // (Qm * Nl)) * Qm * Nl
+        C = O.segmentation(None, O.len_with_crc(1, A), BG)["C"]
+        G = max(G, C * Qm * Nl * 4)
+        lbrm = int(rng.choice([0, 0, 2 * A, 3 * A]))          # Nref >= K - 2Zc (the reference's own contract)
+        tbs.append(dict(A=A, G=G, BG=BG, Qm=Qm, Nl=Nl, rv=int(rng.integers(0, 4)), tbslbrm=lbrm))
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+    for t, p, f in zip(tbs, pays, coded):
+        ref = O.dlsch_encode(t, p)
+        assert f.size == t["G"] == ref.size and np.array_equal(f, ref), t
+
+
 def test_ulsch_decode_matches_reference_chain_with_harq(hip):
     """Two HARQ rounds (rv 0 then rv 2) at an SNR where the first round fails for some blocks: payload, ACK, pass
     counts, soft buffers and the llrLen state must equal the oracle chain's after each round."""
@@ -80,6 +103,47 @@ def test_ulsch_decode_matches_reference_chain_with_harq(hip):
                 assert np.array_equal(harq_gpu[row + r], harq_ref[i][r]), (rnd, i, r)
             row += segs[i]
     assert ack.all()                                          # after combining every block decodes
+
+
+def test_ulsch_decode_random_sweep(hip):
+    """Seeded random transport blocks (both base graphs, all modulations, rv 0..3, LBRM, some too noisy to decode) in one
+    heterogeneous call: ACK, pass counts, payload, soft buffers and llrLen equal the oracle chain's."""
+    rng = np.random.default_rng(777)
+    tbs = []
+    for _ in range(12):
+        bits = int(np.exp(rng.uniform(np.log(24), np.log(20000))))
+        BG = 2 if bits <= 292 else int(rng.integers(1, 3))
+        Qm, Nl = int(rng.choice([2, 4, 6, 8])), int(rng.integers(1, 3))
+        A = valid_tbs(bits, BG)
+        C = O.segmentation(None, O.len_with_crc(1, A), BG)["C"]
+        G = max(int(A / rng.uniform(0.2, 0.8)) // (Qm * Nl), C * 4) * Qm * Nl
+        tbs.append(dict(A=A, G=G, BG=BG, Qm=Qm, Nl=Nl, rv=int(rng.choice([0, 0, 0, 1, 2, 3])), round=0,
+                        tbslbrm=int(rng.choice([0, 0, 3 * A]))))
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    harq_gpu = np.zeros((sum(segs), stride), np.int16)
+    llrs = []
+    for t, p in zip(tbs, pays):
+        f = O.dlsch_encode(t, p)
+        sigma = rng.choice([3.0, 5.0, 9.0])
+        llrs.append(np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + sigma * rng.standard_normal(f.size)), -200, 200).astype(np.int16))
+    out, ack, itm = hip.ldpc.ulsch_decode_host(tbs, llrs, harq_gpu, numMaxIter=6)
+    row, n_ack = 0, 0
+    for i, t in enumerate(tbs):
+        harq_ref = [np.zeros(stride, np.int16) for _ in range(segs[i])]
+        p_ref, ack_ref, its, state = O.ulsch_decode(t, llrs[i], harq_ref, 6, 0, 0)
+        assert bool(ack[i]) == ack_ref and itm[i] == max(its), (t, its, int(itm[i]))
+        assert t["llrLen"] == state
+        if ack_ref:
+            # (a rv != 0 transmission that carries no systematic bits can "decode" to the all-zero word, whose CRC is
+            # zero: the reference ACKs it, so must we -- hence the comparison is with the oracle, not with the payload)
+            assert np.array_equal(out[i], p_ref), t
+            n_ack += int(np.array_equal(p_ref, pays[i]))
+        for r in range(segs[i]):
+            assert np.array_equal(harq_gpu[row + r], harq_ref[r]), (i, r)
+        row += segs[i]
+    assert n_ack >= 4
 
 
 def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
