@@ -121,7 +121,9 @@ typedef struct nrLDPC_hip_dec_batch {
   int32_t *n_iter;            /* [n_blocks] return value of each block (same meaning as LDPCdecoder's) */
   int32_t mem;                /* NRLDPC_HIP_MEM_* for llr/out/n_iter alike */
   void *stream;               /* hipStream_t for DEVICE mem; NULL = HIP's default (null) stream */
-  int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code); 2 = fast kernel or error */
+  int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code); 2 = fast kernel or error;
+                               * 3 / 4 = fast kernel with the throughput / latency workgroup shape forced (0 and 2 pick the
+                               * shape from n_blocks: latency shape up to one workgroup round of the GPU) */
 } nrLDPC_hip_dec_batch_t;
 /* 0 on success, negative on bad parameters / HIP error.  DEVICE mem: asynchronous w.r.t. the host. */
 int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b);
@@ -190,6 +192,9 @@ int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int3
 int32_t nrLDPC_hip_num_llr(int BG, int Z, int R);      /* ncols*Z, -1 if invalid */
 int32_t nrLDPC_hip_out_bytes(int BG, int Z, int R, int outMode);
 int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R);    /* LDS a decoder workgroup uses for this code */
+/* info = {rows, columns, edges of the (BG, R) base graph; 1 if the fast decoder kernel serves the code; its workgroup
+ * size; its LDS bytes; check-node and bit-node tasks per pass (fast kernel)}.  0, or -1 for an invalid code. */
+int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8]);
 const char *nrLDPC_hip_last_error(void);
 const char *nrLDPC_hip_version(void);
 

@@ -90,9 +90,9 @@ int agg_run_group(std::vector<AggReq *> &reqs)
     }
     memcpy(c.h_in + jobs_bytes + in_off[i], reqs[i]->llr, hc.num_llr);
     (hc.f_ok ? fast_idx : gen_idx).push_back((uint32_t)i);
-    if (hc.f_ok) {
-      fast_threads = std::max(fast_threads, hc.f_n_threads);
-      fast_lds = std::max(fast_lds, hc.f_lds_total);
+    if (hc.f_ok) { /* a handful of blocks per launch: latency shape */
+      fast_threads = std::max(fast_threads, reqs[i]->ce->host_lat.f_n_threads);
+      fast_lds = std::max(fast_lds, reqs[i]->ce->host_lat.f_lds_total);
     } else {
       gen_threads = std::max(gen_threads, hc.n_threads);
       gen_lds = std::max(gen_lds, hc.lds_total);
@@ -103,7 +103,7 @@ int agg_run_group(std::vector<AggReq *> &reqs)
   for (int pass = 0; pass < 2; pass++)
     for (uint32_t i : (pass == 0 ? fast_idx : gen_idx)) {
       ldpc_dec_job &j = hj[k++];
-      j.code = reqs[i]->ce->dev;
+      j.code = pass == 0 ? reqs[i]->ce->dev_lat : reqs[i]->ce->dev;
       j.llr_off = jobs_bytes + in_off[i];
       j.out_off = out_off[i];
       j.num_max_iter = reqs[i]->p->numMaxIter;

@@ -42,14 +42,23 @@ int set_error(const char *what, hipError_t e = hipSuccess)
   } while (0)
 
 struct CodeEntry {
-  ldpc_code_desc_t host;
+  ldpc_code_desc_t host;            /* throughput shape (ldpc_graph.h); everything shape independent is read from here */
   ldpc_code_desc_t *dev = nullptr;
+  ldpc_code_desc_t host_lat;        /* latency shape, for launches of at most one workgroup round */
+  ldpc_code_desc_t *dev_lat = nullptr;
+  /* the variant for a decoder launch of n_blocks workgroups; force: 0 = by size, 1 = throughput, 2 = latency */
+  bool use_latency(uint32_t n_blocks, int n_cus, int force = 0) const
+  {
+    if (force)
+      return force == 2;
+    return host.f_ok && n_blocks <= (uint32_t)(n_cus * host_lat.f_wg_per_cu);
+  }
 };
 
 struct Library {
   std::mutex mu;
   bool ready = false;
-  int device = 0;
+  int device = 0, n_cus = 256;
   std::map<uint32_t, CodeEntry *> codes;
   uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8: x^j mod g, j < 8448 */
   uint32_t *crc_pow_24a_long = nullptr;                        /* CRC24_A up to a whole transport block */
@@ -86,6 +95,11 @@ int ensure_ready_locked()
   if (g.device < 0 || g.device >= ndev)
     return set_error("NRLDPC_HIP_DEVICE out of range");
   HIP_TRY(hipSetDevice(g.device));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   HIP_TRY(ldpc_kernels_init());
   HIP_TRY(ldpc_fast_kernel_init());
   static const uint32_t polys[4] = {0x864cfb00u, 0x80006300u, 0x10210000u, 0x9B000000u};
@@ -122,16 +136,21 @@ const CodeEntry *get_code(int BG, int Z, int R)
   if (it != g.codes.end())
     return it->second;
   CodeEntry *ce = new CodeEntry();
-  if (ldpc_build_code_desc(BG, Z, R, &ce->host) != 0) {
+  if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_THROUGHPUT, &ce->host) != 0 ||
+      ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_LATENCY, &ce->host_lat) != 0) {
     delete ce;
     set_error("invalid (BG, Z, R)");
     return nullptr;
   }
   hipError_t e = hipSetDevice(g.device);
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&ce->dev), sizeof(ldpc_code_desc_t));
+    e = hipMalloc(reinterpret_cast<void **>(&ce->dev), 2 * sizeof(ldpc_code_desc_t));
   if (e == hipSuccess)
     e = hipMemcpy(ce->dev, &ce->host, sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ce->dev_lat = ce->dev + 1;
+    e = hipMemcpy(ce->dev_lat, &ce->host_lat, sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     set_error("descriptor upload", e);
     delete ce;
@@ -196,16 +215,24 @@ bool host_ptr_is_pinned(const void *p)
   return at.type == hipMemoryTypeHost;
 }
 
-/* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it) */
-int launch_decoder(int kernel, const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t s)
+/* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it), with the
+ * workgroup shape picked from the launch size; 3 / 4 = fast kernel, throughput / latency shape forced (tests, tuning) */
+int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_blocks, hipStream_t s, uint32_t batch_blocks = 0)
 {
+  if (batch_blocks < n_blocks)
+    batch_blocks = n_blocks; /* the launch is one chunk of a larger batch: the whole batch decides the shape */
+  const ldpc_code_desc_t &hc = ce->host;
   const bool fast_ok = hc.f_ok && ((reinterpret_cast<uintptr_t>(a.llr) | a.llr_stride) & 3) == 0;
-  if (kernel == 2 && !fast_ok)
+  if (kernel >= 2 && !fast_ok)
     return set_error("fast kernel not applicable (needs Zc % 4 == 0, Zc >= 8, 4-byte aligned LLR rows)");
-  if (kernel != 1 && fast_ok)
-    HIP_TRY(ldpc_launch_dec_fast(a, hc, n_blocks, s));
-  else
+  if (kernel != 1 && fast_ok) {
+    const bool lat = ce->use_latency(batch_blocks, g.n_cus, kernel == 3 ? 1 : (kernel == 4 ? 2 : 0));
+    a.code = lat ? ce->dev_lat : ce->dev;
+    HIP_TRY(ldpc_launch_dec_fast(a, lat ? ce->host_lat : ce->host, n_blocks, s));
+  } else {
+    a.code = ce->dev;
     HIP_TRY(ldpc_launch_dec_generic(a, hc, n_blocks, s));
+  }
   return 0;
 }
 
@@ -258,6 +285,19 @@ int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R)
   return ldpc_build_code_desc(BG, Z, R, &d) == 0 ? d.lds_total : -1;
 }
 
+int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8])
+{
+  static thread_local ldpc_code_desc_t d;
+  if (!info || ldpc_build_code_desc(BG, Z, R, &d) != 0)
+    return -1;
+  info[0] = d.nrows; info[1] = d.ncols; info[2] = d.nedges; info[3] = d.f_ok;
+  info[4] = d.f_ok ? d.f_n_threads : d.n_threads;
+  info[5] = d.f_ok ? d.f_lds_total : d.lds_total;
+  info[6] = d.f_ok ? d.f_n_cn_tasks : 0;
+  info[7] = d.f_ok ? d.f_n_bn_tasks : 0;
+  return 0;
+}
+
 int32_t LDPCinit(void) { return ensure_ready() == 0 ? 0 : -1; }
 
 int32_t LDPCshutdown(void)
@@ -292,7 +332,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     a.out = b->out; a.out_stride = b->out_stride;
     a.n_iter = b->n_iter;
     hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
-    return launch_decoder(b->kernel, a, hc, b->n_blocks, s);
+    return launch_decoder(b->kernel, a, ce, b->n_blocks, s);
   }
   /* host buffers: stage through this thread's pinned buffers, synchronous.  Large batches go in chunks of ~2 MiB of
    * LLRs alternating between two streams: the CPU copy of chunk k+1 into pinned memory, the PCIe transfer of chunk k
@@ -320,7 +360,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     a.llr = reinterpret_cast<const int8_t *>(c.d_in + i0 * in_stride); a.llr_stride = (uint32_t)in_stride;
     a.out = reinterpret_cast<int8_t *>(c.d_out + i0 * out_stride); a.out_stride = (uint32_t)out_stride;
     a.n_iter = c.d_iter + i0;
-    if (launch_decoder(b->kernel, a, hc, n, s) != 0)
+    if (launch_decoder(b->kernel, a, ce, n, s, b->n_blocks) != 0)
       return -1;
     HIP_TRY(hipMemcpyAsync(c.h_out + i0 * out_stride, c.d_out + i0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(c.h_iter + i0, c.d_iter + i0, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));

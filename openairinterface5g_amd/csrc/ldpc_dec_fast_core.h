@@ -74,6 +74,8 @@ struct ldpc_fast_lds {
   uint8_t *app;  /* [ncore][2Z]    biased clamped APP, stored twice */
   uint8_t *ext;  /* [ncols-ncore][Z] biased channel LLR of the degree-1 columns */
   const uint32_t *etbl, *ctbl, *rowtbl, *coltbl;
+  const uint8_t *gllr; /* the block's channel LLRs in global memory (true int8 bytes) */
+  int ext_global;      /* extension-column LLRs are read from gllr instead of `ext` (ldpc_graph.c) */
 };
 
 /* LDS offsets held in the LDS-resident tables are ABSOLUTE LDS addresses on the device (the kernel adds the address
@@ -117,7 +119,8 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
 {
   uint32_t al, ah, rl, rh;
   if (IS_EXT) {
-    const uint32_t lw = ldpc_lds_ld32(L.base, info + (uint32_t)t);
+    const uint32_t lw = L.ext_global ? (*reinterpret_cast<const uint32_t *>(L.gllr + info + (uint32_t)t) ^ 0x80808080u)
+                                     : ldpc_lds_ld32(L.base, info + (uint32_t)t);
     al = ldpc_perm(0x80808080u, lw, 0x05010400u);
     ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
     if (first) { /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */

@@ -44,8 +44,11 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
   const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
+  const int ext_global = code->f_ext_global;
+  L.gllr = reinterpret_cast<const uint8_t *>(src32);
+  L.ext_global = ext_global;
   for (int i = tid; i < nedges; i += nt)
-    etbl[i] = code->f_etbl[i] + lds0;
+    etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
   for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
     ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
   for (int i = tid; i < (Z + 4) >> 2; i += nt)
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     dst[zq] = w;
   }
   {
-    const int next4 = (code->ncols - ncore) * zq;
+    const int next4 = ext_global ? 0 : (code->ncols - ncore) * zq;
     uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
     for (int i = tid; i < next4; i += nt)
       e32[i] = src32[ncore * zq + i] ^ 0x80808080u;

@@ -69,7 +69,7 @@ static void lpt_assign(int n, const int *cost, int nw, int32_t *ptr, int32_t *li
 }
 
 /* schedules and tables of the "fast" decoder kernel (see ldpc_graph.h) */
-static void build_fast_section(ldpc_code_desc_t *d)
+static void build_fast_section(ldpc_code_desc_t *d, int shape)
 {
   const int Z = d->Z;
   d->f_ok = 0;
@@ -119,16 +119,6 @@ static void build_fast_section(ldpc_code_desc_t *d)
     i = j;
   }
   d->f_n_cn_tasks = nt;
-  int waves = (nt + 3) / 4;
-  if (waves < 1) waves = 1;
-  int max_waves = LDPC_F_DEFAULT_WAVES;
-  const char *env = getenv("NRLDPC_HIP_FAST_WAVES"); /* tuning knob: waves per workgroup of the fast kernel */
-  if (env && atoi(env) >= 1 && atoi(env) <= LDPC_F_MAX_WAVES)
-    max_waves = atoi(env);
-  if (waves > max_waves) waves = max_waves;
-  d->f_n_threads = waves * 64;
-  lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
-
   /* columns sorted by degree (descending), their adjacency, BN tasks */
   sort_item_t cols[LDPC_MAX_CORE];
   for (int c = 0; c < d->ncore; c++) {
@@ -171,7 +161,6 @@ static void build_fast_section(ldpc_code_desc_t *d)
     nb++;
   }
   d->f_n_bn_tasks = nb;
-  lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
 
   /* the magic division must be exact for every item index that occurs */
   const int max_item = d->nrows * zq > nitems ? d->nrows * zq : nitems;
@@ -179,10 +168,61 @@ static void build_fast_section(ldpc_code_desc_t *d)
     if ((int)(((uint64_t)i * d->f_zq_magic) >> 32) != i / zq)
       return;
 
+  /* LDS layout.  The channel LLRs of the degree-1 columns are read once per pass by one check-node edge each; when
+   * leaving them in global memory (L2) lets one more workgroup fit on a CU, they are not staged (f_ext_global). */
+  const int ext_bytes = align16((d->ncols - d->ncore) * Z);
+  const int fixed = align16(d->nedges * d->f_rstride) + align16(d->ncore * d->f_astride) + align16(d->nedges * 4) +
+                    align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(Z + 4) + 64;
+  /* Workgroup shape.  A CU holds 16 waves of this kernel (<= 128 VGPRs), so the waves per workgroup w and the
+   * workgroups per CU k are chosen together: maximise the resident waves k*w subject to k workgroups fitting in the
+   * 160 KiB of LDS (with or without the staged extension LLRs) and w <= tasks / 2; w a multiple of 4 so that the
+   * waves spread evenly over the four SIMDs.  Ties: more workgroups per CU (their barriers overlap), then LDS staging.
+   * Measured on MI355X (profiles/r01/occupancy_sweep.txt): BG1 Zc=192 10 waves x 1 -> 8 x 2: 35 -> 48 Gb/s.
+   * That is the THROUGHPUT shape (launches that fill the GPU more than once).  The LATENCY shape, for launches of at
+   * most one workgroup round (the per-segment entry point above all), takes as many waves as there are tasks:
+   * BG1 Zc=384 R=8/9, one block per CU: 2 waves 210 us, 8 waves 80 us. */
+  int waves = 1;
+  const int lds_cu = 160 * 1024;
+  if (shape == LDPC_SHAPE_LATENCY) {
+    waves = nt < LDPC_F_MAX_WAVES ? nt : LDPC_F_MAX_WAVES;
+    d->f_ext_global = 0;
+  } else {
+    int best_score = -1, best_k = 0;
+    d->f_ext_global = 0;
+    for (int w = LDPC_F_MAX_WAVES; w >= 1; w = (w > 4 ? w - 4 : w - 1)) {
+      if (w > 1 && 2 * w > nt)
+        continue;
+      for (int eg = 0; eg <= 1; eg++) {
+        int k = lds_cu / (fixed + (eg ? 0 : ext_bytes));
+        if (k > 16 / w) k = 16 / w;
+        if (k > 8) k = 8;
+        if (k < 1)
+          continue;
+        const int score = k * w;
+        if (score > best_score || (score == best_score && k > best_k)) {
+          best_score = score; best_k = k; waves = w; d->f_ext_global = eg;
+        }
+      }
+    }
+    const char *env = getenv("NRLDPC_HIP_FAST_WAVES"); /* tuning knobs: force waves per workgroup / LLR staging */
+    if (env && atoi(env) >= 1 && atoi(env) <= LDPC_F_MAX_WAVES)
+      waves = atoi(env) < nt ? atoi(env) : nt;
+    const char *eg = getenv("NRLDPC_HIP_EXT_GLOBAL");
+    if (eg && (eg[0] == '0' || eg[0] == '1'))
+      d->f_ext_global = eg[0] == '1';
+  }
+  {
+    int k = lds_cu / (fixed + (d->f_ext_global ? 0 : ext_bytes));
+    if (k > 16 / waves) k = 16 / waves;
+    d->f_wg_per_cu = k < 1 ? 1 : k;
+  }
+  d->f_n_threads = waves * 64;
+  lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
+  lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
   d->f_lds_r = 0;
   d->f_lds_app = align16(d->nedges * d->f_rstride);
   d->f_lds_ext = d->f_lds_app + align16(d->ncore * d->f_astride);
-  d->f_lds_etbl = d->f_lds_ext + align16((d->ncols - d->ncore) * Z);
+  d->f_lds_etbl = d->f_lds_ext + (d->f_ext_global ? 0 : ext_bytes);
   d->f_lds_ctbl = d->f_lds_etbl + align16(d->nedges * 4);
   d->f_lds_rowtbl = d->f_lds_ctbl + align16(d->f_n_ctbl * 8);
   d->f_lds_coltbl = d->f_lds_rowtbl + align16(d->nrows * 4);
@@ -198,12 +238,17 @@ static void build_fast_section(ldpc_code_desc_t *d)
   for (int e = 0; e < d->nedges; e++) {
     const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
     d->f_etbl[e] = c < d->ncore ? (uint32_t)(d->f_lds_app + c * d->f_astride + s)
-                                : (uint32_t)(d->f_lds_ext + (c - d->ncore) * Z);
+                                : (d->f_ext_global ? (uint32_t)(c * Z) : (uint32_t)(d->f_lds_ext + (c - d->ncore) * Z));
   }
   d->f_ok = 1;
 }
 
 int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d)
+{
+  return ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_THROUGHPUT, d);
+}
+
+int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t *d)
 {
   const int ils = ldpc_lifting_set_index(Z);
   if (ils < 0)
@@ -367,6 +412,6 @@ int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d)
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;
   d->n_threads = waves * 64;
-  build_fast_section(d);
+  build_fast_section(d, shape);
   return 0;
 }

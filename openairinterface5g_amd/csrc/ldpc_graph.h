@@ -86,13 +86,16 @@ typedef struct ldpc_code_desc {
   /* tables the kernel copies into LDS (read per lane): */
   uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge | pc_lo << 16 */
   uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;
-                                            extension column: f_lds_ext + (col-ncore)*Z */
+                                            extension column: f_lds_ext + (col-ncore)*Z, or col*Z = byte offset in the
+                                            block's LLR input when f_ext_global */
   uint32_t f_coltbl[LDPC_MAX_CORE + 2];  /* per sorted column: col | degree << 8 | first entry in f_ctbl << 16 */
   /* per (sorted column, k): two dwords {x = Z - shift, LDS byte offset of the edge's message row - (x & 3)}.  A column's list is
    * padded up to the degree of the earliest column it can share a task with; padding entries {Z, f_lds_zero} point
    * at a row of zero bytes, so short columns need no predication in the gather loop. */
   uint32_t f_ctbl[2 * LDPC_F_MAX_CTBL];
   int32_t f_n_ctbl;   /* entries (pairs) used */
+  int32_t f_wg_per_cu;  /* workgroups of this shape resident on one CU (16 wave slots, 160 KiB LDS) */
+  int32_t f_ext_global; /* 1: the degree-1 columns' LLRs are read from the input buffer, not staged in LDS */
   int32_t f_lds_zero; /* Z + 4 zero bytes */
 } ldpc_code_desc_t;
 
@@ -100,7 +103,13 @@ typedef struct ldpc_code_desc {
 extern "C" {
 #endif
 /* Fill *d for (BG, Z, R).  Returns 0, or -1 if (BG, Z, R) is not a valid NR LDPC configuration. */
-int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d);
+int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d); /* = throughput shape */
+/* The fast kernel's workgroup shape (waves per workgroup, LLR staging; everything else is identical):
+ * THROUGHPUT fills a CU's 16 wave slots with as many workgroups as its LDS admits -- for launches of more than one
+ * workgroup round; LATENCY gives one block as many waves as it has tasks -- for small launches. */
+#define LDPC_SHAPE_THROUGHPUT 0
+#define LDPC_SHAPE_LATENCY 1
+int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t *d);
 /* set index iLS of lifting size Z (38.212 Table 5.3.2-1), -1 if Z is not a lifting size */
 int ldpc_lifting_set_index(int Z);
 #ifdef __cplusplus

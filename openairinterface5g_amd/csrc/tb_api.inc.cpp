@@ -251,6 +251,15 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   Arena ar;
   int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
   size_t payload_end = 0, llr_end = 0, harq_end = 0;
+  /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
+  uint32_t n_seg_total = 0;
+  for (uint32_t i = 0; i < b->n_tb; i++) {
+    nr_hip_seg_t sg;
+    if (b->tb[i].A && (b->tb[i].BG == 1 || b->tb[i].BG == 2) &&
+        nr_hip_segmentation((uint32_t)nr_hip_len_with_crc(1, (int)b->tb[i].A), b->tb[i].BG, &sg) == 0)
+      n_seg_total += sg.C;
+  }
+  const bool lat_shape = n_seg_total <= (uint32_t)g.n_cus;
   for (uint32_t i = 0; i < b->n_tb; i++) {
     nrLDPC_hip_tb_t &t = b->tb[i];
     if (tb_validate(t) != 0)
@@ -304,7 +313,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
       j.c_off = tj.c_off0 + (uint64_t)r * cstride;
       j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
       ldpc_dec_job dj;
-      dj.code = ce->dev;
+      const ldpc_code_desc_t &shape = lat_shape ? ce->host_lat : ce->host;
+      dj.code = (hc.f_ok && lat_shape) ? ce->dev_lat : ce->dev;
       dj.llr_off = j.l_off;
       dj.out_off = tj.c_off0 + (uint64_t)r * cstride;
       dj.num_max_iter = t.numMaxIter;
@@ -315,8 +325,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
         return set_error("CRC length outside the code block");
       if (hc.f_ok) {
         fast_jobs.push_back(dj);
-        fast_threads = std::max(fast_threads, hc.f_n_threads);
-        fast_lds = std::max(fast_lds, hc.f_lds_total);
+        fast_threads = std::max(fast_threads, shape.f_n_threads);
+        fast_lds = std::max(fast_lds, shape.f_lds_total);
       } else {
         gen_jobs.push_back(dj);
         gen_threads = std::max(gen_threads, hc.n_threads);

@@ -66,7 +66,7 @@ class nrLDPC_hip_enc_batch_t(C.Structure):
 _CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
 
 EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "LDPCdecoder_batch", "LDPCencoder_batch",
-           "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_last_error",
+           "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version"]
 
 _lib = None
@@ -126,6 +126,17 @@ def LDPCshutdown():
 
 def num_llr(BG, Z, R):
     return NCOLS[(BG, R)] * Z
+
+
+def code_info(BG, Z, R):
+    """Shape of a code and of the decoder launch that serves it (nrLDPC_hip_code_info)."""
+    L = load_library()
+    a = (C.c_int32 * 8)()
+    L.nrLDPC_hip_code_info.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    if L.nrLDPC_hip_code_info(BG, Z, R, a) != 0:
+        raise ValueError("invalid code")
+    return dict(nrows=a[0], ncols=a[1], nedges=a[2], kernel="fast" if a[3] else "generic", threads=a[4],
+                lds_kib=round(a[5] / 1024, 1), cn_tasks=a[6], bn_tasks=a[7])
 
 
 def out_bytes(BG, Z, R, outMode=nrLDPC_outMode_BIT):

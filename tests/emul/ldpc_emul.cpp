@@ -141,11 +141,14 @@ extern "C" int ldpc_emul_desc(int BG, int Z, int R, ldpc_code_desc_t *d) { retur
 /* ---- fast kernel (ldpc_decoder_fast.hip) ---------------------------------------------------------------- */
 #include "../../openairinterface5g_amd/csrc/ldpc_dec_fast_core.h"
 
+static int g_fast_shape = LDPC_SHAPE_THROUGHPUT;
+extern "C" void ldpc_emul_set_fast_shape(int shape) { g_fast_shape = shape; }
+
 extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int outMode, int use_crc, int E, int crc_type,
                                      const int8_t *llr_in, int8_t *out)
 {
   ldpc_code_desc_t code_s;
-  if (ldpc_build_code_desc(BG, Z, R, &code_s) != 0)
+  if (ldpc_build_code_desc_shape(BG, Z, R, g_fast_shape, &code_s) != 0)
     return -1;
   const ldpc_code_desc_t *code = &code_s;
   if (!code->f_ok)
@@ -174,6 +177,8 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
   if (use_crc)
     crc_pow_table(polys[crc_type], crc_pow, 8448);
 
+  L.gllr = reinterpret_cast<const uint8_t *>(src32);
+  L.ext_global = code->f_ext_global;
   for (int i = 0; i < nedges; i++) etbl[i] = code->f_etbl[i];
   for (int i = 0; i < 2 * code->f_n_ctbl; i++) ctbl[i] = code->f_ctbl[i];
   for (int i = 0; i < (Z + 4) >> 2; i++) reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
@@ -187,7 +192,7 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
     dst[zq] = w;
   }
   {
-    const int next4 = (code->ncols - ncore) * zq;
+    const int next4 = code->f_ext_global ? 0 : (code->ncols - ncore) * zq;
     uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
     for (int i = 0; i < next4; i++) e32[i] = src32[ncore * zq + i] ^ 0x80808080u;
     const int nr4 = (nedges * rstride) >> 2;

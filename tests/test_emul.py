@@ -26,12 +26,15 @@ def run(emul, fast, BG, Z, R, llr, it, mode=0, use_crc=False, E=0, ct=1, init=0)
     out = np.full(68 * 384 + 64, init, np.uint8)
     llr = np.ascontiguousarray(llr, dtype=np.int8)
     f = emul.ldpc_emul_decode_fast if fast else emul.ldpc_emul_decode
+    if fast:
+        emul.ldpc_emul_set_fast_shape(1 if fast == "latency" else 0)   # ldpc_graph.h LDPC_SHAPE_*
     n = f(BG, Z, R, it, mode, int(use_crc), E, ct, llr.ctypes.data, out.ctypes.data)
     return n, out[:O.out_bytes(BG, Z, R, mode)]
 
 
 def variants(Z):
-    return (False, True) if (Z % 4 == 0 and Z >= 8) else (False,)
+    """generic kernel; fast kernel in its throughput and latency workgroup shapes where it applies"""
+    return (False, "throughput", "latency") if (Z % 4 == 0 and Z >= 8) else (False,)
 
 
 @pytest.mark.parametrize("BG", [1, 2])

@@ -21,6 +21,10 @@ pkg.LDPCinit()
 res = {}
 
 
+def progress(msg):
+    print("[bench_extra]", msg, file=sys.stderr, flush=True)
+
+
 def timeit(fn, n, warm=3):
     for _ in range(warm):
         fn()
@@ -77,6 +81,7 @@ for regime, snr in (("fixed_work", -12.0), ("operating_point", 1.0)):
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_replay_ms"] = dtg * 1e3
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_coded_gbps"] = bits / dtg / 1e9
 
+progress('config3 done')
 # ---- config 2 through HOST buffers (PCIe-inclusive): pinned staging inside the library, 1024 blocks per call ---------
 _, llr_c2 = noisy_llr(1, 384, 13, 1024, 1.0, 5)
 llr_c2_h = llr_c2.cpu().numpy()
@@ -93,6 +98,7 @@ assert np.array_equal(it_ref, it_pin) and np.array_equal(out_ref, out_pin)
 dt = timeit(lambda: pkg.decode_batch_host(1, 384, 13, llr_c2_pn, numMaxIter=8, out=out_c2_h), 10, warm=2)
 res["config2_host_buffers_pinned_llr_1dB"] = {"blocks": 1024, "ms": dt * 1e3, "coded_gbps": 1024 * 66 * 384 / dt / 1e9}
 
+progress('config2 host done')
 # ---- encoder alone: 1024 x BG1 Zc=384, device buffers ---------------------------------------------------------------
 info_e = torch.randint(0, 256, (1024, 22 * 384 // 8), dtype=torch.uint8, device="cuda")
 coded_e = torch.empty((1024, 66 * 384), dtype=torch.uint8, device="cuda")
@@ -100,6 +106,7 @@ dt = timeit(lambda: pkg.encode_batch_device(1, 384, info_e, coded_e), 50)
 res["encoder_bg1_z384_1024_blocks"] = {"ms": dt * 1e3, "coded_gbps": 1024 * 66 * 384 / dt / 1e9,
                                        "out_bytes_gbs": 1024 * 66 * 384 / dt / 1e9}
 
+progress('encoder done')
 # ---- config 4/5: 64 transport blocks of 273 PRB x 13 symbols, 64QAM, 1 layer (TBS ~213 kbit) through the TB chain ----
 A = 213176
 while True:
@@ -138,6 +145,7 @@ host_enc = host_only(enc_batch.encode)
 res["config4_dlsch_encode_64tb_273prb_64qam"] = {
     "tb_bits": A, "G": G, "segments_per_tb": segs[0], "ms": dt_enc * 1e3,
     "host_ms_per_call": host_enc * 1e3, "info_gbps": n_tb * A / dt_enc / 1e9, "coded_gbps": n_tb * G / dt_enc / 1e9}
+progress('config4 done')
 sigma = 0.18
 llr = ((1.0 - 2.0 * coded.float()) * 10 + sigma * 10 * torch.randn(coded.numel(), device="cuda")).round().clamp(-127, 127).to(torch.int16)
 harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
@@ -154,6 +162,7 @@ res["config5_ulsch_decode_64tb_273prb_64qam"] = {
     "info_gbps": n_tb * A / dt_dec / 1e9,
     "coded_gbps": n_tb * G / dt_dec / 1e9, "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
 
+progress('config5 done')
 # ---- per-segment reference ABI (LDPCdecoder, host buffers): latency and multi-thread throughput ------------------------
 BG, Z, R = 1, 384, 13
 _, llr_d = noisy_llr(BG, Z, R, 64, 1.0, 99)
