@@ -339,8 +339,12 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
    * and the kernel of chunk k-1 overlap (every chunk has its own staging region, so no intermediate waits). */
   ThreadCtx &c = tls_ctx;
   const size_t in_stride = align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
-  if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks, b->n_blocks) != 0)
+  /* the pass counts travel behind the output rows in the same buffers: one device->host copy for a one-chunk call */
+  const size_t iter_off = out_stride * b->n_blocks;
+  if (c.ensure(in_stride * b->n_blocks, iter_off + sizeof(int32_t) * b->n_blocks, 1) != 0)
     return -1;
+  int32_t *d_iter = reinterpret_cast<int32_t *>(c.d_out + iter_off);
+  const int32_t *h_iter = reinterpret_cast<const int32_t *>(c.h_out + iter_off);
   const uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)2 << 20) / in_stride);
   /* LLRs that already live in page-locked memory (hipHostMalloc / hipHostRegister) are fetched by the copy engine
    * directly; the CPU staging copy, which bounds the pageable case at memcpy speed, disappears */
@@ -359,17 +363,22 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     }
     a.llr = reinterpret_cast<const int8_t *>(c.d_in + i0 * in_stride); a.llr_stride = (uint32_t)in_stride;
     a.out = reinterpret_cast<int8_t *>(c.d_out + i0 * out_stride); a.out_stride = (uint32_t)out_stride;
-    a.n_iter = c.d_iter + i0;
+    a.n_iter = d_iter + i0;
     if (launch_decoder(b->kernel, a, ce, n, s, b->n_blocks) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.h_out + i0 * out_stride, c.d_out + i0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c.h_iter + i0, c.d_iter + i0, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    if (n == b->n_blocks) {
+      HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, iter_off + sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    } else {
+      HIP_TRY(hipMemcpyAsync(c.h_out + i0 * out_stride, c.d_out + i0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * i0, c.d_out + iter_off + sizeof(int32_t) * i0,
+                             sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    }
   }
   HIP_TRY(hipStreamSynchronize(c.stream));
   if (b->n_blocks > chunk)
     HIP_TRY(hipStreamSynchronize(c.stream2));
   for (uint32_t i = 0; i < b->n_blocks; i++) {
-    const int32_t n = c.h_iter[i];
+    const int32_t n = h_iter[i];
     b->n_iter[i] = n;
     if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
       memcpy(b->out + (size_t)i * b->out_stride, c.h_out + i * out_stride, ob);
