@@ -56,11 +56,15 @@ __device__ __forceinline__ uint32_t tb_block_crc(const uint8_t *__restrict__ dat
  * bits m of v (bit m is followed by m more bits).  256 entries of LDS; the caller synchronises. */
 __device__ __forceinline__ void tb_build_crc_tab(const uint32_t *__restrict__ pow, uint32_t *tab)
 {
+  uint32_t p[8]; /* eight independent loads in flight: one memory latency for the whole table */
+#pragma unroll
+  for (int m = 0; m < 8; m++)
+    p[m] = pow[m];
   for (uint32_t v = threadIdx.x; v < 256; v += blockDim.x) {
     uint32_t x = 0;
+#pragma unroll
     for (int m = 0; m < 8; m++)
-      if (v & (1u << m))
-        x ^= pow[m];
+      x ^= p[m] & (0u - ((v >> m) & 1u));
     tab[v] = x;
   }
 }
@@ -305,7 +309,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   }
   if (j.C > 1 && ok) {
     __syncthreads(); /* the CRC below re-reads b */
-    const uint32_t x = tb_partial_crc<8>(b, j.B, first, count, pow, tab);
+    const uint32_t x = tb_partial_crc<32>(b, j.B, first, count, pow, tab);
     if ((threadIdx.x & 63) == 0 && x)
       atomicXor(&acc[sj.tb], x);
   }
