@@ -150,7 +150,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   }
   d->f_n_ctbl = n;
   const int nitems = d->ncore * zq;
-  int nb = 0, bcost[LDPC_F_MAX_CN_TASKS];
+  int nb = 0, bcost[LDPC_F_MAX_CN_TASKS] = {0};
   for (int b = 0; b < nitems; b += 64) {
     if (nb >= LDPC_F_MAX_BN_TASKS)
       return;
