@@ -58,6 +58,15 @@ int oracle_ldpc_decode(int BG, int Z, int R, int numMaxIter, int outMode, int us
 int oracle_ldpc_decode_mt(int nthreads, int nblocks, int BG, int Z, int R, int numMaxIter, const int8_t *llr,
                           int llr_stride, int8_t *out, int out_stride, int *iters);
 
+/* The same decoder restated for speed (oracle_ldpc_decoder_vec.c: two-minimum check node, lane-contiguous loops that
+ * gcc vectorises, AVX-512BW / AVX2 / baseline clones): identical outputs and pass counts, checked against
+ * oracle_ldpc_decode for every code in tests/test_oracle.py.  Used where the scalar restatement is too slow: the
+ * CPU baseline of bench.py and whole-batch GPU parity tests. */
+int oracle_ldpc_decode_vec(int BG, int Z, int R, int numMaxIter, int outMode, int use_crc, int E, int crc_type,
+                           const int8_t *p_llr, int8_t *p_out);
+int oracle_ldpc_decode_vec_mt(int nthreads, int nblocks, int BG, int Z, int R, int numMaxIter, const int8_t *llr,
+                              int llr_stride, int8_t *out, int out_stride, int *iters);
+
 /* ---- encoder: nrLDPC_encoder/ldpc_encoder.c:44-252 (code word), via H instead of the generator lists */
 /* in: K/8 bytes MSB-first (K = 22*Zc or 10*Zc); out: one bit per byte, (BG1 ? 66 : 50)*Zc bytes =
  * c[2Zc..K) followed by all parity bits.  Kb = number of information columns that enter the parity

@@ -50,6 +50,10 @@ def lib():
         L.oracle_ldpc_decode.restype = C.c_int
         L.oracle_ldpc_decode_mt.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_ldpc_decode_mt.restype = C.c_int
+        L.oracle_ldpc_decode_vec.argtypes = L.oracle_ldpc_decode.argtypes
+        L.oracle_ldpc_decode_vec.restype = C.c_int
+        L.oracle_ldpc_decode_vec_mt.argtypes = L.oracle_ldpc_decode_mt.argtypes
+        L.oracle_ldpc_decode_vec_mt.restype = C.c_int
         L.oracle_ldpc_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_ldpc_encode.restype = C.c_int
         L.oracle_ldpc_syndrome_weight.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -99,23 +103,26 @@ def out_bytes(BG, Z, R, out_mode):
     return ((n + 31) // 32) * 4 if out_mode == OUT_BIT else n
 
 
-def decode(BG, Z, R, llr, max_iter=8, out_mode=OUT_BIT, use_crc=False, E=0, crc_type=CRC24_B, out_init=0):
-    """One code block. llr: int8[ncols*Z]. Returns (n_iter, out uint8[out_bytes])."""
+def decode(BG, Z, R, llr, max_iter=8, out_mode=OUT_BIT, use_crc=False, E=0, crc_type=CRC24_B, out_init=0, vec=False):
+    """One code block. llr: int8[ncols*Z]. Returns (n_iter, out uint8[out_bytes]).  vec: the vectorisable restatement
+    (oracle_ldpc_decoder_vec.c) instead of the scalar one."""
     llr = np.ascontiguousarray(llr, dtype=np.int8)
     assert llr.size >= NCOLS[(BG, R)] * Z
     out = np.full(max(out_bytes(BG, Z, R, OUT_BIT), out_bytes(BG, Z, R, OUT_BITINT8)), out_init, dtype=np.uint8)
-    n = lib().oracle_ldpc_decode(BG, Z, R, max_iter, out_mode, int(use_crc), E, crc_type, _p(llr), _p(out))
+    f = lib().oracle_ldpc_decode_vec if vec else lib().oracle_ldpc_decode
+    n = f(BG, Z, R, max_iter, out_mode, int(use_crc), E, crc_type, _p(llr), _p(out))
     return n, out[:out_bytes(BG, Z, R, out_mode)]
 
 
-def decode_mt(nthreads, BG, Z, R, llr, max_iter=8):
+def decode_mt(nthreads, BG, Z, R, llr, max_iter=8, vec=False):
     """Many blocks on `nthreads` pthreads (PC stop, packed bits). llr: int8[n, >= ncols*Z]. Returns (n_iter, out)."""
     llr = np.ascontiguousarray(llr, dtype=np.int8)
     n = llr.shape[0]
     ob = out_bytes(BG, Z, R, OUT_BIT)
     out = np.zeros((n, ob), dtype=np.uint8)
     it = np.zeros(n, dtype=np.int32)
-    rc = lib().oracle_ldpc_decode_mt(nthreads, n, BG, Z, R, max_iter, _p(llr), llr.shape[1], _p(out), ob, _p(it))
+    f = lib().oracle_ldpc_decode_vec_mt if vec else lib().oracle_ldpc_decode_mt
+    rc = f(nthreads, n, BG, Z, R, max_iter, _p(llr), llr.shape[1], _p(out), ob, _p(it))
     assert rc == 0
     return it, out
 

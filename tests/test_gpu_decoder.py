@@ -154,11 +154,15 @@ def test_full_size_batch_properties_device(hip):
         bits = np.unpackbits(out_h[i])[:26 * Z]
         cw = O.encode(BG, Z, np.packbits(bits[:K]))
         assert np.array_equal(cw[K - 2 * Z:K - 2 * Z + 4 * Z], bits[K:K + 4 * Z])
-    # bit-exact sample vs the oracle
+    # bit-exact vs the oracle: a sample against the scalar restatement, ALL 1024 blocks against the vectorisable one
+    # (itself checked against the scalar one for every code in tests/test_oracle.py)
     llr_h = llr.cpu().numpy()
     for i in list(range(0, n, 97)):
         n_ref, out_ref = O.decode(BG, Z, R, llr_h[i], 8)
         assert n_ref == it_h[i] and np.array_equal(out_ref, out_h[i]), i
+    import os
+    it_v, out_v = O.decode_mt(min(os.cpu_count() or 1, 32), BG, Z, R, llr_h, 8, vec=True)
+    assert np.array_equal(it_v, it_h) and np.array_equal(out_v, out_h)
     # the host-buffer entry point splits a large batch into chunks on two streams (pageable and page-locked callers
     # take different copy paths): same results as the device-resident call, for batch sizes around the chunk edges
     pinned = torch.empty(llr.shape, dtype=torch.int8, pin_memory=True)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import GOLDEN, kbits, load_survey_decoder_vectors, make_llr, random_info
+from common import ALL_RATES, GOLDEN, kbits, load_survey_decoder_vectors, make_llr, random_info
 
 
 def test_crc_known_answers():
@@ -89,6 +89,36 @@ def test_decoder_iteration_control():
     n, bits = O.decode(BG, Z, R, clean, 8, out_mode=O.OUT_BITINT8)
     assert not bits[14 * Z:].any()
     assert np.array_equal(bits, O.decode(BG, Z, R, clean, 8, out_mode=O.OUT_LLRINT8)[1])
+
+
+def test_vectorisable_restatement_equals_the_scalar_one():
+    """oracle_ldpc_decoder_vec.c (two-minimum check node, lane-contiguous loops; used for the CPU baseline and for
+    whole-batch GPU parity tests) against oracle_ldpc_decoder.c: same outputs and pass counts for every (BG, Zc, R),
+    clean / noisy / random / saturated inputs, every output mode, both stop modes, several iteration caps -- and on
+    the survey-stage vectors."""
+    rng = np.random.default_rng(77)
+    n = 0
+    for BG in (1, 2):
+        for Z in O.LIFT_SIZES:
+            for R in ALL_RATES[BG]:
+                K = kbits(BG, Z)
+                info = random_info(rng, BG, Z, with_crc24b=True)
+                for kind in (-1.0, 1.0, "rand", "sat"):
+                    llr = make_llr(rng, BG, Z, R, kind, info)
+                    for it, mode, crc in ((8, 0, False), (1, 1, False), (3, 2, False), (8, 0, True), (2, 0, True)):
+                        if crc and (K % 8 or K < 48):
+                            continue
+                        if Z > 64 and (it, mode) not in ((8, 0),):   # keep the scalar side's run time in check
+                            continue
+                        a = O.decode(BG, Z, R, llr, it, mode, crc, K, 1, out_init=0x3c)
+                        b = O.decode(BG, Z, R, llr, it, mode, crc, K, 1, out_init=0x3c, vec=True)
+                        assert a[0] == b[0] and np.array_equal(a[1], b[1]), (BG, Z, R, kind, it, mode, crc)
+                        n += 1
+    assert n > 2000
+    for v in load_survey_decoder_vectors():
+        it, out = O.decode(v["BG"], v["Z"], v["R"], v["llr"], v["numMaxIter"], v["outMode"], v["use_crc"], v["E"],
+                           v["crc_type"], out_init=0x55, vec=True)
+        assert it == v["n_iter"] and np.array_equal(out, v["out"]), v
 
 
 def test_survey_stage_vectors():
