@@ -255,7 +255,7 @@ def dlsch_encode(tb, payload):
     return np.concatenate(out)
 
 
-def ulsch_decode(tb, llr, harq_d, max_iter=8, rnd=0, llrLen=0):
+def ulsch_decode(tb, llr, harq_d, max_iter=8, rnd=0, llrLen=0, vec=False):
     """The reference's RX chain for one transport block (nr_ulsch_decoding.c:122-470 + nr_postDecode).
     llr: int16[G]; harq_d: list of C int16 arrays (soft buffers, updated in place).
     Returns (payload uint8[A/8], ack, per-segment pass counts, llrLen)."""
@@ -274,7 +274,7 @@ def ulsch_decode(tb, llr, harq_d, max_iter=8, rnd=0, llrLen=0):
         assert rc == 0
         harq_d[r][:] = d
         l = llr_prepack(d, BG, Z, K, F, NCOLS[(BG, R)])
-        n, out = decode(BG, Z, R, l, max_iter, OUT_BIT, True, len_with_crc(Cn, A), crc_type(Cn, A))
+        n, out = decode(BG, Z, R, l, max_iter, OUT_BIT, True, len_with_crc(Cn, A), crc_type(Cn, A), vec=vec)
         iters.append(n)
         nb = K // 8 - F // 8 - (3 if Cn > 1 else 0)
         if n <= max_iter:

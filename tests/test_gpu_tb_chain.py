@@ -146,6 +146,57 @@ def test_ulsch_decode_random_sweep(hip):
     assert n_ack >= 4
 
 
+def test_full_size_slot_64_transport_blocks(hip):
+    """BASELINE configs[3] and [4] at full size: 64 transport blocks of ~213 kbit (273 PRB, 64QAM, 26 segments each,
+    1664 code blocks) through the DL-SCH chain and back through the UL-SCH chain on device-resident buffers; EVERY
+    coded bit, payload byte, ACK, pass count, llrLen and soft-buffer value is compared with the oracle chain."""
+    import torch
+    m = hip.ldpc
+    rng = np.random.default_rng(64)
+    A = valid_tbs(213176, 1)
+    G = (12 * 13 - 6) * 273 * 6
+    n_tb = 64
+    tbs = [dict(A=A, G=G, BG=1, Qm=6, Nl=1, rv=0, tbslbrm=0, round=0) for _ in range(n_tb)]
+    po, co, ho, segs = m.tb_layout(tbs)
+    pay_h = np.zeros(int(po[-1]) + 16, np.uint8)
+    for i in range(n_tb):
+        pay_h[po[i]:po[i] + A // 8] = rng.integers(0, 256, A // 8, dtype=np.uint8)
+    payload = torch.from_numpy(pay_h).cuda()
+    coded = torch.zeros(int(co[-1]) + 16, dtype=torch.uint8, device="cuda")
+    m.dlsch_encode_device(tbs, payload, coded)
+    coded_h = coded.cpu().numpy()
+    refs = [O.dlsch_encode(tbs[i], pay_h[po[i]:po[i] + A // 8]) for i in range(n_tb)]
+    for i in range(n_tb):
+        assert np.array_equal(coded_h[co[i]:co[i] + G], refs[i]), i
+    # a channel where a few blocks need more than the minimum three passes and TB 7 is lost
+    llr_h = np.zeros(int(co[-1]) + 16, np.int16)
+    for i in range(n_tb):
+        sigma = 40.0 if i == 7 else 2.9
+        llr_h[co[i]:co[i] + G] = np.clip(np.round((1 - 2 * refs[i].astype(np.float64)) * 8 + sigma * rng.standard_normal(G)),
+                                         -200, 200).astype(np.int16)
+    llr = torch.from_numpy(llr_h).cuda()
+    harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
+    pay_out = torch.zeros_like(payload)
+    ack = torch.zeros(n_tb, dtype=torch.uint8, device="cuda")
+    itm = torch.zeros(n_tb, dtype=torch.int32, device="cuda")
+    m.ulsch_decode_device(tbs, llr, harq, pay_out, ack, itm)
+    torch.cuda.synchronize()
+    ack_h, itm_h, out_h, harq_h = ack.cpu().numpy(), itm.cpu().numpy(), pay_out.cpu().numpy(), harq.cpu().numpy()
+    stride = m.HARQ_STRIDE
+    n_ack = 0
+    for i in range(n_tb):
+        harq_ref = [np.zeros(stride, np.int16) for _ in range(segs[i])]
+        p_ref, ack_ref, its, state = O.ulsch_decode(tbs[i], llr_h[co[i]:co[i] + G], harq_ref, 8, 0, 0, vec=True)
+        assert bool(ack_h[i]) == ack_ref and itm_h[i] == max(its), (i, its, int(itm_h[i]))
+        assert tbs[i]["llrLen"] == state
+        if ack_ref:
+            n_ack += 1
+            assert np.array_equal(out_h[po[i]:po[i] + A // 8], p_ref) and np.array_equal(p_ref, pay_h[po[i]:po[i] + A // 8])
+        for r in range(segs[i]):
+            assert np.array_equal(harq_h[ho[i] + r * stride:ho[i] + (r + 1) * stride], harq_ref[r]), (i, r)
+    assert n_ack == n_tb - 1 and not ack_h[7] and itm_h[7] == 9
+
+
 def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
     rng = np.random.default_rng(3)
     tbs = make_tbs()
