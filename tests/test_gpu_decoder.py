@@ -185,6 +185,23 @@ def test_full_size_batch_properties_device(hip):
     assert int(out0[torch.from_numpy(ok0).cuda()][:, :K // 8].max()) == 0
 
 
+def test_config3_mixed_bg2_batch_every_block(hip):
+    """BASELINE configs[2] at full size: 256 blocks each of BG2 Zc=64 R=1/5, Zc=64 R=1/3, Zc=208 R=1/5, Zc=208 R=1/3
+    (short URLLC-style blocks), in the waterfall so that pass counts spread from 2 to 9: every block's bits and pass
+    count against the oracle, for both workgroup shapes of the fast kernel."""
+    import os
+    rng = np.random.default_rng(33)
+    for (BG, Z, R) in ((2, 64, 15), (2, 64, 13), (2, 208, 15), (2, 208, 13)):
+        n = 256
+        llr = np.stack([make_llr(rng, BG, Z, R, float(rng.choice([-3.0, -1.0, 0.0, 2.0])), random_info(rng, BG, Z))
+                        for _ in range(n)])
+        it_ref, out_ref = O.decode_mt(min(os.cpu_count() or 1, 32), BG, Z, R, llr, 8, vec=True)
+        assert len(set(it_ref.tolist())) >= 3, set(it_ref.tolist())
+        for kern in (3, 4):
+            it, out = hip.decode_batch_host(BG, Z, R, llr, numMaxIter=8, kernel=kern)
+            assert np.array_equal(it, it_ref) and np.array_equal(out, out_ref), (BG, Z, R, kern)
+
+
 def test_ldpctest_acceptance_and_seed_identical_bler(hip):
     """The reference CI's acceptance criterion for the library (`ldpctest -l{3872..8448} -s10 -n100` must print
     `BLER 0.000000`, cmake_targets/autotests/test_case_list.xml:68-94) on a subset, and -- on identical AWGN seeds --
