@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     rowtbl[i] = code->f_rowtbl[i];
   for (int i = tid; i < ncore; i += nt)
     coltbl[i] = code->f_coltbl[i];
-  if (tid < 4)
-    flags[tid] = 0;
+  if (tid < 8)
+    flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [4], [5] task queues of the two phases */
   /* APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
   for (int i = tid; i < ncore * zq; i += nt) {
     const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
@@ -84,15 +84,22 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const int crcE = job ? job->E : a.E;
   const uint32_t *crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   int n_iter = max_pass;
-  const int cn0 = code->f_cn_ptr[wave], cn1 = code->f_cn_ptr[wave + 1];
-  const int bn0 = code->f_bn_ptr[wave], bn1 = code->f_bn_ptr[wave + 1];
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks;
+  (void)wave;
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
-    for (int ti = cn0; ti < cn1; ti++) {
-      const int task = LDPC_UNIFORM(code->f_cn_list[ti]);
+    /* the phase's tasks are drawn from a queue (LDS counter), most expensive first, by whichever wave is free */
+    for (;;) {
+      int ti = 0;
+      if (lane == 0)
+        ti = atomicAdd(&flags[4], 1);
+      ti = LDPC_UNIFORM(ti);
+      if (ti >= n_cn_tasks)
+        break;
+      const int task = code->f_cn_order[ti];
       const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
       const int item = code->f_cn_task[task][2] + lane;
       const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
@@ -109,16 +116,24 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
 #endif
     if (__any(syn != 0) && lane == 0)
       flags[p & 1] = 1;
-    if (tid == 0)
+    if (tid == 0) {
       flags[2] = 0;
+      flags[5] = 0; /* nobody draws bit-node tasks now */
+    }
     __syncthreads();
     if (!a.use_crc && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;
       break;
     }
 #ifndef LDPC_ABLATE_BN
-    for (int ti = bn0; ti < bn1; ti++) {
-      const int task = LDPC_UNIFORM(code->f_bn_list[ti]);
+    for (;;) {
+      int ti = 0;
+      if (lane == 0)
+        ti = atomicAdd(&flags[5], 1);
+      ti = LDPC_UNIFORM(ti);
+      if (ti >= n_bn_tasks)
+        break;
+      const int task = code->f_bn_order[ti];
       const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
       const int maxdeg = code->f_bn_task[task][2];
       if (item < end) {
@@ -129,8 +144,10 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
       }
     }
 #endif
-    if (tid == 0)
+    if (tid == 0) {
       flags[(p + 1) & 1] = 0;
+      flags[4] = 0; /* nobody draws check-node tasks now */
+    }
     __syncthreads();
     if (a.use_crc && p >= 3) { /* see ldpc_decoder.hip for the CRC argument */
       uint32_t x = 0;
