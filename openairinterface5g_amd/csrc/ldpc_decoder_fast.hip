@@ -12,6 +12,15 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_core.h"
 
+/* next ticket of a task queue (wave-uniform) */
+__device__ __forceinline__ int ldpc_draw(int *counter, int lane)
+{
+  int t = 0;
+  if (lane == 0)
+    t = atomicAdd(counter, 1);
+  return LDPC_UNIFORM(t);
+}
+
 template <int MAX_THREADS>
 __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
@@ -86,20 +95,35 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   int n_iter = max_pass;
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks;
   (void)wave;
+#ifdef LDPC_TIMING /* diagnostic build (tools/task_timing.sh): block 0 dumps, for pass 2, {start, end, degree} of every task
+                      each wave ran into its output row instead of the decoded bits */
+  long long *dbg = reinterpret_cast<long long *>(a.out);
+  int dbg_n = 0;
+  const long long dbg_t0 = clock64();
+#define LDPC_TIMING_BEGIN const long long tt0 = clock64();
+#define LDPC_TIMING_END(phase, deg)                                                        \
+  if (blk == 0 && lane == 0 && p == 2 && dbg_n < 12) {                                     \
+    dbg[(wave * 12 + dbg_n) * 2] = ((tt0 - dbg_t0) << 20) | (long long)((phase) << 8 | (deg)); \
+    dbg[(wave * 12 + dbg_n) * 2 + 1] = clock64() - dbg_t0;                                 \
+    dbg_n++;                                                                               \
+  }
+#else
+#define LDPC_TIMING_BEGIN
+#define LDPC_TIMING_END(phase, deg)
+#endif
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
-    /* the phase's tasks are drawn from a queue (LDS counter), most expensive first, by whichever wave is free */
+    /* The phase's tasks are drawn in id order (= most expensive first, ldpc_graph.c) from a queue -- an LDS counter --
+     * by whichever wave is free: the SIMD issue arbiter favours a CU's older waves, so static equal shares leave the
+     * SIMDs with one or two live waves for the last third of a phase (tools/task_timing.py shows the timeline). */
     for (;;) {
-      int ti = 0;
-      if (lane == 0)
-        ti = atomicAdd(&flags[4], 1);
-      ti = LDPC_UNIFORM(ti);
-      if (ti >= n_cn_tasks)
+      const int task = ldpc_draw(&flags[4], lane);
+      if (task >= n_cn_tasks)
         break;
-      const int task = code->f_cn_order[ti];
+      LDPC_TIMING_BEGIN
       const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
       const int item = code->f_cn_task[task][2] + lane;
       const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
@@ -112,6 +136,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         syn |= m & mask;
       }
+      LDPC_TIMING_END(0, deg)
     }
 #endif
     if (__any(syn != 0) && lane == 0)
@@ -127,13 +152,10 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     }
 #ifndef LDPC_ABLATE_BN
     for (;;) {
-      int ti = 0;
-      if (lane == 0)
-        ti = atomicAdd(&flags[5], 1);
-      ti = LDPC_UNIFORM(ti);
-      if (ti >= n_bn_tasks)
+      const int task = ldpc_draw(&flags[5], lane);
+      if (task >= n_bn_tasks)
         break;
-      const int task = code->f_bn_order[ti];
+      LDPC_TIMING_BEGIN
       const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
       const int maxdeg = code->f_bn_task[task][2];
       if (item < end) {
@@ -142,6 +164,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
         const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
         ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
       }
+      LDPC_TIMING_END(1, maxdeg)
     }
 #endif
     if (tid == 0) {
@@ -169,6 +192,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   }
 
   /* ---- hard decision ------------------------------------------------------------------------------------- */
+#ifdef LDPC_TIMING
+  if (blk != 0)
+#endif
   if (!a.use_crc || n_iter >= 3) {
     if (a.out_mode == 0) {
       uint32_t *o = reinterpret_cast<uint32_t *>(a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride));

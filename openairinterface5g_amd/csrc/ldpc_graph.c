@@ -38,19 +38,6 @@ static int by_key_desc(const void *pa, const void *pb)
 
 static int align16(int x) { return (x + 15) & ~15; }
 
-/* task ids in descending cost order: the order in which the kernel's waves draw tasks from the phase's queue */
-static void cost_order(int n, const int *cost, int32_t *order)
-{
-  sort_item_t it[LDPC_F_MAX_CN_TASKS];
-  for (int i = 0; i < n; i++) {
-    it[i].key = cost[i];
-    it[i].id = i;
-  }
-  qsort(it, n, sizeof(it[0]), by_key_desc);
-  for (int i = 0; i < n; i++)
-    order[i] = it[i].id;
-}
-
 /* longest-processing-time-first assignment of `n` tasks (cost[i]) to `nw` waves; fills ptr[nw+1], list[n] */
 static void lpt_assign(int n, const int *cost, int nw, int32_t *ptr, int32_t *list)
 {
@@ -232,8 +219,14 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   d->f_n_threads = waves * 64;
   lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
   lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
-  cost_order(nt, cost, d->f_cn_order);
-  cost_order(nb, bcost, d->f_bn_order);
+  /* the kernel's waves draw tasks 0, 1, 2, ... from a queue: task ids must already be in descending cost order
+   * (rows and columns are sorted by degree, so they are) */
+  for (int i = 1; i < nt; i++)
+    if (cost[i] > cost[i - 1])
+      return;
+  for (int i = 1; i < nb; i++)
+    if (bcost[i] > bcost[i - 1])
+      return;
   d->f_lds_r = 0;
   d->f_lds_app = align16(d->nedges * d->f_rstride);
   d->f_lds_ext = d->f_lds_app + align16(d->ncore * d->f_astride);
