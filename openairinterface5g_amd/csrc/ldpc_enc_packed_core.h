@@ -23,6 +23,9 @@
 
 #define LDPC_ENCP_SOLVE_PHASES 13
 #define LDPC_ENCP_NUM_PHASES 14
+/* workgroup size cap; measured per 1024 BG1 Zc=384 blocks: 512 -> 0.032 ms, 256 -> 0.024 ms, 128 -> 0.027 ms (more
+ * workgroups per CU overlap the latency chains of the short phases) */
+#define LDPC_ENCP_MAX_THREADS 256
 
 struct ldpc_encp_lds {
   uint32_t *B, *X, *LB, *LX, *ET, *RP;
@@ -54,7 +57,7 @@ LDPC_HD void ldpc_encp_carve(uint32_t *lds, ldpc_code_ptr_t code, ldpc_encp_lds 
 LDPC_ENCP_HOSTDEV int ldpc_encp_threads(int nrows, int Z)
 {
   int n = ((nrows - 4) * ldpc_encp_W(Z) + 63) & ~63;
-  return n < 64 ? 64 : (n > 512 ? 512 : n);
+  return n < 64 ? 64 : (n > LDPC_ENCP_MAX_THREADS ? LDPC_ENCP_MAX_THREADS : n);
 }
 
 /* 32 bits of the bit string s starting at bit offset o */
