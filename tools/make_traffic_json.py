@@ -13,10 +13,15 @@ def maxval(sub, counter):
                 vals.append(float(row["Counter_Value"]))
     return max(vals)   # the fixed-work launches (9 passes) are the largest
 fetch_kib, write_kib = maxval("pmc_fetch", "FETCH_SIZE"), maxval("pmc_write", "WRITE_SIZE")
+valu = maxval("pmc_sq1", "SQ_INSTS_VALU")
 out = {"ldpc_dec_bg1_z384_r13_b1024_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
        "fetch_size_kib_raw": fetch_kib, "fetch_bytes_corrected_x2": int(2 * fetch_kib * 1024),
        "write_size_kib": write_kib, "write_bytes": int(write_kib * 1024),
        "compulsory_bytes_per_launch": 1024 * (68 * 384 + 22 * 384 // 8),
+       "valu_wave_insts_per_launch": int(valu),
+       # issue time per VALU wave-instruction per SIMD from profiles/r01/valu_rate_ubench.txt: ~1.1 ns for the plain 32-bit
+       # ALU ops, ~1.8 ns for packed-16 / perm / alignbyte / min-max; the kernel's CN+BN loops are about half and half
+       "valu_avg_ns_per_wave_inst_per_simd": 1.45,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes on bench.py (1024 x BG1 Zc=384 R13, 9 passes)"}
 Path("profiles").mkdir(exist_ok=True)
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
