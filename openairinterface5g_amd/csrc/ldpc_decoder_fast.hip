@@ -46,6 +46,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
   int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+#ifdef LDPC_TIMING
+  const long long dbg_k0 = clock64(); /* kernel entry */
+#endif
   const int wave = LDPC_UNIFORM(tid >> 6);
   const uint32_t blk = blockIdx.x;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
@@ -56,6 +59,17 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const int ext_global = code->f_ext_global;
   L.gllr = reinterpret_cast<const uint8_t *>(src32);
   L.ext_global = ext_global;
+  /* The block's LLRs come from HBM: the first four dwords per thread of the core and of the extension columns are
+   * requested before anything else and consumed after the table copies and the message initialisation, so that their
+   * latency runs in the background (a 1024-thread workgroup needs 3 + 4 such loads per thread for Zc = 384). */
+  const int n_app = ncore * zq, n_ext = ext_global ? 0 : (code->ncols - ncore) * zq;
+  uint32_t va[4], ve[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ia = tid + k * nt;
+    va[k] = ia < n_app ? src32[ia] : 0u;
+    ve[k] = ia < n_ext ? src32[n_app + ia] : 0u;
+  }
   for (int i = tid; i < nedges; i += nt)
     etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
   for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
@@ -68,24 +82,36 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     coltbl[i] = code->f_coltbl[i];
   if (tid < 8)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [4], [5] task queues of the two phases */
+  {
+    const int nr4 = (nedges * rstride) >> 2;
+    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
+    for (int i = tid; i < nr4; i += nt)
+      r32[i] = 0x80808080u;
+  }
   /* APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
-  for (int i = tid; i < ncore * zq; i += nt) {
+  uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = tid + k * nt;
+    if (i < n_app) {
+      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+      const uint32_t w = va[k] ^ 0x80808080u;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
+      dst[0] = w;
+      dst[zq] = w;
+    }
+    if (i < n_ext)
+      e32[i] = ve[k] ^ 0x80808080u;
+  }
+  for (int i = tid + 4 * nt; i < n_app; i += nt) { /* small workgroups: the rest */
     const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
     const uint32_t w = src32[i] ^ 0x80808080u;
     uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
     dst[0] = w;
     dst[zq] = w;
   }
-  {
-    const int next4 = ext_global ? 0 : (code->ncols - ncore) * zq;
-    uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
-    for (int i = tid; i < next4; i += nt)
-      e32[i] = src32[ncore * zq + i] ^ 0x80808080u;
-    const int nr4 = (nedges * rstride) >> 2;
-    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
-    for (int i = tid; i < nr4; i += nt)
-      r32[i] = 0x80808080u;
-  }
+  for (int i = tid + 4 * nt; i < n_ext; i += nt)
+    e32[i] = src32[n_app + i] ^ 0x80808080u;
   __syncthreads();
 
   /* ---- passes ------------------------------------------------------------------------------------------ */
@@ -191,6 +217,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     }
   }
 
+#ifdef LDPC_TIMING
+  const long long dbg_t1 = clock64();
+#endif
   /* ---- hard decision ------------------------------------------------------------------------------------- */
 #ifdef LDPC_TIMING
   if (blk != 0)
@@ -221,6 +250,14 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   }
   if (tid == 0)
     a.n_iter[job ? (uint32_t)job->iter_idx : blk] = n_iter;
+#ifdef LDPC_TIMING
+  if (tid == 0 && (blk == 0 || blk == 1000)) { /* phases of one block: prologue, passes (incl. this stamp), whole kernel */
+    long long *d2 = reinterpret_cast<long long *>(a.out + (size_t)blk * a.out_stride) + (blk == 0 ? 16 * 12 * 2 : 0);
+    d2[0] = dbg_t0 - dbg_k0;
+    d2[1] = dbg_t1 - dbg_t0;
+    d2[2] = clock64() - dbg_k0;
+  }
+#endif
 }
 
 hipError_t ldpc_fast_kernel_init(void)

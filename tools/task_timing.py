@@ -37,6 +37,12 @@ for w in range(16):
             es = [e for p_, _, _, e in row if p_ == ph]
             if es:
                 ends[ph].append(max(es) - first)
+d0 = out[0].cpu().numpy().view(np.int64)[16 * 12 * 2:16 * 12 * 2 + 3]
+d1 = out[1000].cpu().numpy().view(np.int64)[:3] if n > 1000 else None
+for name, v in (("block 0 (first round)", d0), ("block 1000 (last round)", d1)):
+    if v is not None:
+        print("%s: prologue %d clocks, %d passes %d clocks, whole kernel %d clocks -> prologue+epilogue = %.1f %%" % (
+            name, v[0], int(it[0]), v[1], v[2], 100.0 * (v[2] - v[1]) / v[2]))
 for ph, name in ((0, "CN"), (1, "BN")):
     if ends[ph]:
         print(name, "phase: waves finish between", min(ends[ph]), "and", max(ends[ph]), "clocks after the pass started")
