@@ -36,7 +36,37 @@ struct PinBuf { /* growable pinned host buffer */
   }
 };
 
+/* What a call derives from its descriptor array alone (job lists on the device, launch shapes, buffer extents): kept
+ * per thread and per direction, reused as long as the next call's descriptors are byte-identical -- a scheduler that
+ * repeats an allocation slot after slot then skips the parameter arithmetic and the job upload. */
+struct TbPlan {
+  std::vector<uint8_t> key;
+  DevBuf jobs_d;
+  bool valid = false;
+  size_t n_seg = 0, n_aux = 0, scratch_top = 0, payload_end = 0, coded_end = 0, harq_end = 0;
+  size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int threads[2] = {64, 64}, lds[2] = {0, 0};
+  size_t n_fast = 0, n_gen = 0;
+  std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
+  bool matches(const nrLDPC_hip_tb_batch_t *b, uint32_t salt) const
+  {
+    const size_t n = (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t);
+    return valid && key.size() == n + 8 && memcmp(key.data(), &b->n_tb, 4) == 0 && memcmp(key.data() + 4, &salt, 4) == 0 &&
+           memcmp(key.data() + 8, b->tb, n) == 0;
+  }
+  void remember(const nrLDPC_hip_tb_batch_t *b, uint32_t salt)
+  {
+    const size_t n = (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t);
+    key.resize(n + 8);
+    memcpy(key.data(), &b->n_tb, 4);
+    memcpy(key.data() + 4, &salt, 4);
+    memcpy(key.data() + 8, b->tb, n);
+    valid = true;
+  }
+};
+
 struct TbCtx {
+  TbPlan tx, rx;
   DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small;
   PinBuf jobs_h, small_h;
   hipStream_t own = nullptr, last = nullptr;
@@ -87,10 +117,10 @@ int tb_validate(const nrLDPC_hip_tb_t &t)
   return 0;
 }
 
-/* upload `n` bytes of jobs staged at c.jobs_h.p to c.jobs_d.p */
-int tb_upload_jobs(TbCtx &c, size_t n, hipStream_t s)
+/* upload `n` bytes of jobs staged at c.jobs_h.p to `dst` */
+int tb_upload_jobs(TbCtx &c, uint8_t *dst, size_t n, hipStream_t s)
 {
-  HIP_TRY(hipMemcpyAsync(c.jobs_d.p, c.jobs_h.p, n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dst, c.jobs_h.p, n, hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(c.uploaded, s));
   c.pending = true;
   c.last = s;
@@ -126,13 +156,16 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   if (b->n_tb == 0)
     return 0;
   TbCtx &c = tls_tb;
+  TbPlan &pl = c.tx;
+  const bool fused = ldpc_enc_is_packed() != 0;
+  if (!pl.matches(b, fused ? 1u : 0u)) {
+  pl.valid = false;
   std::vector<tb_tx_tb_job> tbj(b->n_tb);
   std::vector<tb_tx_seg_job> sj;
   std::vector<ldpc_enc_job> ej;
   std::vector<tb_crc_chunk_job> cj;
   Arena ar;
   int enc_threads = 64, enc_lds = 0;
-  const bool fused = ldpc_enc_is_packed() != 0;
   size_t payload_end = 0, coded_end = 0;
   for (uint32_t i = 0; i < b->n_tb; i++) {
     const nrLDPC_hip_tb_t &t = b->tb[i];
@@ -190,15 +223,24 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
                o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
                o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
                jobs_bytes = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16), o_acc = jobs_bytes;
-  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      c.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+  if (c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
   memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
   memcpy(c.jobs_h.p + o_enc, ej.data(), n_seg * sizeof(ldpc_enc_job));
-  if (tb_upload_jobs(c, jobs_bytes, s) != 0)
+  if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
     return -1;
+  pl.n_seg = n_seg; pl.n_aux = cj.size(); pl.scratch_top = ar.top; pl.payload_end = payload_end; pl.coded_end = coded_end;
+  pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_enc; pl.off[3] = o_chk; pl.off[4] = o_acc;
+  pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
+  pl.remember(b, fused ? 1u : 0u);
+  }
+  if (c.scratch.ensure(pl.scratch_top) != 0)
+    return -1;
+  const size_t n_seg = pl.n_seg, payload_end = pl.payload_end, coded_end = pl.coded_end;
+  const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_enc = pl.off[2], o_chk = pl.off[3], o_acc = pl.off[4];
+  const int enc_threads = pl.threads[0], enc_lds = pl.lds[0];
   const uint8_t *payload = b->payload;
   uint8_t *coded = static_cast<uint8_t *>(b->coded);
   if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
@@ -208,13 +250,13 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
     payload = c.io_payload.p;
     coded = c.io_coded.p;
   }
-  const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(c.jobs_d.p + o_tb);
-  const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(c.jobs_d.p + o_seg);
-  uint32_t *d_acc = reinterpret_cast<uint32_t *>(c.jobs_d.p + o_acc);
+  const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(pl.jobs_d.p + o_tb);
+  const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(pl.jobs_d.p + o_seg);
+  uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
   HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
-  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(c.jobs_d.p + o_chk), (uint32_t)cj.size(),
+  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
                            payload, c.scratch.p, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
-  const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(c.jobs_d.p + o_enc);
+  const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(pl.jobs_d.p + o_enc);
   if (fused) {
     HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, enc_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
                                g.crc_pow[NR_HIP_CRC24_B], s));
@@ -245,6 +287,13 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   if (b->n_tb == 0)
     return 0;
   TbCtx &c = tls_tb;
+  TbPlan &pl = c.rx;
+  if (pl.matches(b, (uint32_t)b->harq_stride)) {
+    for (uint32_t i = 0; i < b->n_tb; i++) /* nr_get_R_ldpc_decoder's state leaves the call as it did the first time */
+      b->tb[i].llrLen = pl.llr_len[i];
+  } else {
+  pl.valid = false;
+  std::vector<uint8_t> key_tb((const uint8_t *)b->tb, (const uint8_t *)b->tb + (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t));
   std::vector<tb_rx_tb_job> tbj(b->n_tb);
   std::vector<tb_rx_seg_job> sj;
   std::vector<ldpc_dec_job> fast_jobs, gen_jobs;
@@ -344,16 +393,37 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
                o_iter = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16),
                jobs_bytes = o_iter, /* n_iter and the CRC accumulators live behind the jobs in the same device buffer */
                o_acc = o_iter + align_up(n_seg * sizeof(int32_t), 16);
-  if (c.scratch.ensure(ar.top) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      c.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+  if (c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
   memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
   memcpy(c.jobs_h.p + o_gen, gen_jobs.data(), gen_jobs.size() * sizeof(ldpc_dec_job));
-  if (tb_upload_jobs(c, jobs_bytes, s) != 0)
+  if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
     return -1;
-  int32_t *d_iter = reinterpret_cast<int32_t *>(c.jobs_d.p + o_iter);
+  pl.n_seg = n_seg; pl.scratch_top = ar.top; pl.payload_end = payload_end; pl.coded_end = llr_end; pl.harq_end = harq_end;
+  pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
+  pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
+  pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
+  pl.llr_len.resize(b->n_tb);
+  for (uint32_t i = 0; i < b->n_tb; i++)
+    pl.llr_len[i] = b->tb[i].llrLen;
+  /* the key is the descriptor array as it ARRIVED (llrLen is updated by the loop above) */
+  pl.key.resize(key_tb.size() + 8);
+  {
+    const uint32_t salt = (uint32_t)b->harq_stride;
+    memcpy(pl.key.data(), &b->n_tb, 4);
+    memcpy(pl.key.data() + 4, &salt, 4);
+    memcpy(pl.key.data() + 8, key_tb.data(), key_tb.size());
+    pl.valid = true;
+  }
+  }
+  if (c.scratch.ensure(pl.scratch_top) != 0)
+    return -1;
+  const size_t n_seg = pl.n_seg, payload_end = pl.payload_end, llr_end = pl.coded_end, harq_end = pl.harq_end;
+  const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_fast = pl.off[2], o_gen = pl.off[3], o_iter = pl.off[4], o_acc = pl.off[5];
+  const int fast_threads = pl.threads[0], fast_lds = pl.lds[0], gen_threads = pl.threads[1], gen_lds = pl.lds[1];
+  int32_t *d_iter = reinterpret_cast<int32_t *>(pl.jobs_d.p + o_iter);
   uint8_t *payload = b->payload;
   const int16_t *llr = static_cast<const int16_t *>(b->coded);
   int16_t *harq = b->harq;
@@ -372,7 +442,7 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
     iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
     ack = c.io_small.p + (size_t)b->n_tb * 4;
   }
-  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(c.jobs_d.p + o_seg), (uint32_t)n_seg, llr, harq,
+  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, llr, harq,
                                reinterpret_cast<int8_t *>(c.scratch.p), s));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));
@@ -384,18 +454,18 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   for (int k = 0; k < 4; k++)
     da.crc_pow_tbl[k] = g.crc_pow[k];
   da.crc_pow_tbl[NR_HIP_CRC24_A] = g.crc_pow_24a_long;
-  if (!fast_jobs.empty()) {
-    da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_fast);
-    HIP_TRY(ldpc_launch_dec_fast_jobs(da, fast_threads, fast_lds, (uint32_t)fast_jobs.size(), s));
+  if (pl.n_fast) {
+    da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_fast);
+    HIP_TRY(ldpc_launch_dec_fast_jobs(da, fast_threads, fast_lds, (uint32_t)pl.n_fast, s));
   }
-  if (!gen_jobs.empty()) {
-    da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_gen);
-    HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)gen_jobs.size(), s));
+  if (pl.n_gen) {
+    da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_gen);
+    HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)pl.n_gen, s));
   }
-  uint32_t *d_acc = reinterpret_cast<uint32_t *>(c.jobs_d.p + o_acc);
+  uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
   HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
-  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(c.jobs_d.p + o_tb), b->n_tb,
-                                reinterpret_cast<const tb_rx_seg_job *>(c.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
+  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), b->n_tb,
+                                reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
                                 c.scratch.p, payload, ack, iter_max, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
   if (host) {
     HIP_TRY(hipMemcpyAsync(b->payload, payload, payload_end, hipMemcpyDeviceToHost, s));

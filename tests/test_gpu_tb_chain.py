@@ -197,6 +197,37 @@ def test_full_size_slot_64_transport_blocks(hip):
     assert n_ack == n_tb - 1 and not ack_h[7] and itm_h[7] == 9
 
 
+def test_repeated_descriptors_reuse_the_plan(hip):
+    """The library keeps the job lists of the last call and reuses them when the descriptors repeat (a scheduler that
+    keeps an allocation): calls 2..4 with the same descriptors but new data must still match the oracle chain."""
+    rng = np.random.default_rng(11)
+    tbs = make_tbs()[:6]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    for call in range(4):
+        pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+        tx = [dict(t) for t in tbs]                                  # identical descriptors every call
+        coded = hip.ldpc.dlsch_encode_host(tx, pays)
+        refs = [O.dlsch_encode(t, p) for t, p in zip(tbs, pays)]
+        for f, ref in zip(coded, refs):
+            assert np.array_equal(f, ref), call
+        llrs = [np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + 4.0 * rng.standard_normal(f.size)), -200, 200).astype(np.int16)
+                for f in refs]
+        rx = [dict(t, round=0, llrLen=0) for t in tbs]               # identical on arrival every call
+        harq_gpu = np.zeros((sum(segs), stride), np.int16)
+        out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq_gpu, numMaxIter=8)
+        row = 0
+        for i, t in enumerate(tbs):
+            harq_ref = [np.zeros(stride, np.int16) for _ in range(segs[i])]
+            p_ref, ack_ref, its, state = O.ulsch_decode(dict(t), llrs[i], harq_ref, 8, 0, 0, vec=True)
+            assert bool(ack[i]) == ack_ref and itm[i] == max(its) and rx[i]["llrLen"] == state, (call, i)
+            if ack_ref:
+                assert np.array_equal(out[i], p_ref), (call, i)
+            for r in range(segs[i]):
+                assert np.array_equal(harq_gpu[row + r], harq_ref[r]), (call, i, r)
+            row += segs[i]
+
+
 def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
     rng = np.random.default_rng(3)
     tbs = make_tbs()
