@@ -45,8 +45,9 @@ int nr_hip_segmentation(uint32_t B, int BG, nr_hip_seg_t *s)
   s->Zc = Zc;
   s->K = BG == 1 ? Zc * 22 : Zc * 10; /* :137-140 */
   s->F = s->K - s->Kprime;
-  /* the reference copies whole bytes ((Kprime - L) >> 3, Kprime >> 3 .. K >> 3): anything else is outside its contract */
-  if (((s->Kprime - s->L) & 7) || (s->F & 7))
+  /* the reference copies whole payload bytes ((Kprime - L) >> 3): a segment payload that is not byte aligned is outside
+   * its contract.  K and F themselves need not be multiples of 8 (TBS 24: Zc = 7, K = 70, F = 30). */
+  if ((s->Kprime - s->L) & 7)
     return -1;
   return 0;
 }

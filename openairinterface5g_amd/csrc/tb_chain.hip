@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_segment_kernel(const tb_tx_s
 {
   __shared__ uint32_t red[2];
   const tb_tx_seg_job j = jobs[blockIdx.x];
-  const uint32_t segbytes = (j.Kprime - j.L) >> 3, kbytes = j.K >> 3;
+  const uint32_t segbytes = (j.Kprime - j.L) >> 3, kbytes = (j.K + 7) >> 3;
   const uint8_t *src = scratch + j.b_off + (size_t)j.r * segbytes;
   uint8_t *c = scratch + j.c_off;
   for (uint32_t q = threadIdx.x; q < segbytes; q += blockDim.x)

@@ -160,7 +160,10 @@ def segmentation(tb_bytes, B, BG):
     res = dict(C=Cn.value, K=K.value, Z=Z.value, F=F.value, Kb=kb, segs=[])
     if tb_bytes is not None and kb > 0:
         tb = np.ascontiguousarray(tb_bytes, dtype=np.uint8)
-        segs = [np.full(K.value // 8 + 4, 0xAA, dtype=np.uint8) for _ in range(Cn.value)]
+        # 0xAA where nr_segmentation must write every byte; zeros behind K>>3, like the reference's calloc'ed harq->c[r]:
+        # when K is not a multiple of 8 (Zc = 15: K = 330) the reference never touches the last partial byte, so the
+        # filler bits in it are whatever the buffer held -- zero on first use, which is the case modelled here
+        segs = [np.concatenate([np.full(K.value // 8, 0xAA, np.uint8), np.zeros(4, np.uint8)]) for _ in range(Cn.value)]
         ptrs = (C.c_void_p * Cn.value)(*[s.ctypes.data for s in segs])
         lib().oracle_nr_segmentation(_p(tb), ptrs, B, C.byref(Cn), C.byref(K), C.byref(Z), C.byref(F), BG)
         res["segs"] = [s[:K.value // 8] for s in segs]

@@ -228,6 +228,95 @@ def test_repeated_descriptors_reuse_the_plan(hip):
             row += segs[i]
 
 
+def test_every_small_tbs_of_38214(hip):
+    """All 93 transport block sizes of 38.214 Table 5.1.3.2-1 (TBS <= 3824, the CRC16 / single-segment regime where
+    Kb, Zc and the filler count change from entry to entry), base graph by the 38.212 7.2.2 rule for two code rates:
+    the coded bits of the whole heterogeneous batch equal the oracle chain's."""
+    tbs_table = [24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 208, 224,
+                 240, 256, 272, 288, 304, 320, 336, 352, 368, 384, 408, 432, 456, 480, 504, 528, 552, 576, 608, 640, 672, 704,
+                 736, 768, 808, 848, 888, 928, 984, 1032, 1064, 1128, 1160, 1192, 1224, 1256, 1288, 1320, 1352, 1416, 1480,
+                 1544, 1608, 1672, 1736, 1800, 1864, 1928, 2024, 2088, 2152, 2216, 2280, 2408, 2472, 2536, 2600, 2664, 2728,
+                 2792, 2856, 2976, 3104, 3240, 3368, 3496, 3624, 3752, 3824]
+    assert len(tbs_table) == 93
+    rng = np.random.default_rng(38214)
+    tbs = []
+    for A in tbs_table:
+        for rate in (0.3, 0.75):
+            BG = 2 if (A <= 292 or rate <= 0.25 or (A <= 3824 and rate <= 0.67)) else 1
+            Qm = int(rng.choice([2, 4, 6, 8]))
+            G = max(int(A / rate) // Qm, 4) * Qm
+            tbs.append(dict(A=A, G=G, BG=BG, Qm=Qm, Nl=1, rv=int(rng.integers(0, 4)), tbslbrm=0))
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+    for t, p, f in zip(tbs, pays, coded):
+        assert np.array_equal(f, O.dlsch_encode(t, p)), t
+    # and back: mild noise, one call for all 186 blocks; everything against the oracle chain
+    llrs = [np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + 2.5 * rng.standard_normal(f.size)), -200, 200).astype(np.int16)
+            for f in coded]
+    rx = [dict(t, round=0, llrLen=0) for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    harq_gpu = np.zeros((len(tbs), stride), np.int16)
+    out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq_gpu, numMaxIter=8)
+    n_good = 0
+    for i, t in enumerate(tbs):
+        harq_ref = [np.zeros(stride, np.int16)]
+        p_ref, ack_ref, its, state = O.ulsch_decode(dict(t), llrs[i], harq_ref, 8, 0, 0, vec=True)
+        assert bool(ack[i]) == ack_ref and itm[i] == max(its) and rx[i]["llrLen"] == state, (t, its, int(itm[i]))
+        if ack_ref:
+            assert np.array_equal(out[i], p_ref), t
+            n_good += int(np.array_equal(p_ref, pays[i]))
+        assert np.array_equal(harq_gpu[i], harq_ref[0]), t
+    assert n_good > 90
+
+
+def test_chain_calls_are_capturable_in_a_hip_graph(hip):
+    """With device-resident buffers and repeated descriptors the two chain calls only enqueue kernels and memsets:
+    capture them once in a HIP graph, replay with new payloads / LLRs, compare with the oracle chain."""
+    import torch
+    m = hip.ldpc
+    rng = np.random.default_rng(5)
+    tbs = [dict(t, round=0, llrLen=0) for t in make_tbs()[:5]]
+    po, co, ho, segs = m.tb_layout(tbs)
+    payload = torch.zeros(int(po[-1]) + 16, dtype=torch.uint8, device="cuda")
+    coded = torch.zeros(int(co[-1]) + 16, dtype=torch.uint8, device="cuda")
+    llr = torch.zeros(int(co[-1]) + 16, dtype=torch.int16, device="cuda")
+    harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
+    pay_out = torch.zeros_like(payload)
+    ack = torch.zeros(len(tbs), dtype=torch.uint8, device="cuda")
+    itm = torch.zeros(len(tbs), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        enc = m.PreparedTbBatch(tbs, payload, coded)
+        dec = m.PreparedTbBatch(tbs, pay_out, llr, harq, ack, itm)
+        for _ in range(2):                   # second call: the plans are cached, nothing is uploaded any more
+            enc.encode()
+            dec.decode()
+    torch.cuda.synchronize()
+    g_enc, g_dec = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_enc):
+        enc.encode()
+    with torch.cuda.graph(g_dec):
+        dec.decode()
+    for rep in range(2):
+        pay_h = np.zeros(payload.numel(), np.uint8)
+        for i, t in enumerate(tbs):
+            pay_h[po[i]:po[i] + t["A"] // 8] = rng.integers(0, 256, t["A"] // 8, dtype=np.uint8)
+        payload.copy_(torch.from_numpy(pay_h))
+        g_enc.replay()
+        torch.cuda.synchronize()
+        coded_h = coded.cpu().numpy()
+        for i, t in enumerate(tbs):
+            assert np.array_equal(coded_h[co[i]:co[i] + t["G"]], O.dlsch_encode(t, pay_h[po[i]:po[i] + t["A"] // 8])), (rep, i)
+        llr.copy_(((1 - 2 * coded.to(torch.int16)) * 20).to(torch.int16))
+        harq.zero_()
+        g_dec.replay()
+        torch.cuda.synchronize()
+        out_h = pay_out.cpu().numpy()
+        assert ack.cpu().numpy().all()
+        for i, t in enumerate(tbs):
+            assert np.array_equal(out_h[po[i]:po[i] + t["A"] // 8], pay_h[po[i]:po[i] + t["A"] // 8]), (rep, i)
+
+
 def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
     rng = np.random.default_rng(3)
     tbs = make_tbs()
