@@ -98,10 +98,19 @@ int tb_begin(const nrLDPC_hip_tb_batch_t *b, hipStream_t &s)
     HIP_TRY(hipEventCreateWithFlags(&c.uploaded, hipEventDisableTiming));
   }
   s = b->mem == NRLDPC_HIP_MEM_DEVICE ? static_cast<hipStream_t>(b->stream) : c.own;
-  if (c.pending) { /* the previous call's job upload must have left the pinned staging buffer */
+  if (c.last && c.last != s) { /* scratch is reused: calls on different streams are serialised */
+    HIP_TRY(hipStreamSynchronize(c.last));
+  }
+  c.last = s;
+  return 0;
+}
+
+/* before the pinned job staging buffer is rewritten: the previous upload must have left it.  (Calls that reuse a cached
+ * plan upload nothing and never get here, which keeps them free of host synchronisation -- capturable in a HIP graph.) */
+int tb_wait_upload(TbCtx &c)
+{
+  if (c.pending) {
     HIP_TRY(hipEventSynchronize(c.uploaded));
-    if (c.last != s)
-      HIP_TRY(hipStreamSynchronize(c.last)); /* scratch is reused: calls on different streams are serialised */
     c.pending = false;
   }
   return 0;
@@ -123,7 +132,6 @@ int tb_upload_jobs(TbCtx &c, uint8_t *dst, size_t n, hipStream_t s)
   HIP_TRY(hipMemcpyAsync(dst, c.jobs_h.p, n, hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(c.uploaded, s));
   c.pending = true;
-  c.last = s;
   return 0;
 }
 
@@ -223,7 +231,8 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
                o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
                o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
                jobs_bytes = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16), o_acc = jobs_bytes;
-  if (c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
+      pl.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
   memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
@@ -393,7 +402,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
                o_iter = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16),
                jobs_bytes = o_iter, /* n_iter and the CRC accumulators live behind the jobs in the same device buffer */
                o_acc = o_iter + align_up(n_seg * sizeof(int32_t), 16);
-  if (c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
+      pl.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
     return -1;
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));

@@ -400,6 +400,9 @@ class PreparedTbBatch:
     def decode(self):
         _check(self._lib.nrLDPC_hip_ulsch_decode(C.byref(self.batch)), "nrLDPC_hip_ulsch_decode")
 
+    # HIP graphs: capture on the batch's own stream (torch.cuda.graph(g, stream=<the stream the batch was made on>)) after
+    # two warm-up calls there; a call whose descriptors repeat only enqueues kernels and memsets.
+
 
 def ulsch_decode_device(tbs, llr, harq, payload, ack, iter_max, numMaxIter=8, stream=None):
     """llr: torch int16 [>= co[-1]], harq: torch int16 [>= ho[-1]], payload: torch uint8 [>= po[-1]] (out),

@@ -288,14 +288,14 @@ def test_chain_calls_are_capturable_in_a_hip_graph(hip):
     with torch.cuda.stream(side):
         enc = m.PreparedTbBatch(tbs, payload, coded)
         dec = m.PreparedTbBatch(tbs, pay_out, llr, harq, ack, itm)
-        for _ in range(2):                   # second call: the plans are cached, nothing is uploaded any more
+        for _ in range(3):                   # from the third call on both plans are cached: nothing is uploaded any more
             enc.encode()
             dec.decode()
     torch.cuda.synchronize()
     g_enc, g_dec = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g_enc):
+    with torch.cuda.graph(g_enc, stream=side):
         enc.encode()
-    with torch.cuda.graph(g_dec):
+    with torch.cuda.graph(g_dec, stream=side):
         dec.decode()
     for rep in range(2):
         pay_h = np.zeros(payload.numel(), np.uint8)
