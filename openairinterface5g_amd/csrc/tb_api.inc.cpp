@@ -230,10 +230,11 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_tx_tb_job), 16),
                o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
                o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
-               jobs_bytes = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16), o_acc = jobs_bytes;
-  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      pl.jobs_d.ensure(jobs_bytes + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+               o_acc = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16),
+               jobs_bytes = o_acc + align_up((size_t)b->n_tb * sizeof(uint32_t), 16); /* CRC accumulators: uploaded as zeros */
+  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes) != 0)
     return -1;
+  memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
   memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
@@ -262,7 +263,6 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
   const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(pl.jobs_d.p + o_tb);
   const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(pl.jobs_d.p + o_seg);
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
-  HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
   HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
                            payload, c.scratch.p, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
   const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(pl.jobs_d.p + o_enc);
@@ -399,12 +399,13 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
                o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
                o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
-               o_iter = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16),
-               jobs_bytes = o_iter, /* n_iter and the CRC accumulators live behind the jobs in the same device buffer */
-               o_acc = o_iter + align_up(n_seg * sizeof(int32_t), 16);
+               o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators: uploaded as zeros */
+               jobs_bytes = o_acc + align_up((size_t)b->n_tb * sizeof(uint32_t), 16),
+               o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
   if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      pl.jobs_d.ensure(o_acc + (size_t)b->n_tb * sizeof(uint32_t)) != 0)
+      pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
     return -1;
+  memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
   memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
   memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
   memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
@@ -473,7 +474,6 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
     HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)pl.n_gen, s));
   }
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
-  HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)b->n_tb * sizeof(uint32_t), s));
   HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), b->n_tb,
                                 reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
                                 c.scratch.p, payload, ack, iter_max, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));

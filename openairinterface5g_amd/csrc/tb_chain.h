@@ -52,7 +52,8 @@ struct tb_rx_tb_job {
   uint32_t pad;
 };
 
-/* TB CRC attach in two steps: per-chunk partial CRCs XOR-ed into acc[tb] (zeroed by the caller), then the CRC bytes */
+/* TB CRC attach in two steps: per-chunk partial CRCs XOR-ed into acc[tb], then the CRC bytes.  acc[] must be zero on
+ * entry and is zero again on exit (uploaded as zeros with the plan; no memset per call) */
 hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_crc_chunk_job *chunks, uint32_t n_chunks,
                             const uint8_t *payload, uint8_t *scratch, uint32_t *acc, const uint32_t *pow24a,
                             const uint32_t *pow16, hipStream_t s);
@@ -66,7 +67,7 @@ hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_j
                               const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s);
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
                                 hipStream_t s);
-/* reassembly per segment (payload copy + partial TB CRC into acc[tb], zeroed by the caller), then per-TB verdict */
+/* reassembly per segment (payload copy + partial TB CRC into acc[tb], zero on entry and on exit), then per-TB verdict */
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,
                                  uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);

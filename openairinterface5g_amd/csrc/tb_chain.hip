@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_
     atomicXor(&acc[ch.tb], x);
 }
 __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_final_kernel(const tb_tx_tb_job *jobs, uint32_t n_tb, uint8_t *scratch,
-                                                                     const uint32_t *acc)
+                                                                     uint32_t *acc)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tb)
@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_final_kernel(const tb_tx
   const tb_tx_tb_job j = jobs[i];
   uint8_t *b = scratch + j.b_off + (j.A >> 3);
   const uint32_t crc = acc[i];
+  acc[i] = 0; /* the accumulators are zero when a plan is uploaded and are left zero by every call that uses them */
   b[0] = (uint8_t)(crc >> 24);
   b[1] = (uint8_t)(crc >> 16);
   if (j.crc_type == 0)
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   }
 }
 __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_tb_job *jobs, uint32_t n_tb, const int32_t *n_iter,
-                                                                   const uint32_t *acc, uint8_t *ack, int32_t *iter_max)
+                                                                   uint32_t *acc, uint8_t *ack, int32_t *iter_max)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tb)
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_t
   }
   /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
   ack[i] = (uint8_t)(all_ok && (j.C == 1 || acc[i] == 0));
+  acc[i] = 0; /* left zero for the next call (see tb_tx_crc_final_kernel) */
   iter_max[i] = imax;
 }
 

@@ -312,7 +312,13 @@ def test_chain_calls_are_capturable_in_a_hip_graph(hip):
         g_dec.replay()
         torch.cuda.synchronize()
         out_h = pay_out.cpu().numpy()
-        assert ack.cpu().numpy().all()
+        if not ack.cpu().numpy().all():     # diagnostics: the same call issued eagerly
+            a_g, i_g = ack.cpu().numpy().copy(), itm.cpu().numpy().copy()
+            harq.zero_()
+            with torch.cuda.stream(side):
+                dec.decode()
+            torch.cuda.synchronize()
+            raise AssertionError(("graph", a_g, i_g, "eager", ack.cpu().numpy(), itm.cpu().numpy(), rep))
         for i, t in enumerate(tbs):
             assert np.array_equal(out_h[po[i]:po[i] + t["A"] // 8], pay_h[po[i]:po[i] + t["A"] // 8]), (rep, i)
 
