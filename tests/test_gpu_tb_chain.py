@@ -323,6 +323,40 @@ def test_chain_calls_are_capturable_in_a_hip_graph(hip):
             assert np.array_equal(out_h[po[i]:po[i] + t["A"] // 8], pay_h[po[i]:po[i] + t["A"] // 8]), (rep, i)
 
 
+def test_chain_calls_from_concurrent_threads(hip):
+    """Four host threads, each with its own batches, call both chain entry points at the same time (every calling thread
+    has its own stream, scratch and plan cache): all results equal the oracle chain's."""
+    import threading
+    all_tbs = make_tbs()
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(100 + k)
+            tbs = [dict(t) for t in all_tbs[k::4]]
+            for _ in range(3):
+                pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+                coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+                for t, p, f in zip(tbs, pays, coded):
+                    assert np.array_equal(f, O.dlsch_encode(t, p)), (k, t)
+                rx = [dict(t, rv=0, tbslbrm=0, round=0, llrLen=0) for t in tbs]
+                coded0 = [O.dlsch_encode(t, p) for t, p in zip(rx, pays)]
+                llrs = [((1 - 2 * f.astype(np.int16)) * 20).astype(np.int16) for f in coded0]
+                segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in rx]
+                harq = np.zeros((sum(segs), hip.ldpc.HARQ_STRIDE), np.int16)
+                out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq)
+                assert ack.all() and all(np.array_equal(o, p) for o, p in zip(out, pays)), k
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
     rng = np.random.default_rng(3)
     tbs = make_tbs()
