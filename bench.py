@@ -206,7 +206,7 @@ def main():
                          "binding_resource": binding},
             "operating_point": op,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(llr_fixed[:256].cpu().numpy())
         print(json.dumps(line))
     if dist is not None:
