@@ -60,12 +60,23 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   const int crcE = job ? job->E : a.E;
   const uint32_t *crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   int n_iter = max_pass;
+  /* small lifting sizes: several rows / a run of column bits per 64-lane step (ldpc_graph.h `pack`) */
+  const int pack = code->pack;
+  const int sub = pack > 1 ? (lane * code->zinv16) >> 16 : 0, tl = lane - sub * Z;
   for (int p = 1; p <= max_pass; ++p) {
     /* check-node phase; its syndrome is that of pass p-1 */
     int par_acc = 0;
     const int ncn = code->n_cn_slots;
     for (int k = wave; k < ncn; k += nw) {
       const int ent = LDPC_UNIFORM(code->cn_order[k]);
+      if (pack > 1) {
+        if (sub < (ent >> 8)) {
+          const int row = code->cn_rows[(ent & 0xff) + sub];
+          const int par = ldpc_cn_row(code, row, tl, r, app, llr_s);
+          par_acc |= (tl < code->pc_lo[row]) ? par : 0;
+        }
+        continue;
+      }
       const int row = ent >> 4, t = ((ent & 15) << 6) + lane;
       if (t < Z) {
         const int par = ldpc_cn_row(code, row, t, r, app, llr_s);
@@ -85,6 +96,14 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
     /* bit-node phase */
     const int nbn = code->n_bn_slots;
     for (int k = wave; k < nbn; k += nw) {
+      if (pack > 1) {
+        const int i = 64 * k + lane;
+        if (i < ncz) {
+          const int ci = (i * code->zinv16) >> 16;
+          ldpc_bn_update(code, code->bn_cols[ci], i - ci * Z, r, app, llr_s);
+        }
+        continue;
+      }
       const int ent = LDPC_UNIFORM(code->bn_order[k]);
       const int c = ent >> 4, u = ((ent & 15) << 6) + lane;
       if (u < Z)

@@ -333,6 +333,40 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
 
   /* schedules (longest work first, then round-robin over the waves of the workgroup) */
   sort_item_t items[LDPC_MAX_ROWS * LDPC_MAX_ZW];
+  d->pack = Z <= 32 ? 64 / Z : 1;
+  d->zinv16 = (65536 + Z - 1) / Z;
+  if (d->pack > 1) {
+    for (int x = 0; x < d->ncore * Z + 64; x++) /* the reciprocal must be exact for every lane and bit index */
+      if (((x * d->zinv16) >> 16) != x / Z)
+        d->pack = 1;
+  }
+  if (d->pack > 1) {
+    /* rows by (core rows first, degree descending); packs of up to `pack` rows of one kind and degree */
+    for (int r = 0; r < d->nrows; r++) {
+      items[r].id = r;
+      items[r].key = (r < 4 ? 1000 : 0) + d->row_deg[r];
+    }
+    qsort(items, d->nrows, sizeof(items[0]), by_key_desc);
+    for (int r = 0; r < d->nrows; r++)
+      d->cn_rows[r] = items[r].id;
+    int np = 0;
+    for (int i = 0; i < d->nrows;) {
+      int j = i;
+      while (j < d->nrows && j - i < d->pack && items[j].key == items[i].key)
+        j++;
+      d->cn_order[np++] = i | ((j - i) << 8);
+      i = j;
+    }
+    d->n_cn_slots = np;
+    for (int c = 0; c < d->ncore; c++) {
+      items[c].id = c;
+      items[c].key = d->col_ptr[c + 1] - d->col_ptr[c];
+    }
+    qsort(items, d->ncore, sizeof(items[0]), by_key_desc);
+    for (int c = 0; c < d->ncore; c++)
+      d->bn_cols[c] = items[c].id;
+    d->n_bn_slots = (d->ncore * Z + 63) / 64;
+  } else {
   d->n_cn_slots = d->nrows * d->zw;
   for (int s = 0; s < d->n_cn_slots; s++) {
     items[s].id = s;
@@ -350,7 +384,7 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
   qsort(items, d->n_bn_slots, sizeof(items[0]), by_key_desc);
   for (int s = 0; s < d->n_bn_slots; s++)
     d->bn_order[s] = ((items[s].id / d->zw) << 4) | (items[s].id % d->zw);
-
+  }
 
   /* encoder core-parity solve order (only meaningful for the full-rate descriptors R13 / R15, but the
    * four core rows are present in every mode) */

@@ -39,6 +39,13 @@ typedef struct ldpc_code_desc {
   /* LDS carve-up (bytes, 16-aligned) used by the generic decoder kernel */
   int32_t lds_r, lds_app, lds_llr, lds_misc, lds_total;
   int32_t n_threads; /* workgroup size the generic decoder kernel is launched with for this code */
+  /* Small lifting sizes (Z <= 32): a 64-lane step of the generic kernel takes pack = 64 / Z lifted rows (of equal degree)
+   * resp. 64 consecutive bits of the degree-sorted core columns instead of one row / column, lane l -> (l / Z, l % Z).
+   * pack = 1: one (row | column, 64-lane chunk) per step.  zinv16 = ceil(2^16 / Z): (x * zinv16) >> 16 = x / Z for the
+   * indices that occur (checked on the host). */
+  int32_t pack, zinv16;
+  int32_t cn_rows[LDPC_MAX_ROWS + 2];  /* pack > 1: rows sorted by (core/extension, degree); cn_order[k] = first | count << 8 */
+  int32_t bn_cols[LDPC_MAX_CORE + 2];  /* pack > 1: core columns sorted by degree, descending; slot k = bits 64k .. 64k+63 */
 
   /* All tables are 32-bit so that wave-uniform lookups compile to scalar (s_load_dword) loads. */
   int32_t row_ptr[LDPC_MAX_ROWS + 2];

@@ -49,8 +49,17 @@ extern "C" int ldpc_emul_decode(int BG, int Z, int R, int numMaxIter, int outMod
     for (int tid = 0; tid < nt; tid++) {
       const int lane = tid & 63, wave = tid >> 6;
       int par_acc = 0;
+      const int pack = code->pack, sub = pack > 1 ? (lane * code->zinv16) >> 16 : 0, tl = lane - sub * Z;
       for (int k = wave; k < code->n_cn_slots; k += nw) {
         const int ent = code->cn_order[k];
+        if (pack > 1) {
+          if (sub < (ent >> 8)) {
+            const int row = code->cn_rows[(ent & 0xff) + sub];
+            const int par = ldpc_cn_row(code, row, tl, r, app, llr_s);
+            par_acc |= (tl < code->pc_lo[row]) ? par : 0;
+          }
+          continue;
+        }
         const int row = ent >> 4, t = ((ent & 15) << 6) + lane;
         if (t < Z) {
           const int par = ldpc_cn_row(code, row, t, r, app, llr_s);
@@ -68,6 +77,14 @@ extern "C" int ldpc_emul_decode(int BG, int Z, int R, int numMaxIter, int outMod
     for (int tid = 0; tid < nt; tid++) {
       const int lane = tid & 63, wave = tid >> 6;
       for (int k = wave; k < code->n_bn_slots; k += nw) {
+        if (code->pack > 1) {
+          const int i = 64 * k + lane;
+          if (i < ncz) {
+            const int ci = (i * code->zinv16) >> 16;
+            ldpc_bn_update(code, code->bn_cols[ci], i - ci * Z, r, app, llr_s);
+          }
+          continue;
+        }
         const int ent = code->bn_order[k];
         const int c = ent >> 4, u = ((ent & 15) << 6) + lane;
         if (u < Z)
