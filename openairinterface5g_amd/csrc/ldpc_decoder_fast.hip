@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
   const int crcE = job ? job->E : a.E;
   const uint32_t *crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   int n_iter = max_pass;
-  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks;
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
   (void)wave;
 #ifdef LDPC_TIMING /* diagnostic build (tools/task_timing.sh): block 0 dumps, for pass 2, {start, end, degree} of every task
                       each wave ran into its output row instead of the decoded bits */
@@ -178,19 +178,21 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     }
 #ifndef LDPC_ABLATE_BN
     for (;;) {
-      const int task = ldpc_draw(&flags[5], lane);
-      if (task >= n_bn_tasks)
+      const int ticket = ldpc_draw(&flags[5], lane);
+      if (ticket * bn_group >= n_bn_tasks)
         break;
-      LDPC_TIMING_BEGIN
-      const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
-      const int maxdeg = code->f_bn_task[task][2];
-      if (item < end) {
-        const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
-        const uint32_t colrec = coltbl[sc];
-        const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
-        ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+      for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
+        LDPC_TIMING_BEGIN
+        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+        const int maxdeg = code->f_bn_task[task][2];
+        if (item < end) {
+          const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
+          const uint32_t colrec = coltbl[sc];
+          const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
+          ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+        }
+        LDPC_TIMING_END(1, maxdeg)
       }
-      LDPC_TIMING_END(1, maxdeg)
     }
 #endif
     if (tid == 0) {

@@ -175,7 +175,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
                     align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(Z + 4) + 64;
   /* Workgroup shape.  A CU holds 16 waves of this kernel (<= 128 VGPRs), so the waves per workgroup w and the
    * workgroups per CU k are chosen together: maximise the resident waves k*w subject to k workgroups fitting in the
-   * 160 KiB of LDS (with or without the staged extension LLRs) and w <= tasks / 2; w a multiple of 4 so that the
+   * 160 KiB of LDS (with or without the staged extension LLRs) and w <= check-node tasks; w a multiple of 4 so that the
    * waves spread evenly over the four SIMDs.  Ties: more workgroups per CU (their barriers overlap), then LDS staging.
    * Measured on MI355X (profiles/r01/occupancy_sweep.txt): BG1 Zc=192 10 waves x 1 -> 8 x 2: 35 -> 48 Gb/s.
    * That is the THROUGHPUT shape (launches that fill the GPU more than once).  The LATENCY shape, for launches of at
@@ -190,7 +190,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
     int best_score = -1, best_k = 0;
     d->f_ext_global = 0;
     for (int w = LDPC_F_MAX_WAVES; w >= 1; w = (w > 4 ? w - 4 : w - 1)) {
-      if (w > 1 && 2 * w > nt)
+      if (w > nt)
         continue;
       for (int eg = 0; eg <= 1; eg++) {
         int k = lds_cu / (fixed + (eg ? 0 : ext_bytes));
@@ -217,6 +217,18 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
     d->f_wg_per_cu = k < 1 ? 1 : k;
   }
   d->f_n_threads = waves * 64;
+  /* bit-node tasks of low-degree columns (the high-rate modes) are short next to the fetch chain in front of every
+   * task: a queue ticket then stands for f_bn_group consecutive tasks, as long as every wave still gets two tickets */
+  {
+    int sum = 0;
+    for (int i = 0; i < nb; i++)
+      sum += bcost[i];
+    const int avg = nb ? sum / nb : 1;
+    int m = avg >= 120 ? 1 : (240 + avg - 1) / avg;
+    if (m > 4) m = 4;
+    if (m > nb / (2 * waves)) m = nb / (2 * waves);
+    d->f_bn_group = m < 1 ? 1 : m;
+  }
   lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
   lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
   /* the kernel's waves draw tasks 0, 1, 2, ... from a queue: task ids must already be in descending cost order

@@ -105,6 +105,7 @@ typedef struct ldpc_code_desc {
   uint32_t f_ctbl[2 * LDPC_F_MAX_CTBL];
   int32_t f_n_ctbl;   /* entries (pairs) used */
   int32_t f_wg_per_cu;  /* workgroups of this shape resident on one CU (16 wave slots, 160 KiB LDS) */
+  int32_t f_bn_group;   /* bit-node tasks per queue ticket (>= 1) */
   int32_t f_ext_global; /* 1: the degree-1 columns' LLRs are read from the input buffer, not staged in LDS */
   int32_t f_lds_zero; /* Z + 4 zero bytes */
 } ldpc_code_desc_t;
