@@ -202,9 +202,17 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
     __syncthreads();
     if (a.use_crc && p >= 3) { /* see ldpc_decoder.hip for the CRC argument */
       uint32_t x = 0;
-      for (int i = tid; i < crcE; i += nt)
-        if (ldpc_fast_hd(L, i, Z, z_magic, astride))
-          x ^= crc_pow[crcE - 1 - i];
+      /* four hard decisions (one APP dword: Zc % 4 == 0 keeps them in one column) and their four table entries per
+       * step, the loads unconditional and masked afterwards: independent loads in flight instead of a chain of
+       * bit test -> load -> wait (E is a multiple of 8) */
+      for (int i = 4 * tid; i < crcE; i += 4 * nt) {
+        const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
+        const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u); /* bit 8k+7 set <=> APP of lane k < 0 */
+        const uint32_t *pw = crc_pow + (crcE - 4 - i);                                    /* pw[3 - k] belongs to bit i + k */
+        const uint32_t p3 = pw[3], p2 = pw[2], p1 = pw[1], p0 = pw[0];
+        x ^= (p3 & (0u - ((nb >> 7) & 1u))) ^ (p2 & (0u - ((nb >> 15) & 1u))) ^ (p1 & (0u - ((nb >> 23) & 1u))) ^
+             (p0 & (0u - (nb >> 31)));
+      }
       for (int off = 32; off; off >>= 1)
         x ^= __shfl_xor(x, off);
       if (lane == 0 && x)
