@@ -4,9 +4,9 @@
  * Same contract as the generic kernel (ldpc_decoder.hip; reference nrLDPC_decoder.c:206-880), one
  * workgroup per code block, everything resident in LDS between the LLR load and the bit store.
  * What differs is the work decomposition (ldpc_dec_fast_core.h): 4 lanes per thread, biased-byte
- * messages moved as dwords, packed 16-bit arithmetic, degree-sorted 64-item tasks balanced over the
- * waves by the host (ldpc_graph.c build_fast_section).  Requires Zc % 4 == 0 and 4-byte aligned LLR rows;
- * other cases are served by the generic kernel.
+ * messages moved as dwords, packed 16-bit arithmetic, degree-sorted 64-item tasks (ldpc_graph.c
+ * build_fast_section) that the waves of the workgroup draw from a queue.  Requires Zc % 4 == 0 and 4-byte
+ * aligned LLR rows; other cases are served by the generic kernel.
  */
 #include <hip/hip_runtime.h>
 #include "ldpc_kernels.h"
