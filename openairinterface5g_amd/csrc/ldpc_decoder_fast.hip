@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
       for (int i = 4 * tid; i < crcE; i += 4 * nt) {
         const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
         const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u); /* bit 8k+7 set <=> APP of lane k < 0 */
-        const uint32_t *pw = crc_pow + (crcE - 4 - i);                                    /* pw[3 - k] belongs to bit i + k */
-        const uint32_t p3 = pw[3], p2 = pw[2], p1 = pw[1], p0 = pw[0];
+        /* pw[3 - k] belongs to bit i + k; E % 8 == 0 and i % 4 == 0 make the four entries one aligned 16-byte load */
+        const uint4 pw = *reinterpret_cast<const uint4 *>(crc_pow + (crcE - 4 - i));
+        const uint32_t p3 = pw.w, p2 = pw.z, p1 = pw.y, p0 = pw.x;
         x ^= (p3 & (0u - ((nb >> 7) & 1u))) ^ (p2 & (0u - ((nb >> 15) & 1u))) ^ (p1 & (0u - ((nb >> 23) & 1u))) ^
              (p0 & (0u - (nb >> 31)));
       }
