@@ -38,36 +38,6 @@ static int by_key_desc(const void *pa, const void *pb)
 
 static int align16(int x) { return (x + 15) & ~15; }
 
-/* longest-processing-time-first assignment of `n` tasks (cost[i]) to `nw` waves; fills ptr[nw+1], list[n] */
-static void lpt_assign(int n, const int *cost, int nw, int32_t *ptr, int32_t *list)
-{
-  sort_item_t it[LDPC_F_MAX_CN_TASKS];
-  int load[LDPC_F_MAX_WAVES], cnt[LDPC_F_MAX_WAVES], owner[LDPC_F_MAX_CN_TASKS];
-  for (int i = 0; i < n; i++) {
-    it[i].key = cost[i];
-    it[i].id = i;
-  }
-  qsort(it, n, sizeof(it[0]), by_key_desc);
-  memset(load, 0, sizeof(load));
-  memset(cnt, 0, sizeof(cnt));
-  for (int i = 0; i < n; i++) {
-    int best = 0;
-    for (int w = 1; w < nw; w++)
-      if (load[w] < load[best])
-        best = w;
-    owner[i] = best;
-    load[best] += it[i].key;
-    cnt[best]++;
-  }
-  ptr[0] = 0;
-  for (int w = 0; w < nw; w++)
-    ptr[w + 1] = ptr[w] + cnt[w];
-  int fill[LDPC_F_MAX_WAVES];
-  memset(fill, 0, sizeof(fill));
-  for (int i = 0; i < n; i++) /* sorted order is kept inside a wave: its most expensive task first */
-    list[ptr[owner[i]] + fill[owner[i]]++] = it[i].id;
-}
-
 /* schedules and tables of the "fast" decoder kernel (see ldpc_graph.h) */
 static void build_fast_section(ldpc_code_desc_t *d, int shape)
 {
@@ -229,8 +199,6 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
     if (m > nb / (2 * waves)) m = nb / (2 * waves);
     d->f_bn_group = m < 1 ? 1 : m;
   }
-  lpt_assign(nt, cost, waves, d->f_cn_ptr, d->f_cn_list);
-  lpt_assign(nb, bcost, waves, d->f_bn_ptr, d->f_bn_list);
   /* the kernel's waves draw tasks 0, 1, 2, ... from a queue: task ids must already be in descending cost order
    * (rows and columns are sorted by degree, so they are) */
   for (int i = 1; i < nt; i++)

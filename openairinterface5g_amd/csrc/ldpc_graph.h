@@ -84,11 +84,9 @@ typedef struct ldpc_code_desc {
   int32_t f_lds_r, f_lds_app, f_lds_ext, f_lds_etbl, f_lds_ctbl, f_lds_rowtbl, f_lds_coltbl, f_lds_misc, f_lds_total;
   int32_t f_n_threads;
   int32_t f_n_cn_tasks, f_n_bn_tasks;
-  int32_t f_cn_ptr[LDPC_F_MAX_WAVES + 1], f_bn_ptr[LDPC_F_MAX_WAVES + 1]; /* wave w runs list[ptr[w] .. ptr[w+1]) */
-  int32_t f_cn_list[LDPC_F_MAX_CN_TASKS], f_bn_list[LDPC_F_MAX_BN_TASKS];
   /* The kernel's waves draw the tasks of a phase in id order (= most expensive first) from a queue, an LDS counter:
-   * static per-wave lists -- the two arrays above, still used by the CPU emulation -- leave the SIMDs' oldest waves
-   * idle early, because the issue arbiter favours them and equal shares do not finish together. */
+   * static per-wave shares leave the SIMDs' oldest waves idle early, because the issue arbiter favours them and equal
+   * shares do not finish together. */
   /* CN task: {degree, has_ext, first item, group first item, group end item, sorted-row index of the group's first row} */
   int32_t f_cn_task[LDPC_F_MAX_CN_TASKS][6];
   /* BN task: {first item, end item (all columns), loop bound = degree of the first item's column} */

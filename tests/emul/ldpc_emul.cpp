@@ -219,11 +219,11 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
   const int max_pass = numMaxIter + 1;
   int n_iter = max_pass;
   for (int p = 1; p <= max_pass; ++p) {
-    for (int tid = 0; tid < nt; tid++) {
-      const int lane = tid & 63, wave = tid >> 6;
-      uint32_t syn = 0;
-      for (int ti = code->f_cn_ptr[wave]; ti < code->f_cn_ptr[wave + 1]; ti++) {
-        const int task = code->f_cn_list[ti];
+    (void)nt;
+    /* the kernel's waves draw the tasks of a phase from a queue; the tasks are independent, so any order will do */
+    for (int task = 0; task < code->f_n_cn_tasks; task++) {
+      for (int lane = 0; lane < 64; lane++) {
+        uint32_t syn = 0;
         const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
         const int item = code->f_cn_task[task][2] + lane;
         const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
@@ -236,19 +236,17 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
           const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
           syn |= m & mask;
         }
+        if (syn)
+          flags[p & 1] = 1;
       }
-      if (syn)
-        flags[p & 1] = 1;
     }
     flags[2] = 0;
     if (!use_crc && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;
       break;
     }
-    for (int tid = 0; tid < nt; tid++) {
-      const int lane = tid & 63, wave = tid >> 6;
-      for (int ti = code->f_bn_ptr[wave]; ti < code->f_bn_ptr[wave + 1]; ti++) {
-        const int task = code->f_bn_list[ti];
+    for (int task = 0; task < code->f_n_bn_tasks; task++) {
+      for (int lane = 0; lane < 64; lane++) {
         const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
         const int maxdeg = code->f_bn_task[task][2];
         if (item < end) {
