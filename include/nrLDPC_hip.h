@@ -54,10 +54,29 @@ typedef struct nrLDPC_dec_params {
   uint8_t setCombIn;
 } t_nrLDPC_dec_params;
 
-/* nrLDPC_decoder/nrLDPC_types.h:115-127 -- 11 x time_stats_t; opaque here, never dereferenced. */
-typedef struct nrLDPC_time_stats t_nrLDPC_time_stats;
-/* common/utils/time_meas.h:61-74 -- opaque, the encoder's optional meters are ignored. */
-typedef struct time_stats time_stats_t;
+/* common/utils/time_meas.h:61-74 (oai_cputime_t = long long on x86-64, :39).  The encoder's four optional meters
+ * (tinput, tprep, tparity, toutput) and the decoder's `total` are filled the way start_meas()/stop_meas() (:148-176) fill
+ * them, gated by the host executable's `opp_enabled` when it exports one. */
+typedef struct time_stats {
+  long long in;        /* time stamp of the running measurement */
+  long long diff;      /* accumulated ticks */
+  long long p_time;    /* last duration */
+  double diff_square;
+  long long max;
+  int trials;
+  int meas_flag;
+  char *meas_name;
+  int meas_index;
+  int meas_enabled;
+  void *tpoolmsg;
+  void *tstatptr;
+} time_stats_t;
+/* nrLDPC_decoder/nrLDPC_types.h:115-127.  Only `total` is written (the reference's per-function split -- cnProc,
+ * bnProc, the buffer copies -- has no counterpart in a kernel that keeps a block in LDS from LLR load to bit store). */
+typedef struct nrLDPC_time_stats {
+  time_stats_t llr2llrProcBuf, llr2CnProcBuf, cnProc, cnProcPc, bnProcPc, bnProc, cn2bnProcBuf, bn2cnProcBuf, llrRes2llrOut,
+      llr2bit, total;
+} t_nrLDPC_time_stats;
 
 /* openair1/PHY/defs_common.h:998-1027 -- transport-block wide "stop decoding" flag shared by the segments */
 typedef struct {
@@ -98,11 +117,16 @@ int32_t LDPCshutdown(void);
 /* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
  * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
  * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);
- * numMaxIter+2 when *ab was already set on entry. */
+ * numMaxIter+2 when *ab was already set on entry.  Never negative, like the reference: an internal error (bad
+ * parameters, HIP failure) is reported as numMaxIter+1 with *ab set, so that callers which only test
+ * `<= numMaxIter` (nr_ulsch_decoding.c:219-222) NACK; nrLDPC_hip_last_error() tells why.
+ * Calls are served by a resident GPU kernel through per-thread mailboxes (no HIP runtime call per segment); see
+ * csrc/ldpc_server.h for NRLDPC_HIP_SERVER / _SRV_SLOTS / _SRV_IDLE_US. */
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
 /* Up to 8 segments per call (ldpc_encoder_optim8segmulti.c:46-213): input[j] K/8 bytes MSB first,
- * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Returns 0, -1 on bad parameters. */
+ * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Returns 0, -1 on bad parameters (the
+ * reference's callers ignore the value: nr_dlsch_coding.c:171). */
 int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp);
 
 /* ===================================================================================================
@@ -195,6 +219,9 @@ int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R);    /* LDS a decoder workgrou
 /* info = {rows, columns, edges of the (BG, R) base graph; 1 if the fast decoder kernel serves the code; its workgroup
  * size; its LDS bytes; check-node and bit-node tasks per pass (fast kernel)}.  0, or -1 for an invalid code. */
 int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8]);
+/* resident submission path behind LDPCdecoder / LDPCencoder (csrc/ldpc_server.h): out = {status (-1 not started yet, 0 in
+ * use, 1 switched off or unavailable), caller slots, server kernel launches so far, calls served through it} */
+int32_t nrLDPC_hip_server_stats(int64_t out[4]);
 const char *nrLDPC_hip_last_error(void);
 const char *nrLDPC_hip_version(void);
 

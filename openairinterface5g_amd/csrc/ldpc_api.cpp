@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -21,6 +23,7 @@
 #include "ldpc_kernels.h"
 #include "nr_coding_host.h"
 #include "tb_chain.h"
+#include "ldpc_enc_packed_core.h"
 
 namespace {
 
@@ -59,7 +62,9 @@ struct Library {
   std::mutex mu;
   bool ready = false;
   int device = 0, n_cus = 256;
-  std::map<uint32_t, CodeEntry *> codes;
+  std::map<uint32_t, CodeEntry *> codes;      /* under mu: the builder's view */
+  std::atomic<CodeEntry *> code_tbl[2][385][3]; /* published entries, [BG-1][Z][rate index]: read without a lock */
+  const int *opp_enabled = nullptr;           /* the host executable's meter switch (common/utils/time_meas.h), if it has one */
   uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8: x^j mod g, j < 8448 */
   uint32_t *crc_pow_24a_long = nullptr;                        /* CRC24_A up to a whole transport block */
 } g;
@@ -115,6 +120,7 @@ int ensure_ready_locked()
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow_24a_long), t.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(g.crc_pow_24a_long, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
+  g.opp_enabled = static_cast<const int *>(dlsym(RTLD_DEFAULT, "opp_enabled"));
   g.ready = true;
   return 0;
 }
@@ -125,9 +131,24 @@ int ensure_ready()
   return ensure_ready_locked();
 }
 
-/* descriptor cache: built on first use of a (BG, Z, R), uploaded once, never modified afterwards */
+int rate_index(int BG, int R)
+{
+  if (BG == 1)
+    return R == 13 ? 0 : R == 23 ? 1 : R == 89 ? 2 : -1;
+  return R == 15 ? 0 : R == 13 ? 1 : R == 23 ? 2 : -1;
+}
+
+/* descriptor cache: built on first use of a (BG, Z, R), uploaded once, never modified afterwards.  The per-segment
+ * entry points come through here on every call: a published entry is found without taking the library mutex. */
 const CodeEntry *get_code(int BG, int Z, int R)
 {
+  const int ri = (BG == 1 || BG == 2) ? rate_index(BG, R) : -1;
+  if (ri < 0 || Z < 2 || Z > 384) {
+    set_error("invalid (BG, Z, R)");
+    return nullptr;
+  }
+  if (CodeEntry *hit = g.code_tbl[BG - 1][Z][ri].load(std::memory_order_acquire))
+    return hit;
   const uint32_t key = ((uint32_t)BG << 24) | ((uint32_t)Z << 8) | (uint32_t)R;
   std::lock_guard<std::mutex> lk(g.mu);
   if (ensure_ready_locked() != 0)
@@ -157,6 +178,7 @@ const CodeEntry *get_code(int BG, int Z, int R)
     return nullptr;
   }
   g.codes[key] = ce;
+  g.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
   return ce;
 }
 
@@ -165,15 +187,28 @@ int out_bytes_of(const ldpc_code_desc_t &c, int outMode)
   return outMode == 0 ? ((c.num_llr + 31) / 32) * 4 : c.num_llr;
 }
 
+/* Buffers that are outgrown are parked, not freed: hipFree / hipHostFree wait for every stream of the device, and the
+ * resident server kernel (ldpc_server.inc.cpp) may be running on one.  Growth is geometric, so the parked total stays
+ * below the live total. */
+std::mutex retired_mu;
+std::vector<std::pair<void *, bool>> retired; /* (pointer, is host) */
+void retire(void *p, bool host)
+{
+  if (!p)
+    return;
+  std::lock_guard<std::mutex> lk(retired_mu);
+  retired.emplace_back(p, host);
+}
+
 /* per-thread staging for the synchronous host-buffer entry points (callers are thread-pool workers:
- * reference nr_ulsch_decoding.c:435-468, nr_dlsch_coding.c:389-403) */
+ * reference nr_ulsch_decoding.c:435-468, nr_dlsch_coding.c:389-403).  A context outlives its thread: it goes back to a
+ * pool and the next new thread takes it over, so threads that come and go neither leak nor free. */
 struct ThreadCtx {
   hipStream_t stream = nullptr, stream2 = nullptr; /* stream2: second lane of the chunked host-buffer pipeline */
   uint8_t *h_in = nullptr, *h_out = nullptr; /* pinned */
   uint8_t *d_in = nullptr, *d_out = nullptr;
-  int32_t *h_iter = nullptr, *d_iter = nullptr;
-  size_t cap_in = 0, cap_out = 0, cap_iter = 0;
-  int ensure(size_t in_bytes, size_t out_bytes, size_t n_iter)
+  size_t cap_in = 0, cap_out = 0;
+  int ensure(size_t in_bytes, size_t out_bytes)
   {
     HIP_TRY(hipSetDevice(g.device));
     if (!stream) {
@@ -181,27 +216,73 @@ struct ThreadCtx {
       HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     }
     if (in_bytes > cap_in) {
-      if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
-      cap_in = in_bytes + in_bytes / 2 + 4096;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_in), cap_in, hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), cap_in));
+      retire(h_in, true); retire(d_in, false);
+      h_in = d_in = nullptr; cap_in = 0;
+      const size_t cap = in_bytes + in_bytes / 2 + 4096;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_in), cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), cap));
+      cap_in = cap;
     }
     if (out_bytes > cap_out) {
-      if (h_out) { (void)hipHostFree(h_out); (void)hipFree(d_out); }
-      cap_out = out_bytes + out_bytes / 2 + 4096;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_out), cap_out, hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), cap_out));
-    }
-    if (n_iter > cap_iter) {
-      if (h_iter) { (void)hipHostFree(h_iter); (void)hipFree(d_iter); }
-      cap_iter = n_iter + n_iter / 2 + 64;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_iter), cap_iter * sizeof(int32_t), hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_iter), cap_iter * sizeof(int32_t)));
+      retire(h_out, true); retire(d_out, false);
+      h_out = d_out = nullptr; cap_out = 0;
+      const size_t cap = out_bytes + out_bytes / 2 + 4096;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_out), cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), cap));
+      cap_out = cap;
     }
     return 0;
   }
+  /* an entry point that fails half way leaves nothing in flight on this thread's streams */
+  void drain()
+  {
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamSynchronize(stream2);
+    }
+  }
 };
-thread_local ThreadCtx tls_ctx;
+template <typename T> struct CtxPool {
+  std::mutex mu;
+  std::vector<T *> idle;
+  T *take()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (idle.empty())
+      return new T();
+    T *c = idle.back();
+    idle.pop_back();
+    return c;
+  }
+  void give(T *c)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back(c);
+  }
+};
+template <typename T> struct CtxHolder { /* thread_local: takes a context on first use, hands it back when the thread ends */
+  static CtxPool<T> &pool()
+  {
+    static CtxPool<T> *p = new CtxPool<T>(); /* never destroyed: threads may end after the static destructors ran */
+    return *p;
+  }
+  T *c = nullptr;
+  T &get()
+  {
+    if (!c)
+      c = pool().take();
+    return *c;
+  }
+  ~CtxHolder()
+  {
+    if (c) {
+      c->drain();
+      pool().give(c);
+    }
+  }
+};
+thread_local CtxHolder<ThreadCtx> tls_ctx_holder;
+#define tls_ctx (tls_ctx_holder.get())
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -262,7 +343,38 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
 
 } // namespace
 
-#include "ldpc_aggregator.inc.cpp"
+#include "ldpc_server.inc.cpp"
+
+namespace {
+/* start_meas / stop_meas of the reference (common/utils/time_meas.h:148-176), which are inline functions of the host
+ * executable gated by its global `opp_enabled`; a host without that symbol (tests) counts as enabled */
+inline bool meters_on() { return !g.opp_enabled || *g.opp_enabled; }
+inline long long meter_clock() { return (long long)__builtin_ia32_rdtsc(); }
+void meter_start(time_stats_t *ts)
+{
+  if (!ts || !meters_on())
+    return;
+  if (ts->meas_flag == 0) {
+    ts->trials++;
+    ts->meas_flag = 1;
+  }
+  ts->in = meter_clock();
+  if ((ts->trials & 16383) < 10)
+    ts->max = 0;
+}
+void meter_stop(time_stats_t *ts)
+{
+  if (!ts || !meters_on() || !ts->in)
+    return;
+  const long long d = meter_clock() - ts->in;
+  ts->diff += d;
+  ts->p_time = d;
+  ts->diff_square += (double)d * (double)d;
+  if (d > ts->max)
+    ts->max = d;
+  ts->meas_flag = 0;
+}
+} // namespace
 
 extern "C" {
 
@@ -298,13 +410,28 @@ int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8])
   return 0;
 }
 
+int32_t nrLDPC_hip_server_stats(int64_t out[4])
+{
+  if (!out)
+    return -1;
+  out[0] = srv.status.load();
+  out[1] = srv.n_slots;
+  out[2] = srv.gen.load();
+  int64_t calls = 0;
+  for (int i = 0; i < srv.n_slots; i++)
+    calls += (int64_t)srv.slots[i].calls; /* racy snapshot, exact when no call is in flight */
+  out[3] = calls;
+  return 0;
+}
+
 int32_t LDPCinit(void) { return ensure_ready() == 0 ? 0 : -1; }
 
 int32_t LDPCshutdown(void)
 {
   /* The reference's LDPCshutdown is a no-op (nrLDPC_decoder.c:167).  Device objects are kept: the loader
    * maps the library RTLD_NODELETE (common/utils/load_module_shlib.c:160) and other threads may still be
-   * inside a call. */
+   * inside a call.  The resident server kernel is asked to leave (a later call simply starts it again). */
+  srv_stop();
   return 0;
 }
 
@@ -341,7 +468,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
   const size_t in_stride = align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
   /* the pass counts travel behind the output rows in the same buffers: one device->host copy for a one-chunk call */
   const size_t iter_off = out_stride * b->n_blocks;
-  if (c.ensure(in_stride * b->n_blocks, iter_off + sizeof(int32_t) * b->n_blocks, 1) != 0)
+  if (c.ensure(in_stride * b->n_blocks, iter_off + sizeof(int32_t) * b->n_blocks) != 0)
     return -1;
   int32_t *d_iter = reinterpret_cast<int32_t *>(c.d_out + iter_off);
   const int32_t *h_iter = reinterpret_cast<const int32_t *>(c.h_out + iter_off);
@@ -389,8 +516,8 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab)
 {
-  (void)harq_pid; (void)ulsch_id; (void)C; (void)p_profiler;
-  if (!p_decParams || !p_llr || !p_out)
+  (void)harq_pid; (void)ulsch_id; (void)C;
+  if (!p_decParams)
     return set_error("null argument");
   /* decoder.c:556-559: a segment of an already failed transport block is not worked on */
   if (ab) {
@@ -400,31 +527,39 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
     if (failed)
       return p_decParams->numMaxIter + 2;
   }
-  const CodeEntry *ce = get_code(p_decParams->BG, p_decParams->Z, p_decParams->R);
-  if (!ce)
-    return -1;
+  if (p_profiler)
+    meter_start(&p_profiler->total);
   int32_t n_iter = 0;
-  {
-    std::lock_guard<std::mutex> lk(agg.mu);
-    agg_config_locked();
+  int rc = -1;
+  const CodeEntry *ce = (p_llr && p_out) ? get_code(p_decParams->BG, p_decParams->Z, p_decParams->R) : nullptr;
+  if (!p_llr || !p_out)
+    set_error("null argument");
+  if (ce) {
+    rc = 1;
+    if (srv_ready() == 0) /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp) */
+      rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter);
+    if (rc == 1) { /* server switched off, or a code it cannot hold: one launch per call on this thread's stream */
+      const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
+      nrLDPC_hip_dec_batch_t b;
+      memset(&b, 0, sizeof(b));
+      b.params = *p_decParams;
+      b.n_blocks = 1;
+      b.llr = p_llr; b.llr_stride = (uint32_t)ce->host.num_llr;
+      b.out = p_out; b.out_stride = (uint32_t)align_up(ob, 4);
+      b.n_iter = &n_iter;
+      b.mem = NRLDPC_HIP_MEM_HOST;
+      rc = LDPCdecoder_batch(&b);
+    }
   }
-  if (agg.enabled) {
-    /* concurrent callers (the reference's thread-pool workers) share launches: ldpc_aggregator.inc.cpp */
-    if (agg_decode(p_decParams, ce, p_llr, p_out, &n_iter) != 0)
-      return -1;
-  } else {
-    const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
-    nrLDPC_hip_dec_batch_t b;
-    memset(&b, 0, sizeof(b));
-    b.params = *p_decParams;
-    b.n_blocks = 1;
-    b.llr = p_llr; b.llr_stride = (uint32_t)ce->host.num_llr;
-    b.out = p_out; b.out_stride = (uint32_t)align_up(ob, 4);
-    b.n_iter = &n_iter;
-    b.mem = NRLDPC_HIP_MEM_HOST;
-    if (LDPCdecoder_batch(&b) != 0)
-      return -1;
+  if (rc != 0) {
+    /* The reference's LDPCdecoder cannot fail and its callers test only `decodeIterations <= numMaxIter`
+     * (nr_ulsch_decoding.c:219-222, nr_dlsch_decoding.c:259): report an internal error as "not decoded" so that they
+     * NACK instead of taking an untouched p_out for a code word.  nrLDPC_hip_last_error() has the reason. */
+    fprintf(stderr, "[libldpc_hip] LDPCdecoder failed: %s\n", tls_error.c_str());
+    n_iter = p_decParams->numMaxIter + 1;
   }
+  if (p_profiler)
+    meter_stop(&p_profiler->total);
   if (n_iter > p_decParams->numMaxIter && ab) { /* decoder.c:190-193 */
     pthread_mutex_lock(&ab->mutex_failure);
     ab->failed = true;
@@ -461,7 +596,7 @@ int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b)
   }
   ThreadCtx &c = tls_ctx;
   const size_t in_stride = align_up(in_bytes, 16), out_stride = align_up(N, 16);
-  if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks, 1) != 0)
+  if (c.ensure(in_stride * b->n_blocks, out_stride * b->n_blocks) != 0)
     return -1;
   for (uint32_t i = 0; i < b->n_blocks; i++)
     memcpy(c.h_in + i * in_stride, b->in + (size_t)i * b->in_stride, in_bytes);
@@ -478,6 +613,8 @@ int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b)
 
 int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp)
 {
+  /* Returns 0, or -1 on bad parameters / an internal error -- which the reference's callers ignore
+   * (nr_dlsch_coding.c:171, nr_ulsch_coding.c:167 discard the return value), as they do for the reference library. */
   if (!input || !output || !impp)
     return set_error("null argument");
   /* ldpc_encoder_optim8segmulti.c:64-65: this call covers segments 8*macro_num .. min(n_segments, +8) */
@@ -492,27 +629,47 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
   const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
   if ((uint32_t)K != impp->K)
     return set_error("K must be 22*Zc (BG1) or 10*Zc (BG2)");
+  if ((int)impp->Kb < 1 || (int)impp->Kb > hc.kb_full)
+    return set_error("bad Kb");
   const unsigned n = last - first;
+  /* the reference's four meters (ldpc_encoder_optim8segmulti.c:120-210), with this library's phases: tinput = staging
+   * the segments, tprep = nothing, tparity = the encode on the GPU, toutput = handing the code words back */
+  if (srv_ready() == 0) {
+    meter_start(impp->tinput);
+    const int rc = srv_encode(ce, (int)impp->Kb, input, output, first, n, impp->tinput, impp->tprep, impp->tparity, impp->toutput);
+    if (rc <= 0)
+      return rc;
+  }
   ThreadCtx &c = tls_ctx;
   const size_t in_stride = align_up(in_bytes, 16), out_stride = align_up(N, 16);
-  if (c.ensure(in_stride * n, out_stride * n, 1) != 0)
+  if (c.ensure(in_stride * n, out_stride * n) != 0)
     return -1;
+  meter_start(impp->tinput);
   for (unsigned j = 0; j < n; j++)
     memcpy(c.h_in + j * in_stride, input[first + j], in_bytes);
-  HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * n, hipMemcpyHostToDevice, c.stream));
+  meter_stop(impp->tinput);
+  meter_start(impp->tprep);
+  meter_stop(impp->tprep);
+  meter_start(impp->tparity);
   ldpc_enc_args a;
   a.jobs = nullptr;
   a.code = ce->dev;
   a.Kb = (int)impp->Kb;
-  if (a.Kb < 1 || a.Kb > hc.kb_full)
-    return set_error("bad Kb");
   a.in = c.d_in; a.in_stride = (uint32_t)in_stride;
   a.out = c.d_out; a.out_stride = (uint32_t)out_stride;
-  HIP_TRY(ldpc_launch_enc(a, hc, n, c.stream));
-  HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, out_stride * n, hipMemcpyDeviceToHost, c.stream));
-  HIP_TRY(hipStreamSynchronize(c.stream));
+  hipError_t e = hipMemcpyAsync(c.d_in, c.h_in, in_stride * n, hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess)
+    e = ldpc_launch_enc(a, hc, n, c.stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(c.h_out, c.d_out, out_stride * n, hipMemcpyDeviceToHost, c.stream);
+  const hipError_t e2 = hipStreamSynchronize(c.stream); /* also on the error path: nothing stays in flight */
+  meter_stop(impp->tparity);
+  if (e != hipSuccess || e2 != hipSuccess)
+    return set_error("LDPCencoder", e != hipSuccess ? e : e2);
+  meter_start(impp->toutput);
   for (unsigned j = 0; j < n; j++)
     memcpy(output[first + j], c.h_out + j * out_stride, N);
+  meter_stop(impp->toutput);
   return 0;
 }
 

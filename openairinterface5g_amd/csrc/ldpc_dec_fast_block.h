@@ -1,0 +1,249 @@
+/*
+ * ldpc_dec_fast_block.h -- one code block through the "fast" flooding min-sum decoder, executed by one workgroup
+ * (device code).  Shared by the batch kernel (ldpc_decoder_fast.hip: one workgroup per block of a launch) and by the
+ * resident server kernel (ldpc_server.hip: one workgroup per caller slot, blocks arrive through a mailbox).
+ *
+ * Contract = nrLDPC_decoder_core (reference openair1/PHY/CODING/nrLDPC_decoder/nrLDPC_decoder.c:206-880); per-thread
+ * arithmetic in ldpc_dec_fast_core.h.  Everything of the block lives in the workgroup's LDS between the LLR load and
+ * the bit store.  The function contains workgroup barriers: every thread of the workgroup must call it with the same
+ * (wave-uniform) arguments.  Any workgroup size that is a multiple of 64 works: the loops stride by blockDim.x and the
+ * tasks of a phase are drawn from a queue.
+ */
+#ifndef LDPC_DEC_FAST_BLOCK_H
+#define LDPC_DEC_FAST_BLOCK_H
+#include <hip/hip_runtime.h>
+#include "ldpc_kernels.h"
+#include "ldpc_dec_fast_core.h"
+
+struct ldpc_block_io {
+  const uint32_t *src32;   /* the block's channel LLRs: ncols*Z int8, 4-byte aligned, device memory (re-read every pass) */
+  int8_t *out;             /* output row (packed bits: 4-byte aligned) */
+  int max_pass;            /* numMaxIter + 1 */
+  int use_crc, crcE;       /* CRC stop mode and the bits it covers */
+  const uint32_t *crc_pow; /* x^j mod g, left aligned */
+  int out_mode;            /* 0 packed bits, else one bit per byte */
+  int *tb_abort;           /* optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559) */
+};
+
+/* next ticket of a task queue (wave-uniform) */
+__device__ __forceinline__ int ldpc_draw(int *counter, int lane)
+{
+  int t = 0;
+  if (lane == 0)
+    t = atomicAdd(counter, 1);
+  return LDPC_UNIFORM(t);
+}
+
+/* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
+__device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_block_io &io)
+{
+  const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
+  const uint32_t zq_magic = code->f_zq_magic;
+  const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u; /* ceil(2^32 / Z) for Z not a power of two, exact enough
+                                                               for b < 2^16 either way (checked on the host) */
+  ldpc_fast_lds L;
+  L.base = fsm;
+  L.r = fsm + code->f_lds_r;
+  L.app = fsm + code->f_lds_app;
+  L.ext = fsm + code->f_lds_ext;
+  uint32_t *etbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_etbl);
+  uint32_t *ctbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_ctbl);
+  uint32_t *rowtbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_rowtbl);
+  uint32_t *coltbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_coltbl);
+  L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
+  int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
+  const uint32_t *__restrict__ src32 = io.src32;
+
+  /* ---- tables and state into LDS -------------------------------------------------------------------- */
+  const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
+  const int ext_global = code->f_ext_global;
+  L.gllr = reinterpret_cast<const uint8_t *>(src32);
+  L.ext_global = ext_global;
+  /* The block's LLRs come from HBM: the first four dwords per thread of the core and of the extension columns are
+   * requested before anything else and consumed after the table copies and the message initialisation, so that their
+   * latency runs in the background (a 1024-thread workgroup needs 3 + 4 such loads per thread for Zc = 384). */
+  const int n_app = ncore * zq, n_ext = ext_global ? 0 : (code->ncols - ncore) * zq;
+  uint32_t va[4], ve[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ia = tid + k * nt;
+    va[k] = ia < n_app ? src32[ia] : 0u;
+    ve[k] = ia < n_ext ? src32[n_app + ia] : 0u;
+  }
+  for (int i = tid; i < nedges; i += nt)
+    etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
+  for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
+    ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
+  for (int i = tid; i < (Z + 4) >> 2; i += nt)
+    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
+  for (int i = tid; i < code->nrows; i += nt)
+    rowtbl[i] = code->f_rowtbl[i];
+  for (int i = tid; i < ncore; i += nt)
+    coltbl[i] = code->f_coltbl[i];
+  if (tid < 8)
+    flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen,
+                       [4], [5] task queues of the two phases */
+  {
+    const int nr4 = (nedges * rstride) >> 2;
+    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
+    for (int i = tid; i < nr4; i += nt)
+      r32[i] = 0x80808080u;
+  }
+  /* APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
+  uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = tid + k * nt;
+    if (i < n_app) {
+      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+      const uint32_t w = va[k] ^ 0x80808080u;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
+      dst[0] = w;
+      dst[zq] = w;
+    }
+    if (i < n_ext)
+      e32[i] = ve[k] ^ 0x80808080u;
+  }
+  for (int i = tid + 4 * nt; i < n_app; i += nt) { /* small workgroups: the rest */
+    const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+    const uint32_t w = src32[i] ^ 0x80808080u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
+    dst[0] = w;
+    dst[zq] = w;
+  }
+  for (int i = tid + 4 * nt; i < n_ext; i += nt)
+    e32[i] = src32[n_app + i] ^ 0x80808080u;
+  __syncthreads();
+
+  /* ---- passes ------------------------------------------------------------------------------------------ */
+  const int max_pass = io.max_pass;
+  const int crcE = io.crcE;
+  const uint32_t *crc_pow = io.crc_pow;
+  int n_iter = max_pass;
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
+  for (int p = 1; p <= max_pass; ++p) {
+    uint32_t syn = 0;
+#ifdef LDPC_ABLATE_CN
+    syn = 1;
+#else
+    /* The phase's tasks are drawn in id order (= most expensive first, ldpc_graph.c) from a queue -- an LDS counter --
+     * by whichever wave is free: the SIMD issue arbiter favours a CU's older waves, so static equal shares leave the
+     * SIMDs with one or two live waves for the last third of a phase (profiles/r01/task_timeline.txt). */
+    for (;;) {
+      const int task = ldpc_draw(&flags[4], lane);
+      if (task >= n_cn_tasks)
+        break;
+      const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+      const int item = code->f_cn_task[task][2] + lane;
+      const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
+      if (item < gend) {
+        const int gi = item - gstart;
+        const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
+        const uint32_t rowrec = rowtbl[srow0 + rig];
+        const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
+        const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
+        const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+        syn |= m & mask;
+      }
+    }
+#endif
+    if (__any(syn != 0) && lane == 0)
+      flags[p & 1] = 1;
+    if (tid == 0) {
+      flags[2] = 0;
+      flags[5] = 0; /* nobody draws bit-node tasks now */
+      /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
+      if (io.tb_abort && p >= 2 && __hip_atomic_load(io.tb_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        flags[3] = 1;
+    }
+    __syncthreads();
+    if (io.tb_abort && flags[3]) {
+      n_iter = max_pass + 1;
+      break;
+    }
+    if (!io.use_crc && p >= 3 && flags[p & 1] == 0) {
+      n_iter = p - 1;
+      break;
+    }
+#ifndef LDPC_ABLATE_BN
+    for (;;) {
+      const int ticket = ldpc_draw(&flags[5], lane);
+      if (ticket * bn_group >= n_bn_tasks)
+        break;
+      for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
+        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+        const int maxdeg = code->f_bn_task[task][2];
+        if (item < end) {
+          const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
+          const uint32_t colrec = coltbl[sc];
+          const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
+          ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+        }
+      }
+    }
+#endif
+    if (tid == 0) {
+      flags[(p + 1) & 1] = 0;
+      flags[4] = 0; /* nobody draws check-node tasks now */
+    }
+    __syncthreads();
+    if (io.use_crc && p >= 3) { /* see ldpc_dec_generic_block.h for the CRC argument */
+      uint32_t x = 0;
+      /* four hard decisions (one APP dword: Zc % 4 == 0 keeps them in one column) and their four table entries per
+       * step, the loads unconditional and masked afterwards: independent loads in flight instead of a chain of
+       * bit test -> load -> wait (E is a multiple of 8) */
+      for (int i = 4 * tid; i < crcE; i += 4 * nt) {
+        const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
+        const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u); /* bit 8k+7 set <=> APP of lane k < 0 */
+        /* pw[3 - k] belongs to bit i + k; E % 8 == 0 and i % 4 == 0 make the four entries one aligned 16-byte load */
+        const uint4 pw = *reinterpret_cast<const uint4 *>(crc_pow + (crcE - 4 - i));
+        const uint32_t p3 = pw.w, p2 = pw.z, p1 = pw.y, p0 = pw.x;
+        x ^= (p3 & (0u - ((nb >> 7) & 1u))) ^ (p2 & (0u - ((nb >> 15) & 1u))) ^ (p1 & (0u - ((nb >> 23) & 1u))) ^
+             (p0 & (0u - (nb >> 31)));
+      }
+      for (int off = 32; off; off >>= 1)
+        x ^= __shfl_xor(x, off);
+      if (lane == 0 && x)
+        atomicXor(reinterpret_cast<unsigned int *>(&flags[2]), x);
+      __syncthreads();
+      const int rem = flags[2];
+      __syncthreads();
+      if (rem == 0) {
+        n_iter = p;
+        break;
+      }
+    }
+  }
+  if (io.tb_abort && n_iter == max_pass && tid == 0) /* decoder.c:190-193: a failed segment gives the whole TB up */
+    __hip_atomic_store(io.tb_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  /* ---- hard decision ------------------------------------------------------------------------------------- */
+  if ((!io.use_crc || n_iter >= 3) && n_iter <= max_pass) {
+    if (io.out_mode == 0) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(io.out);
+      const int nwords = (num_llr + 31) >> 5;
+      for (int w = tid; w < nwords; w += nt) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
+          if (b < ncz) {
+            const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+            const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+            word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
+          }
+        }
+        o[w] = word;
+      }
+    } else {
+      int8_t *o = io.out;
+      for (int i = tid; i < num_llr; i += nt)
+        o[i] = (i < ncz) ? (int8_t)ldpc_fast_hd(L, i, Z, z_magic, astride) : (int8_t)0;
+    }
+  }
+  return n_iter;
+}
+#endif

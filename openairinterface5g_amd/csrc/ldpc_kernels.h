@@ -18,6 +18,8 @@ struct ldpc_dec_job {
   int32_t E;                    /* CRC mode: bits covered */
   int32_t crc_type;             /* CRC mode: index into ldpc_dec_args.crc_pow_tbl */
   int32_t iter_idx;             /* where in ldpc_dec_args.n_iter this block reports */
+  int32_t abort_idx;            /* index into ldpc_dec_args.tb_abort of the block's transport block, -1: none */
+  int32_t pad;
 };
 struct ldpc_enc_job {
   const ldpc_code_desc_t *code; /* device, full-rate descriptor */
@@ -40,6 +42,7 @@ struct ldpc_dec_args {
   const uint32_t *crc_pow; /* device table, crc_pow[j] = x^j mod g(x), left aligned in 32 bits */
   const ldpc_dec_job *jobs; /* NULL: homogeneous batch addressed by strides */
   const uint32_t *crc_pow_tbl[4]; /* per crc_type, used with jobs */
+  int *tb_abort;            /* with jobs: per transport block "a segment failed" flags (zero on entry), or NULL */
 };
 
 struct ldpc_enc_args {

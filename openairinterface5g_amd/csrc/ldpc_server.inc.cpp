@@ -1,0 +1,280 @@
+/*
+ * ldpc_server.inc.cpp -- host side of the resident submission path (protocol and rationale: ldpc_server.h; kernel:
+ * ldpc_server.hip).  Included by ldpc_api.cpp (shares its library state).
+ *
+ * The reference's callers invoke LDPCdecoder / LDPCencoder from N thread-pool workers at once, one code segment (resp.
+ * one group of 8 segments) per call (openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:219,435-468, nr_dlsch_coding.c:171,
+ * 386-403).  Each calling thread owns a slot (its mailbox + a workgroup of the server kernel); a call touches no lock
+ * shared with other callers and makes no HIP runtime call while the server is up.
+ *
+ * Environment: NRLDPC_HIP_SERVER=0 falls back to one launch per call (stream + pinned staging per thread);
+ * NRLDPC_HIP_SRV_SLOTS=<n> caller slots = workgroups = CUs the server occupies while it is up (default 64, more
+ * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
+ * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls).
+ */
+#include <atomic>
+#include <sched.h>
+#include "ldpc_server.h"
+
+hipError_t ldpc_server_init(void);
+hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream);
+
+namespace {
+
+void meter_start(time_stats_t *ts);
+void meter_stop(time_stats_t *ts);
+
+struct alignas(64) SrvSlotHost {
+  std::atomic<uint32_t> busy{0};
+  uint32_t seq = 0;
+  uint64_t calls = 0; /* written by the slot's holder only */
+};
+
+struct Server {
+  std::mutex mu;            /* init / launch / stop only -- never taken by a call that finds the server running */
+  std::atomic<int> status{-1}; /* -1 not initialised, 0 usable, 1 disabled or failed */
+  int n_slots = 0;
+  srv_args args;            /* template of the kernel arguments (gen filled in per launch) */
+  srv_slot_ctl *ctl = nullptr;
+  uint8_t *in_h = nullptr, *out_h = nullptr;
+  uint32_t *state = nullptr, *host_stop = nullptr;
+  hipStream_t stream = nullptr;
+  std::atomic<uint32_t> gen{0};
+  std::atomic<uint32_t> next_slot{0};
+  SrvSlotHost *slots = nullptr;
+} srv;
+
+void srv_stop_at_exit();
+
+int srv_init_locked()
+{
+  const char *e = getenv("NRLDPC_HIP_SERVER");
+  if (e && atoi(e) == 0) {
+    srv.status = 1;
+    return 1;
+  }
+  int n = 64;
+  if ((e = getenv("NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
+    n = atoi(e);
+  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.n_cus / 2)));
+  int idle_us = 20000;
+  if ((e = getenv("NRLDPC_HIP_SRV_IDLE_US")) && atoi(e) >= 1)
+    idle_us = atoi(e);
+  srv.status = 1; /* until everything below has worked */
+  HIP_TRY(hipSetDevice(g.device));
+  HIP_TRY(ldpc_server_init());
+  const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
+  uint8_t *small = nullptr;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.ctl), (size_t)n * sizeof(srv_slot_ctl), flags));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.in_h), (size_t)n * SRV_IN_STRIDE, flags));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.out_h), (size_t)n * SRV_OUT_STRIDE, flags));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&small), 256, flags));
+  memset(srv.ctl, 0, (size_t)n * sizeof(srv_slot_ctl));
+  memset(small, 0, 256);
+  srv.state = reinterpret_cast<uint32_t *>(small);
+  srv.host_stop = reinterpret_cast<uint32_t *>(small + 128);
+  srv_args &a = srv.args;
+  memset(&a, 0, sizeof(a));
+  void *dp = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dp, srv.ctl, 0));
+  a.ctl = static_cast<srv_slot_ctl *>(dp);
+  HIP_TRY(hipHostGetDevicePointer(&dp, srv.in_h, 0));
+  a.in_host = static_cast<const uint8_t *>(dp);
+  HIP_TRY(hipHostGetDevicePointer(&dp, srv.out_h, 0));
+  a.out_host = static_cast<uint8_t *>(dp);
+  HIP_TRY(hipHostGetDevicePointer(&dp, srv.state, 0));
+  a.state = static_cast<uint32_t *>(dp);
+  HIP_TRY(hipHostGetDevicePointer(&dp, srv.host_stop, 0));
+  a.host_stop = static_cast<const uint32_t *>(dp);
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * SRV_IN_STRIDE));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.gctl), sizeof(srv_gctl)));
+  HIP_TRY(hipMemset(a.gctl, 0, sizeof(srv_gctl)));
+  a.idle_ticks = (uint32_t)idle_us * 100u; /* wall_clock64: 100 MHz */
+  for (int i = 0; i < 4; i++)
+    a.crc_pow_tbl[i] = g.crc_pow[i];
+  /* its own hardware queue: a kernel that stays resident must not sit in front of other streams' launches */
+  int lo = 0, hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_TRY(hipStreamCreateWithPriority(&srv.stream, hipStreamNonBlocking, hi));
+  srv.slots = new SrvSlotHost[n];
+  srv.n_slots = n;
+  atexit(srv_stop_at_exit); /* registered after the HIP runtime's own handlers, hence run before them */
+  srv.status = 0;
+  return 0;
+}
+
+/* 0: usable */
+int srv_ready()
+{
+  int st = srv.status.load(std::memory_order_acquire);
+  if (st >= 0)
+    return st;
+  if (ensure_ready() != 0)
+    return 1;
+  std::lock_guard<std::mutex> lk(srv.mu);
+  if (srv.status.load() < 0 && srv_init_locked() != 0 && srv.status.load() < 0)
+    srv.status = 1;
+  return srv.status.load();
+}
+
+/* Called by a waiting caller: (re)launch the server if no generation is running or on its way. */
+int srv_ensure_running()
+{
+  uint32_t gcur = srv.gen.load(std::memory_order_acquire);
+  uint32_t st = __atomic_load_n(srv.state, __ATOMIC_ACQUIRE);
+  if (gcur && st <= 2 * gcur + 1)
+    return 0; /* running (== 2g+1) or launched and not started yet (< 2g+1) */
+  std::lock_guard<std::mutex> lk(srv.mu);
+  gcur = srv.gen.load();
+  st = __atomic_load_n(srv.state, __ATOMIC_ACQUIRE);
+  if (gcur && st <= 2 * gcur + 1)
+    return 0;
+  srv_args a = srv.args;
+  a.gen = gcur + 1;
+  HIP_TRY(hipSetDevice(g.device));
+  HIP_TRY(ldpc_server_launch(a, (uint32_t)srv.n_slots, srv.stream));
+  srv.gen.store(gcur + 1, std::memory_order_release);
+  return 0;
+}
+
+/* Ask the running generation to leave and wait for it (requests already rung are served first or picked up by the next
+ * generation).  Used at exit / LDPCshutdown; nothing on the call path needs it. */
+void srv_stop()
+{
+  if (srv.status.load() != 0)
+    return;
+  std::lock_guard<std::mutex> lk(srv.mu);
+  const uint32_t gcur = srv.gen.load();
+  if (!gcur)
+    return;
+  __atomic_store_n(srv.host_stop, gcur, __ATOMIC_RELEASE);
+  (void)hipSetDevice(g.device);
+  (void)hipStreamSynchronize(srv.stream);
+}
+void srv_stop_at_exit() { srv_stop(); }
+
+thread_local int tls_srv_slot = -1;
+
+struct SrvCall {
+  int slot;
+  uint8_t *in, *out;
+  srv_slot_ctl *ctl;
+};
+
+SrvCall srv_acquire()
+{
+  if (tls_srv_slot < 0)
+    tls_srv_slot = (int)(srv.next_slot.fetch_add(1) % (uint32_t)srv.n_slots);
+  const int s = tls_srv_slot;
+  SrvSlotHost &h = srv.slots[s];
+  for (int spins = 0;; spins++) { /* uncontended unless there are more caller threads than slots */
+    uint32_t z = 0;
+    if (h.busy.compare_exchange_weak(z, 1, std::memory_order_acquire))
+      break;
+    if (spins > 64)
+      sched_yield();
+  }
+  return SrvCall{s, srv.in_h + (size_t)s * SRV_IN_STRIDE, srv.out_h + (size_t)s * SRV_OUT_STRIDE, srv.ctl + s};
+}
+void srv_release(const SrvCall &c) { srv.slots[c.slot].busy.store(0, std::memory_order_release); }
+
+/* ring the doorbell for [header | payload_bytes] and wait for the completion word; returns n_iter via *n_iter */
+int srv_submit(const SrvCall &c, size_t payload_bytes, int32_t *n_iter)
+{
+  SrvSlotHost &h = srv.slots[c.slot];
+  h.seq = (h.seq + 1) & 0xfffffu;
+  h.calls++;
+  const uint32_t n16 = (uint32_t)((SRV_REQ_BYTES + payload_bytes + 15) / 16);
+  const uint32_t db = (h.seq << 12) | n16;
+  __atomic_store_n(&c.ctl->doorbell, db, __ATOMIC_SEQ_CST); /* header and payload are ordered before it */
+  for (uint32_t spins = 0;; spins++) {
+    if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == db)
+      break;
+    if ((spins & 7) == 0 && srv_ensure_running() != 0)
+      return -1;
+    if (spins < 32)
+      __builtin_ia32_pause();
+    else
+      sched_yield(); /* callers outnumber cores on a loaded box: give the others the CPU while the GPU works */
+  }
+  if (n_iter)
+    *n_iter = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
+  return 0;
+}
+
+/* 0: decoded through the server, 1: this code cannot be served (caller uses the launch path), -1: error */
+int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *llr, int8_t *out, int32_t *n_iter)
+{
+  const ldpc_code_desc_t &hl = ce->host_lat;
+  uint32_t kind;
+  if (hl.f_ok && hl.f_lds_total <= SRV_CODE_LDS_MAX)
+    kind = SRV_KIND_DEC_FAST;
+  else if (hl.lds_total <= SRV_CODE_LDS_MAX)
+    kind = SRV_KIND_DEC_GENERIC;
+  else
+    return 1;
+  ldpc_dec_args a;
+  if (fill_dec_args(*p, ce, a) != 0)
+    return -1;
+  const int out_mode = a.out_mode, ob = out_bytes_of(hl, out_mode);
+  if (SRV_REQ_BYTES + (size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob > SRV_OUT_STRIDE)
+    return 1;
+  const SrvCall c = srv_acquire();
+  srv_req *rq = reinterpret_cast<srv_req *>(c.in);
+  memset(rq, 0, sizeof(*rq));
+  rq->kind = kind;
+  rq->max_pass = (uint32_t)p->numMaxIter + 1u;
+  rq->use_crc = (uint32_t)a.use_crc;
+  rq->crcE = (uint32_t)a.E;
+  rq->crc_type = a.use_crc ? (uint32_t)p->crc_type : 0u;
+  rq->out_mode = (uint32_t)out_mode;
+  rq->code = reinterpret_cast<uint64_t>(ce->dev_lat);
+  memcpy(c.in + SRV_REQ_BYTES, llr, (size_t)hl.num_llr);
+  int32_t n = 0;
+  const int rc = srv_submit(c, (size_t)hl.num_llr, &n);
+  if (rc == 0) {
+    *n_iter = n;
+    if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+      memcpy(out, c.out, (size_t)ob);
+  }
+  srv_release(c);
+  return rc;
+}
+
+/* segments first .. first+n-1 of an LDPCencoder call; 0 / 1 / -1 as above */
+int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, unsigned first, unsigned n, time_stats_t *tinput,
+               time_stats_t *tprep, time_stats_t *tparity, time_stats_t *toutput)
+{
+  const ldpc_code_desc_t &hc = ce->host;
+  const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
+  const size_t in_stride = align_up((size_t)in_bytes + 8, 16), out_stride = align_up((size_t)N, 16);
+  const size_t lds = (size_t)4 * ((ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z, hc.nrows, hc.nedges) + 3) & ~3) * 8;
+  if (n > 8 || SRV_REQ_BYTES + in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
+    return 1;
+  const SrvCall c = srv_acquire();
+  srv_req *rq = reinterpret_cast<srv_req *>(c.in);
+  memset(rq, 0, sizeof(*rq));
+  rq->kind = SRV_KIND_ENC;
+  rq->Kb = (uint32_t)Kb;
+  rq->n_seg = n;
+  rq->code = reinterpret_cast<uint64_t>(ce->dev);
+  rq->seg_in_stride = (uint32_t)in_stride;
+  rq->seg_out_stride = (uint32_t)out_stride;
+  for (unsigned j = 0; j < n; j++)
+    memcpy(c.in + SRV_REQ_BYTES + j * in_stride, input[first + j], (size_t)in_bytes);
+  meter_stop(tinput); /* started by the caller */
+  meter_start(tprep);
+  meter_stop(tprep);
+  meter_start(tparity);
+  const int rc = srv_submit(c, in_stride * n, nullptr);
+  meter_stop(tparity);
+  meter_start(toutput);
+  if (rc == 0)
+    for (unsigned j = 0; j < n; j++)
+      memcpy(output[first + j], c.out + j * out_stride, (size_t)N);
+  meter_stop(toutput);
+  srv_release(c);
+  return rc;
+}
+
+} // namespace

@@ -14,10 +14,12 @@ struct DevBuf { /* growable device buffer */
   {
     if (n <= cap)
       return 0;
-    if (p)
-      (void)hipFree(p);
-    cap = n + n / 4 + 65536;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), cap));
+    retire(p, false); /* parked, not freed: see retire() */
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 65536;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), want));
+    cap = want;
     return 0;
   }
 };
@@ -28,10 +30,12 @@ struct PinBuf { /* growable pinned host buffer */
   {
     if (n <= cap)
       return 0;
-    if (p)
-      (void)hipHostFree(p);
-    cap = n + n / 4 + 65536;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), cap, hipHostMallocDefault));
+    retire(p, true);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 65536;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault));
+    cap = want;
     return 0;
   }
 };
@@ -72,8 +76,15 @@ struct TbCtx {
   hipStream_t own = nullptr, last = nullptr;
   hipEvent_t uploaded = nullptr;
   bool pending = false;
+  void drain() /* nothing of this thread's stays in flight (error paths, thread exit) */
+  {
+    if (own)
+      (void)hipStreamSynchronize(own);
+    pending = false;
+  }
 };
-thread_local TbCtx tls_tb;
+thread_local CtxHolder<TbCtx> tls_tb_holder; /* pooled like ThreadCtx: contexts outlive their threads */
+#define tls_tb (tls_tb_holder.get())
 
 struct Arena { /* bump allocator over the scratch buffer, 16-byte granules */
   size_t top = 0;
@@ -114,6 +125,17 @@ int tb_wait_upload(TbCtx &c)
     c.pending = false;
   }
   return 0;
+}
+
+/* NRLDPC_HIP_TB_ABORT=0: every segment of a lost transport block is decoded to the end (the reference's behaviour when its
+ * workers never overlap); default: siblings of a failed segment give up at their next pass (decoder.c:190-193, 556-559) */
+bool tb_abort_enabled()
+{
+  static const int v = [] {
+    const char *e = getenv("NRLDPC_HIP_TB_ABORT");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return v != 0;
 }
 
 int tb_validate(const nrLDPC_hip_tb_t &t)
@@ -379,6 +401,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
       dj.E = nr_hip_len_with_crc((int)sg.C, (int)t.A); /* nr_ulsch_decoding.c:190 */
       dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
       dj.iter_idx = (int32_t)sj.size();
+      dj.abort_idx = tb_abort_enabled() ? (int32_t)i : -1;
+      dj.pad = 0;
       if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
         return set_error("CRC length outside the code block");
       if (hc.f_ok) {
@@ -399,8 +423,9 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
                o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
                o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
-               o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators: uploaded as zeros */
-               jobs_bytes = o_acc + align_up((size_t)b->n_tb * sizeof(uint32_t), 16),
+               o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators, then the per-TB
+                                                                                         abort flags: uploaded as zeros */
+               jobs_bytes = o_acc + align_up((size_t)b->n_tb * 2 * sizeof(uint32_t), 16),
                o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
   if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
       pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
@@ -465,6 +490,8 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   for (int k = 0; k < 4; k++)
     da.crc_pow_tbl[k] = g.crc_pow[k];
   da.crc_pow_tbl[NR_HIP_CRC24_A] = g.crc_pow_24a_long;
+  int *d_abort = reinterpret_cast<int *>(pl.jobs_d.p + o_acc) + b->n_tb; /* zero on entry, left zero by the verdict kernel */
+  da.tb_abort = d_abort;
   if (pl.n_fast) {
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_fast);
     HIP_TRY(ldpc_launch_dec_fast_jobs(da, fast_threads, fast_lds, (uint32_t)pl.n_fast, s));
@@ -476,7 +503,7 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
   HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), b->n_tb,
                                 reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
-                                c.scratch.p, payload, ack, iter_max, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+                                c.scratch.p, payload, ack, iter_max, d_acc, d_abort, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
   if (host) {
     HIP_TRY(hipMemcpyAsync(b->payload, payload, payload_end, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(b->harq, harq, harq_end * 2, hipMemcpyDeviceToHost, s));

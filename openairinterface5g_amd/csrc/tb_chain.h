@@ -70,5 +70,5 @@ hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int
 /* reassembly per segment (payload copy + partial TB CRC into acc[tb], zero on entry and on exit), then per-TB verdict */
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,
-                                 uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);
+                                 uint32_t *acc, int *tb_abort, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s);
 #endif

@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_s
  * per TB: ACK = every segment decoded and (C == 1 or the CRC register of the whole b is zero). */
 __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_tb_job *jobs, const tb_rx_seg_job *segs,
                                                                     const int32_t *n_iter, uint8_t *scratch, uint8_t *payload,
-                                                                    uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16)
+                                                                    uint32_t *acc, const int *tb_abort, const uint32_t *pow24a,
+                                                                    const uint32_t *pow16)
 {
   __shared__ uint32_t tab[256];
   const tb_rx_seg_job sj = segs[blockIdx.x];
@@ -297,7 +298,9 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   tb_build_crc_tab(pow, tab);
   uint8_t *b = scratch + j.b_off;
   const uint32_t bbytes = j.B >> 3, abytes = j.A >> 3, first = sj.r * j.seg_bytes;
-  const bool ok = n_iter[sj.iter_idx] <= (int)j.num_max_iter;
+  /* A transport block with a failed segment is lost as a whole: its siblings may have given up half way (the abort flag
+   * is final here, every decoder workgroup has finished), so what it delivers is defined as all-zero bytes. */
+  const bool ok = n_iter[sj.iter_idx] <= (int)j.num_max_iter && !(tb_abort && tb_abort[sj.tb]);
   const uint8_t *c = scratch + sj.c_off;
   uint32_t count = 0;
   if (first < bbytes)
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   }
 }
 __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_tb_job *jobs, uint32_t n_tb, const int32_t *n_iter,
-                                                                   uint32_t *acc, uint8_t *ack, int32_t *iter_max)
+                                                                   uint32_t *acc, int *tb_abort, uint8_t *ack, int32_t *iter_max)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tb)
@@ -332,7 +335,11 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_t
   /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
   ack[i] = (uint8_t)(all_ok && (j.C == 1 || acc[i] == 0));
   acc[i] = 0; /* left zero for the next call (see tb_tx_crc_final_kernel) */
-  iter_max[i] = imax;
+  if (tb_abort)
+    tb_abort[i] = 0;
+  /* a segment that gave up because a sibling had failed reports numMaxIter + 2 (decoder.c:556-559); which siblings get
+   * that far is a matter of timing, so the per-TB figure is capped at "failed" = numMaxIter + 1 */
+  iter_max[i] = imax > (int)j.num_max_iter + 1 ? (int)j.num_max_iter + 1 : imax;
 }
 
 #define TB_LAUNCH(kernel, n, s, ...)                                              \
@@ -376,11 +383,11 @@ hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int
 }
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,
-                                 uint32_t *acc, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s)
+                                 uint32_t *acc, int *tb_abort, const uint32_t *pow24a, const uint32_t *pow16, hipStream_t s)
 {
   if (n_tb == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(tb_rx_assemble_kernel, dim3(n_seg), dim3(TB_THREADS), 0, s, jobs, segs, n_iter, scratch, payload, acc, pow24a, pow16);
-  hipLaunchKernelGGL(tb_rx_verdict_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, n_iter, acc, ack, iter_max);
+  hipLaunchKernelGGL(tb_rx_assemble_kernel, dim3(n_seg), dim3(TB_THREADS), 0, s, jobs, segs, n_iter, scratch, payload, acc, tb_abort, pow24a, pow16);
+  hipLaunchKernelGGL(tb_rx_verdict_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, n_iter, acc, tb_abort, ack, iter_max);
   return hipGetLastError();
 }

@@ -45,6 +45,19 @@ class encoder_implemparams_t(C.Structure):
                 ("G", C.c_uint), ("rv", C.c_uint8)]
 
 
+class time_stats_t(C.Structure):
+    """common/utils/time_meas.h:61-74 (x86-64)"""
+    _fields_ = [("in_", C.c_longlong), ("diff", C.c_longlong), ("p_time", C.c_longlong), ("diff_square", C.c_double),
+                ("max", C.c_longlong), ("trials", C.c_int), ("meas_flag", C.c_int), ("meas_name", C.c_char_p),
+                ("meas_index", C.c_int), ("meas_enabled", C.c_int), ("tpoolmsg", C.c_void_p), ("tstatptr", C.c_void_p)]
+
+
+class t_nrLDPC_time_stats(C.Structure):
+    """nrLDPC_types.h:115-127"""
+    _fields_ = [(n, time_stats_t) for n in ("llr2llrProcBuf", "llr2CnProcBuf", "cnProc", "cnProcPc", "bnProcPc", "bnProc",
+                                            "cn2bnProcBuf", "bn2cnProcBuf", "llrRes2llrOut", "llr2bit", "total")]
+
+
 class decode_abort_t(C.Structure):
     """openair1/PHY/defs_common.h:998-1001 (pthread_mutex_t is 40 bytes on x86-64 glibc; all-zero = initialised)"""
     _fields_ = [("mutex_failure", C.c_uint64 * 5), ("failed", C.c_bool)]
@@ -67,7 +80,7 @@ _CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
 
 EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "LDPCdecoder_batch", "LDPCencoder_batch",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
-           "nrLDPC_hip_version"]
+           "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
 
 _lib = None
 
@@ -124,6 +137,15 @@ def LDPCshutdown():
     return load_library().LDPCshutdown()
 
 
+def server_stats():
+    """State of the resident submission path behind LDPCdecoder / LDPCencoder (nrLDPC_hip_server_stats)."""
+    L = load_library()
+    a = (C.c_int64 * 4)()
+    L.nrLDPC_hip_server_stats.argtypes = [C.POINTER(C.c_int64)]
+    L.nrLDPC_hip_server_stats(a)
+    return dict(status=int(a[0]), slots=int(a[1]), launches=int(a[2]), calls=int(a[3]))
+
+
 def num_llr(BG, Z, R):
     return NCOLS[(BG, R)] * Z
 
@@ -151,22 +173,23 @@ def make_dec_params(BG, Z, R, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_cr
     return p
 
 
-def LDPCdecoder(p_decParams, p_llr, p_out=None, ab=None, harq_pid=0, ulsch_id=0, C_=0):
+def LDPCdecoder(p_decParams, p_llr, p_out=None, ab=None, harq_pid=0, ulsch_id=0, C_=0, profiler=None):
     """One code block through the reference's own entry point (nrLDPC_decoder.c:172).
-    p_llr: int8[ncols*Z]; returns (numIter, p_out)."""
+    p_llr: int8[ncols*Z]; returns (numIter, p_out).  profiler: optional t_nrLDPC_time_stats."""
     L = load_library()
     p_llr = np.ascontiguousarray(p_llr, dtype=np.int8)
     nb = out_bytes(p_decParams.BG, p_decParams.Z, p_decParams.R, p_decParams.outMode)
     if p_out is None:
         p_out = np.zeros(nb, dtype=np.uint8)
-    n = L.LDPCdecoder(C.byref(p_decParams), harq_pid, ulsch_id, C_, p_llr.ctypes.data, p_out.ctypes.data, None,
+    n = L.LDPCdecoder(C.byref(p_decParams), harq_pid, ulsch_id, C_, p_llr.ctypes.data, p_out.ctypes.data,
+                      C.addressof(profiler) if profiler is not None else None,
                       C.addressof(ab) if ab is not None else None)
     if n < 0:
         raise RuntimeError(f"LDPCdecoder failed: {last_error()}")
     return n, p_out
 
 
-def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0):
+def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=None):
     """Up to 8 segments through the reference entry point (ldpc_encoder_optim8segmulti.c:46).
     inputs: list of uint8[K/8]; returns list of uint8[(66|50)*Zc] (one bit per byte) for ALL n_segments
     (entries outside this macro group are left zero)."""
@@ -180,6 +203,8 @@ def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0):
     op = (C.c_void_p * n_segments)(*[a.ctypes.data for a in outs])
     impp = encoder_implemparams_t(n_segments=n_segments, macro_num=macro_num, gen_code=0, Kr=K,
                                   Kb=kbf if Kb is None else Kb, Zc=Zc, BG=BG, K=K, E=K)
+    if meters is not None:      # four time_stats_t: tinput, tprep, tparity, toutput (nrLDPC_defs.h:44-47)
+        impp.tinput, impp.tprep, impp.tparity, impp.toutput = (C.addressof(m) for m in meters)
     rc = L.LDPCencoder(ip, op, C.byref(impp))
     _check(rc, "LDPCencoder")
     N = (66 if BG == 1 else 50) * Zc

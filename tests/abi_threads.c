@@ -5,7 +5,9 @@
  * returned single-threaded (outputs and pass counts), and reports calls per second.  Test infrastructure.
  *
  *   gcc -O2 -I include tests/abi_threads.c -o abi_threads -ldl -lpthread
- *   ./abi_threads <path/libldpc_hip.so> <threads> <calls per thread>
+ *   ./abi_threads <path/libldpc_hip.so> <threads> <calls per thread> [case]
+ * With a case index every call uses that one case (1 = BG1 Zc=384 R=1/3 at high SNR, 2 passes: the per-call latency
+ * figure that corresponds to `ldpctest -l 8448 -s10`'s "Decoding time mean").
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -17,6 +19,7 @@
 #include "nrLDPC_hip.h"
 
 typedef int32_t (*init_t)(void);
+typedef int32_t (*stats_t)(int64_t *);
 typedef int32_t (*dec_t)(t_nrLDPC_dec_params *, uint8_t, uint8_t, uint8_t, int8_t *, int8_t *, t_nrLDPC_time_stats *, decode_abort_t *);
 
 #define NCASE 12
@@ -31,7 +34,7 @@ static int8_t *llr[NCASE];
 static uint8_t *expect[NCASE];
 static int expect_iter[NCASE], out_len[NCASE];
 static t_nrLDPC_dec_params prm[NCASE];
-static int calls_per_thread;
+static int calls_per_thread, only_case = -1;
 static volatile int failures;
 
 static void *worker(void *arg)
@@ -39,7 +42,7 @@ static void *worker(void *arg)
   const int tid = (int)(long)arg;
   uint8_t *out = malloc(68 * 384);
   for (int i = 0; i < calls_per_thread; i++) {
-    const int c = (tid * 7 + i) % NCASE;
+    const int c = only_case >= 0 ? only_case : (tid * 7 + i) % NCASE;
     t_nrLDPC_dec_params p = prm[c];
     memset(out, 0xA5, out_len[c]);
     const int n = dec(&p, 0, 0, 0, llr[c], (int8_t *)out, NULL, NULL);
@@ -62,6 +65,7 @@ int main(int argc, char **argv)
   if (!init || !dec || init() != 0) { fprintf(stderr, "LDPCinit failed\n"); return 2; }
   const int T = atoi(argv[2]);
   calls_per_thread = atoi(argv[3]);
+  if (argc > 4) only_case = atoi(argv[4]) % NCASE;
   unsigned s = 12345;
   for (int c = 0; c < NCASE; c++) {
     const int BG = cases[c][0], Z = cases[c][1], R = cases[c][2], n = ncols(BG, R) * Z;
@@ -88,8 +92,12 @@ int main(int argc, char **argv)
   for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
   clock_gettime(CLOCK_MONOTONIC, &b);
   const double dt = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1e9;
-  printf("{\"threads\": %d, \"calls\": %d, \"seconds\": %.4f, \"calls_per_s\": %.0f, \"failures\": %d, \"iters\": [", T,
-         T * calls_per_thread, dt, T * calls_per_thread / dt, failures);
+  int64_t st[4] = {0, 0, 0, 0}; /* resident submission path: status, slots, kernel launches, calls served */
+  stats_t stats = (stats_t)dlsym(h, "nrLDPC_hip_server_stats");
+  if (stats) stats(st);
+  printf("{\"threads\": %d, \"calls\": %d, \"seconds\": %.4f, \"calls_per_s\": %.0f, \"failures\": %d, \"served\": %lld, "
+         "\"server_launches\": %lld, \"slots\": %lld, \"us_per_call_per_thread\": %.2f, \"iters\": [", T, T * calls_per_thread, dt,
+         T * calls_per_thread / dt, failures, (long long)st[3], (long long)st[2], (long long)st[1], dt / calls_per_thread * 1e6);
   for (int c = 0; c < NCASE; c++) printf("%d%s", expect_iter[c], c + 1 < NCASE ? ", " : "]}\n");
   return failures ? 1 : 0;
 }

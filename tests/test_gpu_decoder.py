@@ -220,8 +220,9 @@ def test_ldpctest_acceptance_and_seed_identical_bler(hip):
 
 def test_concurrent_callers_of_the_reference_entry_point(hip, tmp_path):
     """16 pthreads calling LDPCdecoder() at once with different codes / caps / stop modes (the reference's thread-pool
-    usage): every concurrent call must return what it returned single-threaded -- with per-thread streams (default)
-    and with call aggregation (NRLDPC_HIP_AGGREGATE=1)."""
+    usage): every concurrent call must return what it returned single-threaded -- through the resident server kernel
+    (default; 16 callers on 64 slots, then 16 callers sharing 4 slots) and with one launch per call
+    (NRLDPC_HIP_SERVER=0)."""
     import json
     import os
     import subprocess
@@ -230,9 +231,11 @@ def test_concurrent_callers_of_the_reference_entry_point(hip, tmp_path):
     exe = tmp_path / "abi_threads"
     subprocess.run(["gcc", "-O2", "-I", str(root / "include"), str(root / "tests" / "abi_threads.c"), "-o", str(exe),
                     "-ldl", "-lpthread"], check=True)
-    for agg in ("0", "1"):
-        env = dict(os.environ, NRLDPC_HIP_AGGREGATE=agg)
-        r = subprocess.run([str(exe), str(hip.ldpc.LIB_PATH), "16", "150"], capture_output=True, text=True, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
+    for extra in ({}, {"NRLDPC_HIP_SRV_SLOTS": "4", "NRLDPC_HIP_SRV_IDLE_US": "150"}, {"NRLDPC_HIP_SERVER": "0"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([str(exe), str(hip.ldpc.LIB_PATH), "16", "150"], capture_output=True, text=True, env=env,
+                           timeout=300)
+        assert r.returncode == 0, (extra, r.stderr[-2000:])
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        assert d["failures"] == 0 and d["calls"] == 2400
+        assert d["failures"] == 0 and d["calls"] == 2400, extra
+        assert d["served"] == (0 if extra.get("NRLDPC_HIP_SERVER") == "0" else 2400 + 12), (extra, d)
