@@ -219,9 +219,10 @@ int32_t nrLDPC_hip_lds_bytes(int BG, int Z, int R);    /* LDS a decoder workgrou
 /* info = {rows, columns, edges of the (BG, R) base graph; 1 if the fast decoder kernel serves the code; its workgroup
  * size; its LDS bytes; check-node and bit-node tasks per pass (fast kernel)}.  0, or -1 for an invalid code. */
 int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8]);
-/* resident submission path behind LDPCdecoder / LDPCencoder (csrc/ldpc_server.h): out = {status (-1 not started yet, 0 in
- * use, 1 switched off or unavailable), caller slots, server kernel launches so far, calls served through it} */
-int32_t nrLDPC_hip_server_stats(int64_t out[4]);
+/* resident submission path behind LDPCdecoder (csrc/ldpc_server.h): out = {status (-1 not started yet, 0 in use, 1 switched
+ * off or unavailable), caller slots, server kernel launches so far, calls served through it, and summed over those calls
+ * in ns: GPU doorbell-seen -> payload staged, staged -> decoded, host doorbell -> completion seen, whole host call} */
+int32_t nrLDPC_hip_server_stats(int64_t out[8]);
 const char *nrLDPC_hip_last_error(void);
 const char *nrLDPC_hip_version(void);
 

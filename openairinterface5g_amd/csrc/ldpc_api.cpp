@@ -177,6 +177,8 @@ const CodeEntry *get_code(int BG, int Z, int R)
     delete ce;
     return nullptr;
   }
+  if (getenv("NRLDPC_HIP_SRV_DEBUG"))
+    fprintf(stderr, "[libldpc_hip] code BG%d Z%d R%d: descriptors at %p (2 x %zu B)\n", BG, Z, R, (void *)ce->dev, sizeof(ldpc_code_desc_t));
   g.codes[key] = ce;
   g.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
   return ce;
@@ -410,10 +412,26 @@ int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8])
   return 0;
 }
 
-int32_t nrLDPC_hip_server_stats(int64_t out[4])
+int32_t nrLDPC_hip_server_stats(int64_t out[8])
 {
   if (!out)
     return -1;
+  out[4] = out[5] = out[6] = out[7] = 0;
+  if (getenv("NRLDPC_HIP_SRV_DEBUG")) {
+    uint64_t pro = 0, pas = 0, n = 0;
+    for (int i = 0; i < srv.n_slots; i++) {
+      pro += srv.slots[i].ticks_prologue; pas += srv.slots[i].ticks_passes; n += srv.slots[i].calls;
+    }
+    if (n)
+      fprintf(stderr, "[libldpc_hip] server, fast decoder per call (only meaningful when every call used it): prologue %.2f us, passes %.2f us\n",
+              pro / 100.0 / n, pas / 100.0 / n);
+  }
+  for (int i = 0; i < srv.n_slots; i++) {
+    out[4] += (int64_t)srv.slots[i].ticks_stage * 10;  /* ns: doorbell seen -> payload staged (GPU clock) */
+    out[5] += (int64_t)srv.slots[i].ticks_decode * 10; /* ns: payload staged -> block decoded */
+    out[6] += (int64_t)(srv.slots[i].host_wait_s * 1e9);  /* ns: doorbell rung -> completion seen (host clock) */
+    out[7] += (int64_t)(srv.slots[i].host_total_s * 1e9); /* ns: whole srv_decode call */
+  }
   out[0] = srv.status.load();
   out[1] = srv.n_slots;
   out[2] = srv.gen.load();

@@ -23,6 +23,7 @@ struct ldpc_block_io {
   const uint32_t *crc_pow; /* x^j mod g, left aligned */
   int out_mode;            /* 0 packed bits, else one bit per byte */
   int *tb_abort;           /* optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559) */
+  uint32_t *stamps = nullptr; /* optional (LDS): wall_clock64 after the prologue and after the last pass (server diagnostics) */
 };
 
 /* next ticket of a task queue (wave-uniform) */
@@ -116,6 +117,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   for (int i = tid + 4 * nt; i < n_ext; i += nt)
     e32[i] = src32[n_app + i] ^ 0x80808080u;
   __syncthreads();
+  if (io.stamps && tid == 0)
+    io.stamps[0] = (uint32_t)wall_clock64();
 
   /* ---- passes ------------------------------------------------------------------------------------------ */
   const int max_pass = io.max_pass;
@@ -216,6 +219,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       }
     }
   }
+  if (io.stamps && tid == 0)
+    io.stamps[1] = (uint32_t)wall_clock64();
   if (io.tb_abort && n_iter == max_pass && tid == 0) /* decoder.c:190-193: a failed segment gives the whole TB up */
     __hip_atomic_store(io.tb_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 

@@ -48,7 +48,10 @@ typedef struct srv_slot_ctl { /* 128 bytes: one cache line per direction */
   uint32_t pad0[15];
   uint32_t done;           /* GPU-written: the doorbell value whose results are complete */
   int32_t n_iter;
-  uint32_t pad1[14];
+  uint32_t t_seen, t_staged, t_decoded; /* wall_clock64 (100 MHz) stamps of the request just served: doorbell seen,
+                                           payload staged, block function returned (diagnostics, nrLDPC_hip_server_stats) */
+  uint32_t t_prologue, t_passes; /* fast decoder only: state in LDS (first barrier passed), last pass finished */
+  uint32_t pad1[9];
 } srv_slot_ctl;
 
 typedef struct srv_gctl {  /* device memory, shared by the workgroups of a generation */

@@ -18,8 +18,15 @@
 #include "ldpc_dec_generic_block.h"
 #include "ldpc_enc_packed_core.h"
 
-#define SRV_THREADS 1024
-#define SRV_ENC_GROUP 128 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
+/* 12 waves: 168 VGPRs per lane, which is what the loop below needs to hold the fast decoder (127 VGPRs on its own)
+ * without spilling -- a resident kernel had better not depend on scratch memory.  With 16 waves (128 VGPRs) it spills
+ * 36-45 registers; with the encoder's phases compiled in as well (SRV_WITH_ENCODER) 7 even at 12 waves, so LDPCencoder
+ * calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
+#define SRV_THREADS 768
+#define SRV_ENC_GROUP 96 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
+#ifndef SRV_WITH_ENCODER
+#define SRV_WITH_ENCODER 0
+#endif
 
 __device__ __forceinline__ uint32_t srv_ld_sys(const uint32_t *p)
 {
@@ -30,107 +37,51 @@ __device__ __forceinline__ void srv_st_sys(uint32_t *p, uint32_t v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-/* Out of line on purpose: each body gets the register allocation it has in its own batch kernel (the fast decoder sits
- * at 127 of the 128 VGPRs a 1024-thread workgroup may use; inlined next to the server loop's live values it spills). */
-/* arguments of a non-kernel function arrive in VGPRs: make the wave-uniform ones scalar again, so that everything
- * derived from the descriptor stays in SGPRs / s_load as in the batch kernels */
-template <typename T> __device__ __forceinline__ T *srv_uniform_ptr(T *p)
-{
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  return reinterpret_cast<T *>(((uint64_t)LDPC_UNIFORM((uint32_t)(v >> 32)) << 32) | LDPC_UNIFORM((uint32_t)v));
-}
-__device__ __forceinline__ ldpc_code_ptr_t srv_uniform_code(uint64_t v)
-{
-  return (ldpc_code_ptr_t)(((uint64_t)LDPC_UNIFORM((uint32_t)(v >> 32)) << 32) | LDPC_UNIFORM((uint32_t)v));
-}
-__device__ __noinline__ int srv_dec_fast(uint64_t code_addr, const uint32_t *src32, int8_t *out, int max_pass, int use_crc, int crcE,
-                                         const uint32_t *crc_pow, int out_mode)
-{
-  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  ldpc_block_io io;
-  io.src32 = srv_uniform_ptr(src32);
-  io.out = srv_uniform_ptr(out);
-  io.max_pass = LDPC_UNIFORM(max_pass);
-  io.use_crc = LDPC_UNIFORM(use_crc);
-  io.crcE = LDPC_UNIFORM(crcE);
-  io.crc_pow = srv_uniform_ptr(crc_pow);
-  io.out_mode = LDPC_UNIFORM(out_mode);
-  io.tb_abort = nullptr;
-  return ldpc_dec_fast_block(fsm, srv_uniform_code(code_addr), io);
-}
-__device__ __noinline__ int srv_dec_generic(uint64_t code_addr, const int8_t *llr, int8_t *out, int max_pass, int use_crc, int crcE,
-                                            const uint32_t *crc_pow, int out_mode)
-{
-  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  ldpc_gblock_io io;
-  io.llr = srv_uniform_ptr(llr);
-  io.out = srv_uniform_ptr(out);
-  io.max_pass = LDPC_UNIFORM(max_pass);
-  io.use_crc = LDPC_UNIFORM(use_crc);
-  io.crcE = LDPC_UNIFORM(crcE);
-  io.crc_pow = srv_uniform_ptr(crc_pow);
-  io.out_mode = LDPC_UNIFORM(out_mode);
-  io.tb_abort = nullptr;
-  return ldpc_dec_generic_block(reinterpret_cast<int8_t *>(fsm), srv_uniform_code(code_addr), io);
-}
-__device__ __noinline__ void srv_encode(uint64_t code_addr, const uint8_t *payload_, uint8_t *hout_, int n_seg_, int Kb_,
-                                        uint32_t seg_in_stride_, uint32_t seg_out_stride_)
-{
-  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  ldpc_code_ptr_t code = srv_uniform_code(code_addr);
-  const uint8_t *payload = srv_uniform_ptr(payload_);
-  uint8_t *hout = srv_uniform_ptr(hout_);
-  const int n_seg = LDPC_UNIFORM(n_seg_), Kb = LDPC_UNIFORM(Kb_);
-  const uint32_t seg_in_stride = LDPC_UNIFORM(seg_in_stride_), seg_out_stride = LDPC_UNIFORM(seg_out_stride_);
-  /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases */
-  const int tid = threadIdx.x, grp = tid / SRV_ENC_GROUP, gt = tid - grp * SRV_ENC_GROUP;
-  const int words = ldpc_encp_lds_words(code->ncols, code->kb_full, code->Z, code->nrows, code->nedges);
-  ldpc_encp_lds L;
-  ldpc_encp_carve(reinterpret_cast<uint32_t *>(fsm) + (size_t)grp * ((words + 3) & ~3), code, L);
-  const uint8_t *in = payload + (size_t)grp * seg_in_stride;
-  uint8_t *out = hout + (size_t)grp * seg_out_stride;
-  for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++) {
-    if (grp < n_seg)
-      ldpc_encp_phase(ph, code, Kb, in, L, out, gt, SRV_ENC_GROUP);
-    __syncthreads();
-  }
-}
+/* The server loop keeps next to nothing live across a decode: the kernel arguments are re-read from the kernarg segment
+ * (scalar loads) where they are needed, the loop state sits in LDS.  Inlined next to a loop with its own live values
+ * the fast decoder -- 127 of the 128 VGPRs a 1024-thread workgroup may use -- would spill; out of line it would need a
+ * stack.  Either way scratch memory, which a resident kernel had better not depend on. */
+typedef const srv_args LDPC_CONST_AS *srv_args_ptr_t;
 
-__global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args a)
+__global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  uint32_t *bc = reinterpret_cast<uint32_t *>(fsm + SRV_BC_OFF); /* [0] doorbell / quit, [4..19] request header */
-  const int tid = threadIdx.x, w = blockIdx.x;
-  srv_slot_ctl *slot = a.ctl + w;
-  const uint4 *hin = reinterpret_cast<const uint4 *>(a.in_host + (size_t)w * SRV_IN_STRIDE);
-  uint4 *stg = reinterpret_cast<uint4 *>(a.staging + (size_t)w * SRV_IN_STRIDE);
-  uint8_t *hout = a.out_host + (size_t)w * SRV_OUT_STRIDE;
-  uint32_t last = 0;
-  if (tid == 0) {
-    last = srv_ld_sys(&slot->done); /* a request the previous generation left unserved shows as doorbell != done */
-    if (w == 0) {
-      atomicMax(&a.gctl->last_activity, (long long)wall_clock64());
-      srv_st_sys(a.state, 2u * a.gen + 1u);
+  uint32_t *bc = reinterpret_cast<uint32_t *>(fsm + SRV_BC_OFF); /* [0] doorbell / quit, [1] last served, [2], [3] time stamps, [4..19] request header */
+  /* laundered wherever it is used: the loads behind it must not be hoisted out of the loop and kept live */
+#define SRV_ARGS() ({ uint64_t p_ = args_u64; asm volatile("" : "+s"(p_)); (srv_args_ptr_t)p_; })
+  (void)args_by_value; /* = the kernarg segment, read through the laundered pointer */
+  const uint64_t args_u64 = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  srv_args_ptr_t a = SRV_ARGS();
+  if (threadIdx.x == 0) {
+    srv_slot_ctl *slot = a->ctl + blockIdx.x;
+    bc[1] = srv_ld_sys(&slot->done); /* a request the previous generation left unserved shows as doorbell != done */
+    if (blockIdx.x == 0) {
+      atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
+      srv_st_sys(a->state, 2u * a->gen + 1u);
     }
   }
   for (;;) {
-    if (tid == 0) {
+    a = SRV_ARGS();
+    if (threadIdx.x == 0) {
+      srv_slot_ctl *slot = a->ctl + blockIdx.x;
+      const uint32_t last = bc[1], gen = a->gen;
+      const int w = blockIdx.x;
       uint32_t d;
       for (;;) {
         /* both host words are requested before either is looked at: one PCIe round trip per poll */
         d = srv_ld_sys(&slot->doorbell);
-        const uint32_t hs = w == 0 ? srv_ld_sys(a.host_stop) : 0u;
+        const uint32_t hs = w == 0 ? srv_ld_sys(a->host_stop) : 0u;
         if (d != last)
           break;
-        if (__hip_atomic_load(&a.gctl->stopping_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.gen) {
+        if (__hip_atomic_load(&a->gctl->stopping_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
           d = 0xffffffffu;
           break;
         }
         if (w == 0) { /* workgroup 0 decides for everybody: host request, or nobody has called for idle_ticks */
           const long long idle = (long long)wall_clock64() -
-                                 __hip_atomic_load(&a.gctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (hs == a.gen || idle > (long long)a.idle_ticks) {
-            __hip_atomic_store(&a.gctl->stopping_gen, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                 __hip_atomic_load(&a->gctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (hs == gen || idle > (long long)a->idle_ticks) {
+            __hip_atomic_store(&a->gctl->stopping_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d = 0xffffffffu;
             break;
           }
@@ -138,6 +89,7 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
         __builtin_amdgcn_s_sleep(4);
       }
       bc[0] = d;
+      bc[2] = (uint32_t)wall_clock64();
     }
     __syncthreads();
     const uint32_t d = bc[0];
@@ -145,9 +97,12 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
       break;
     /* the host wrote [header | payload] before the doorbell: order our loads behind the doorbell load */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const uint32_t n16 = d & 0xfffu;
+    a = SRV_ARGS();
     {
-      const uint32_t i0 = (uint32_t)tid, i1 = (uint32_t)tid + SRV_THREADS;
+      const uint32_t n16 = d & 0xfffu;
+      const uint4 *hin = reinterpret_cast<const uint4 *>(a->in_host + (size_t)blockIdx.x * SRV_IN_STRIDE);
+      uint4 *stg = reinterpret_cast<uint4 *>(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
+      const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + SRV_THREADS;
       uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
       if (i0 < n16)
         v0 = hin[i0];
@@ -157,39 +112,86 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
         stg[i0] = v0;
       if (i1 < n16)
         stg[i1] = v1;
-      if (tid < 4)
-        reinterpret_cast<uint4 *>(bc + 4)[tid] = v0;
+      if (threadIdx.x < 4)
+        reinterpret_cast<uint4 *>(bc + 4)[threadIdx.x] = v0;
     }
     __threadfence(); /* the staged payload is re-read by other waves of this workgroup through L1 / L2 */
     __syncthreads();
+    a = SRV_ARGS();
+    if (threadIdx.x == 0)
+      bc[3] = (uint32_t)wall_clock64();
     const srv_req *rq = reinterpret_cast<const srv_req *>(bc + 4);
-    const uint32_t kind = rq->kind;
-    const uint64_t code_addr = rq->code;
-    const uint8_t *payload = reinterpret_cast<const uint8_t *>(stg) + SRV_REQ_BYTES;
-    const uint32_t *crc_pow = a.crc_pow_tbl[rq->crc_type & 3u];
+    const uint32_t kind = LDPC_UNIFORM(rq->kind);
+    /* (readfirstlane returns int: widen as unsigned, or a low dword >= 2^31 smears ones over the high dword) */
+    ldpc_code_ptr_t code = (ldpc_code_ptr_t)(((uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)(rq->code >> 32)) << 32) |
+                                             (uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)rq->code));
+    const uint8_t *payload = a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE + SRV_REQ_BYTES;
+    uint8_t *hout = a->out_host + (size_t)blockIdx.x * SRV_OUT_STRIDE;
     int n_iter = 0;
-    if (kind == SRV_KIND_DEC_FAST)
-      n_iter = srv_dec_fast(code_addr, reinterpret_cast<const uint32_t *>(payload), reinterpret_cast<int8_t *>(hout), (int)rq->max_pass,
-                            (int)rq->use_crc, (int)rq->crcE, crc_pow, (int)rq->out_mode);
-    else if (kind == SRV_KIND_DEC_GENERIC)
-      n_iter = srv_dec_generic(code_addr, reinterpret_cast<const int8_t *>(payload), reinterpret_cast<int8_t *>(hout), (int)rq->max_pass,
-                               (int)rq->use_crc, (int)rq->crcE, crc_pow, (int)rq->out_mode);
-    else if (kind == SRV_KIND_ENC)
-      srv_encode(code_addr, payload, hout, (int)rq->n_seg, (int)rq->Kb, rq->seg_in_stride, rq->seg_out_stride);
+    if (kind == SRV_KIND_DEC_FAST) {
+      ldpc_block_io io;
+      io.src32 = reinterpret_cast<const uint32_t *>(payload);
+      io.out = reinterpret_cast<int8_t *>(hout);
+      io.max_pass = LDPC_UNIFORM((int)rq->max_pass);
+      io.use_crc = LDPC_UNIFORM((int)rq->use_crc);
+      io.crcE = LDPC_UNIFORM((int)rq->crcE);
+      io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u];
+      io.out_mode = LDPC_UNIFORM((int)rq->out_mode);
+      io.tb_abort = nullptr;
+      io.stamps = bc + 24;
+      n_iter = ldpc_dec_fast_block(fsm, code, io);
+    } else if (kind == SRV_KIND_DEC_GENERIC) {
+      ldpc_gblock_io io;
+      io.llr = reinterpret_cast<const int8_t *>(payload);
+      io.out = reinterpret_cast<int8_t *>(hout);
+      io.max_pass = LDPC_UNIFORM((int)rq->max_pass);
+      io.use_crc = LDPC_UNIFORM((int)rq->use_crc);
+      io.crcE = LDPC_UNIFORM((int)rq->crcE);
+      io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u];
+      io.out_mode = LDPC_UNIFORM((int)rq->out_mode);
+      io.tb_abort = nullptr;
+      n_iter = ldpc_dec_generic_block(reinterpret_cast<int8_t *>(fsm), code, io);
+    } else if (SRV_WITH_ENCODER && kind == SRV_KIND_ENC) {
+      /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases */
+      const int tid = threadIdx.x, grp = tid / SRV_ENC_GROUP, gt = tid - grp * SRV_ENC_GROUP;
+      const int n_seg = LDPC_UNIFORM((int)rq->n_seg), Kb = LDPC_UNIFORM((int)rq->Kb);
+      const int words = ldpc_encp_lds_words(code->ncols, code->kb_full, code->Z, code->nrows, code->nedges);
+      ldpc_encp_lds L;
+      ldpc_encp_carve(reinterpret_cast<uint32_t *>(fsm) + (size_t)grp * ((words + 3) & ~3), code, L);
+      const uint8_t *in = payload + (size_t)grp * LDPC_UNIFORM(rq->seg_in_stride);
+      uint8_t *out = hout + (size_t)grp * LDPC_UNIFORM(rq->seg_out_stride);
+      for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++) {
+        if (grp < n_seg)
+          ldpc_encp_phase(ph, code, Kb, in, L, out, gt, SRV_ENC_GROUP);
+        __syncthreads();
+      }
+    }
     /* results -> host, then the completion word: every thread's stores are out before thread 0 rings */
+    const uint32_t t_decoded = (uint32_t)wall_clock64();
     __threadfence_system();
     __syncthreads();
-    if (tid == 0) {
+    a = SRV_ARGS();
+    if (threadIdx.x == 0) {
+      srv_slot_ctl *slot = a->ctl + blockIdx.x;
       srv_st_sys(reinterpret_cast<uint32_t *>(&slot->n_iter), (uint32_t)n_iter);
+      srv_st_sys(&slot->t_seen, bc[2]);
+      srv_st_sys(&slot->t_staged, bc[3]);
+      srv_st_sys(&slot->t_decoded, t_decoded);
+      srv_st_sys(&slot->t_prologue, bc[24]);
+      srv_st_sys(&slot->t_passes, bc[25]);
       __hip_atomic_store(&slot->done, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      atomicMax(&a.gctl->last_activity, (long long)wall_clock64());
-      last = d;
+      atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
+      bc[1] = d;
     }
   }
   /* workgroup 0 publishes "stopped": a caller that sees it relaunches on the same stream, i.e. behind this generation */
-  if (tid == 0 && w == 0)
-    srv_st_sys(a.state, 2u * a.gen + 2u);
+  a = SRV_ARGS();
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    srv_st_sys(a->state, 2u * a->gen + 2u);
+#undef SRV_ARGS
 }
+
+int ldpc_server_has_encoder(void) { return SRV_WITH_ENCODER; }
 
 hipError_t ldpc_server_init(void)
 {

@@ -14,10 +14,12 @@
  */
 #include <atomic>
 #include <sched.h>
+#include <time.h>
 #include "ldpc_server.h"
 
 hipError_t ldpc_server_init(void);
 hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream);
+int ldpc_server_has_encoder(void);
 
 namespace {
 
@@ -28,6 +30,9 @@ struct alignas(64) SrvSlotHost {
   std::atomic<uint32_t> busy{0};
   uint32_t seq = 0;
   uint64_t calls = 0; /* written by the slot's holder only */
+  uint64_t ticks_stage = 0, ticks_decode = 0; /* GPU-side: doorbell seen -> payload staged -> block function returned */
+  uint64_t ticks_prologue = 0, ticks_passes = 0; /* fast decoder: staged -> state in LDS -> last pass done */
+  double host_wait_s = 0, host_total_s = 0;   /* host-side: doorbell rung -> completion seen; whole call */
 };
 
 struct Server {
@@ -96,6 +101,11 @@ int srv_init_locked()
   int lo = 0, hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIP_TRY(hipStreamCreateWithPriority(&srv.stream, hipStreamNonBlocking, hi));
+  if (getenv("NRLDPC_HIP_SRV_DEBUG"))
+    fprintf(stderr, "[libldpc_hip] server: %d slots, ctl %p in %p out %p state %p | staging %p (%zu B) gctl %p crc_pow %p %p %p %p\n", n,
+            (void *)a.ctl, (const void *)a.in_host, (void *)a.out_host, (void *)a.state, (void *)a.staging, (size_t)n * SRV_IN_STRIDE,
+            (void *)a.gctl, (const void *)a.crc_pow_tbl[0], (const void *)a.crc_pow_tbl[1], (const void *)a.crc_pow_tbl[2],
+            (const void *)a.crc_pow_tbl[3]);
   srv.slots = new SrvSlotHost[n];
   srv.n_slots = n;
   atexit(srv_stop_at_exit); /* registered after the HIP runtime's own handlers, hence run before them */
@@ -155,6 +165,13 @@ void srv_stop_at_exit() { srv_stop(); }
 
 thread_local int tls_srv_slot = -1;
 
+inline double srv_now()
+{
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
 struct SrvCall {
   int slot;
   uint8_t *in, *out;
@@ -186,6 +203,7 @@ int srv_submit(const SrvCall &c, size_t payload_bytes, int32_t *n_iter)
   h.calls++;
   const uint32_t n16 = (uint32_t)((SRV_REQ_BYTES + payload_bytes + 15) / 16);
   const uint32_t db = (h.seq << 12) | n16;
+  const double t_ring = srv_now();
   __atomic_store_n(&c.ctl->doorbell, db, __ATOMIC_SEQ_CST); /* header and payload are ordered before it */
   for (uint32_t spins = 0;; spins++) {
     if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == db)
@@ -197,8 +215,13 @@ int srv_submit(const SrvCall &c, size_t payload_bytes, int32_t *n_iter)
     else
       sched_yield(); /* callers outnumber cores on a loaded box: give the others the CPU while the GPU works */
   }
+  h.host_wait_s += srv_now() - t_ring;
   if (n_iter)
     *n_iter = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
+  h.ticks_stage += (uint32_t)(c.ctl->t_staged - c.ctl->t_seen);
+  h.ticks_decode += (uint32_t)(c.ctl->t_decoded - c.ctl->t_staged);
+  h.ticks_prologue += (uint32_t)(c.ctl->t_prologue - c.ctl->t_staged);
+  h.ticks_passes += (uint32_t)(c.ctl->t_passes - c.ctl->t_prologue);
   return 0;
 }
 
@@ -219,6 +242,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   const int out_mode = a.out_mode, ob = out_bytes_of(hl, out_mode);
   if (SRV_REQ_BYTES + (size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob > SRV_OUT_STRIDE)
     return 1;
+  const double t_call = srv_now();
   const SrvCall c = srv_acquire();
   srv_req *rq = reinterpret_cast<srv_req *>(c.in);
   memset(rq, 0, sizeof(*rq));
@@ -237,6 +261,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
     if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
       memcpy(out, c.out, (size_t)ob);
   }
+  srv.slots[c.slot].host_total_s += srv_now() - t_call;
   srv_release(c);
   return rc;
 }
@@ -249,7 +274,7 @@ int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, u
   const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
   const size_t in_stride = align_up((size_t)in_bytes + 8, 16), out_stride = align_up((size_t)N, 16);
   const size_t lds = (size_t)4 * ((ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z, hc.nrows, hc.nedges) + 3) & ~3) * 8;
-  if (n > 8 || SRV_REQ_BYTES + in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
+  if (!ldpc_server_has_encoder() || n > 8 || SRV_REQ_BYTES + in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
     return 1;
   const SrvCall c = srv_acquire();
   srv_req *rq = reinterpret_cast<srv_req *>(c.in);

@@ -140,10 +140,11 @@ def LDPCshutdown():
 def server_stats():
     """State of the resident submission path behind LDPCdecoder / LDPCencoder (nrLDPC_hip_server_stats)."""
     L = load_library()
-    a = (C.c_int64 * 4)()
+    a = (C.c_int64 * 8)()
     L.nrLDPC_hip_server_stats.argtypes = [C.POINTER(C.c_int64)]
     L.nrLDPC_hip_server_stats(a)
-    return dict(status=int(a[0]), slots=int(a[1]), launches=int(a[2]), calls=int(a[3]))
+    return dict(status=int(a[0]), slots=int(a[1]), launches=int(a[2]), calls=int(a[3]), gpu_stage_ns=int(a[4]),
+                gpu_decode_ns=int(a[5]), host_wait_ns=int(a[6]), host_call_ns=int(a[7]))
 
 
 def num_llr(BG, Z, R):

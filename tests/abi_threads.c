@@ -20,6 +20,7 @@
 
 typedef int32_t (*init_t)(void);
 typedef int32_t (*stats_t)(int64_t *);
+typedef int32_t (*batch_t)(const nrLDPC_hip_dec_batch_t *);
 typedef int32_t (*dec_t)(t_nrLDPC_dec_params *, uint8_t, uint8_t, uint8_t, int8_t *, int8_t *, t_nrLDPC_time_stats *, decode_abort_t *);
 
 #define NCASE 12
@@ -36,6 +37,8 @@ static int expect_iter[NCASE], out_len[NCASE];
 static t_nrLDPC_dec_params prm[NCASE];
 static int calls_per_thread, only_case = -1;
 static volatile int failures;
+static int progress;
+static struct timespec t_start;
 
 static void *worker(void *arg)
 {
@@ -45,6 +48,11 @@ static void *worker(void *arg)
     const int c = only_case >= 0 ? only_case : (tid * 7 + i) % NCASE;
     t_nrLDPC_dec_params p = prm[c];
     memset(out, 0xA5, out_len[c]);
+    if (progress && i % 100 == 0) {
+      struct timespec t;
+      clock_gettime(CLOCK_MONOTONIC, &t);
+      fprintf(stderr, "thread %d call %d at %.3f ms\n", tid, i, (t.tv_sec - t_start.tv_sec) * 1e3 + (t.tv_nsec - t_start.tv_nsec) / 1e6);
+    }
     const int n = dec(&p, 0, 0, 0, llr[c], (int8_t *)out, NULL, NULL);
     if (n != expect_iter[c] || memcmp(out, expect[c], out_len[c]) != 0) {
       __sync_fetch_and_add(&failures, 1);
@@ -63,10 +71,24 @@ int main(int argc, char **argv)
   init_t init = (init_t)dlsym(h, "LDPCinit");
   dec = (dec_t)dlsym(h, "LDPCdecoder");
   if (!init || !dec || init() != 0) { fprintf(stderr, "LDPCinit failed\n"); return 2; }
+  progress = getenv("ABI_PROGRESS") != NULL;
+  clock_gettime(CLOCK_MONOTONIC, &t_start);
   const int T = atoi(argv[2]);
   calls_per_thread = atoi(argv[3]);
   if (argc > 4) only_case = atoi(argv[4]) % NCASE;
   unsigned s = 12345;
+  if (getenv("ABI_WARM")) { /* build every code's descriptor before the first per-segment call */
+    batch_t batch = (batch_t)dlsym(h, "LDPCdecoder_batch");
+    for (int c = 0; c < NCASE; c++) {
+      nrLDPC_hip_dec_batch_t b;
+      int8_t dummy[16];
+      int32_t it;
+      memset(&b, 0, sizeof(b));
+      b.params.BG = cases[c][0]; b.params.Z = cases[c][1]; b.params.R = cases[c][2]; b.params.numMaxIter = 1;
+      b.llr = dummy; b.out = dummy; b.n_iter = &it; b.llr_stride = 68 * 384; b.out_stride = 68 * 384;
+      batch(&b);
+    }
+  }
   for (int c = 0; c < NCASE; c++) {
     const int BG = cases[c][0], Z = cases[c][1], R = cases[c][2], n = ncols(BG, R) * Z;
     llr[c] = aligned_alloc(64, (n + 63) / 64 * 64);
@@ -92,12 +114,15 @@ int main(int argc, char **argv)
   for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
   clock_gettime(CLOCK_MONOTONIC, &b);
   const double dt = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1e9;
-  int64_t st[4] = {0, 0, 0, 0}; /* resident submission path: status, slots, kernel launches, calls served */
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* resident submission path: status, slots, kernel launches, calls served, ns sums */
   stats_t stats = (stats_t)dlsym(h, "nrLDPC_hip_server_stats");
   if (stats) stats(st);
   printf("{\"threads\": %d, \"calls\": %d, \"seconds\": %.4f, \"calls_per_s\": %.0f, \"failures\": %d, \"served\": %lld, "
-         "\"server_launches\": %lld, \"slots\": %lld, \"us_per_call_per_thread\": %.2f, \"iters\": [", T, T * calls_per_thread, dt,
-         T * calls_per_thread / dt, failures, (long long)st[3], (long long)st[2], (long long)st[1], dt / calls_per_thread * 1e6);
+         "\"server_launches\": %lld, \"slots\": %lld, \"us_per_call_per_thread\": %.2f, \"srv_us\": {\"gpu_stage\": %.2f, \"gpu_decode\": %.2f, "
+         "\"host_wait\": %.2f, \"host_call\": %.2f}, \"iters\": [", T, T * calls_per_thread, dt,
+         T * calls_per_thread / dt, failures, (long long)st[3], (long long)st[2], (long long)st[1], dt / calls_per_thread * 1e6,
+         st[3] ? st[4] / 1e3 / st[3] : 0.0, st[3] ? st[5] / 1e3 / st[3] : 0.0, st[3] ? st[6] / 1e3 / st[3] : 0.0,
+         st[3] ? st[7] / 1e3 / st[3] : 0.0);
   for (int c = 0; c < NCASE; c++) printf("%d%s", expect_iter[c], c + 1 < NCASE ? ", " : "]}\n");
   return failures ? 1 : 0;
 }
