@@ -22,8 +22,11 @@
  * without spilling -- a resident kernel had better not depend on scratch memory.  With 16 waves (128 VGPRs) it spills
  * 36-45 registers; with the encoder's phases compiled in as well (SRV_WITH_ENCODER) 7 even at 12 waves, so LDPCencoder
  * calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
+#ifndef SRV_THREADS
 #define SRV_THREADS 768
+#endif
 #define SRV_ENC_GROUP 96 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
+#define SRV_FETCH ((SRV_IN_STRIDE / 16 + SRV_THREADS - 1) / SRV_THREADS)
 #ifndef SRV_WITH_ENCODER
 #define SRV_WITH_ENCODER 0
 #endif
@@ -102,16 +105,23 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
       const uint32_t n16 = d & 0xfffu;
       const uint4 *hin = reinterpret_cast<const uint4 *>(a->in_host + (size_t)blockIdx.x * SRV_IN_STRIDE);
       uint4 *stg = reinterpret_cast<uint4 *>(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
-      const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + SRV_THREADS;
-      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-      if (i0 < n16)
-        v0 = hin[i0];
-      if (i1 < n16)
-        v1 = hin[i1];
-      if (i0 < n16)
-        stg[i0] = v0;
-      if (i1 < n16)
-        stg[i1] = v1;
+      /* SRV_FETCH loads per thread, all in flight together: SRV_FETCH * SRV_THREADS * 16 bytes >= SRV_IN_STRIDE */
+      static_assert((size_t)SRV_FETCH * SRV_THREADS * 16 >= SRV_IN_STRIDE, "a request must fit the fetch");
+      uint4 v[SRV_FETCH];
+#pragma unroll
+      for (int k = 0; k < SRV_FETCH; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * SRV_THREADS;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (i < n16)
+          v[k] = hin[i];
+      }
+#pragma unroll
+      for (int k = 0; k < SRV_FETCH; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * SRV_THREADS;
+        if (i < n16)
+          stg[i] = v[k];
+      }
+      const uint4 v0 = v[0];
       if (threadIdx.x < 4)
         reinterpret_cast<uint4 *>(bc + 4)[threadIdx.x] = v0;
     }

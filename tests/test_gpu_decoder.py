@@ -110,6 +110,46 @@ def test_reference_entry_point_and_abort(hip):
     assert n == n_ref and np.array_equal(out, out_ref)
 
 
+def test_per_segment_entry_point_every_code_and_mode(hip):
+    """LDPCdecoder() -- served by the resident kernel through the caller's mailbox (csrc/ldpc_server.h) -- for every
+    lifting size and decoder-rate mode of both base graphs, every output mode, parity-check and CRC stop, several
+    iteration caps: output bytes and pass counts equal the oracle's, and the calls really went through the server."""
+    rng = np.random.default_rng(2024)
+    before = hip.ldpc.server_stats()
+    n_calls = 0
+    for BG in (1, 2):
+        for Z in O.LIFT_SIZES:
+            for R in ALL_RATES[BG]:
+                for kind in (-1.0, 1.5, "rand"):
+                    llr = make_llr(rng, BG, Z, R, kind)
+                    p = hip.make_dec_params(BG, Z, R, 8)
+                    n, out = hip.LDPCdecoder(p, llr, p_out=np.full(hip.ldpc.out_bytes(BG, Z, R), 0x33, np.uint8))
+                    n_ref, out_ref = O.decode(BG, Z, R, llr, 8, out_init=0x33)
+                    assert n == n_ref and np.array_equal(out, out_ref), (BG, Z, R, kind, n, n_ref)
+                    n_calls += 1
+    for (BG, Z, R, ct) in [(1, 384, 13, 1), (1, 176, 23, 1), (2, 64, 15, 1), (2, 208, 13, 0), (2, 16, 23, 2), (1, 8, 89, 1),
+                           (1, 6, 13, 1)]:
+        K = kbits(BG, Z)
+        for it in (0, 1, 2, 3, 8, 20):
+            for kind in (-2.0, 0.0, 2.0, "sat"):
+                info = random_info(rng, BG, Z, with_crc24b=(ct == 1))
+                llr = make_llr(rng, BG, Z, R, kind, info)
+                for mode in (0, 1, 2):
+                    p = hip.make_dec_params(BG, Z, R, it, outMode=mode)
+                    n, out = hip.LDPCdecoder(p, llr, p_out=np.full(hip.ldpc.out_bytes(BG, Z, R, mode), 0x33, np.uint8))
+                    n_ref, out_ref = O.decode(BG, Z, R, llr, it, mode, out_init=0x33)
+                    assert n == n_ref and np.array_equal(out, out_ref), (BG, Z, R, it, kind, mode)
+                    n_calls += 1
+                if K % 8 == 0:
+                    p = hip.make_dec_params(BG, Z, R, it, check_crc=True, E=K, crc_type=ct)
+                    n, out = hip.LDPCdecoder(p, llr, p_out=np.full(hip.ldpc.out_bytes(BG, Z, R), 0x33, np.uint8))
+                    n_ref, out_ref = O.decode(BG, Z, R, llr, it, 0, True, K, ct, out_init=0x33)
+                    assert n == n_ref and np.array_equal(out, out_ref), (BG, Z, R, it, kind, "crc")
+                    n_calls += 1
+    after = hip.ldpc.server_stats()
+    assert after["status"] == 0 and after["calls"] - before["calls"] == n_calls, (before, after, n_calls)
+
+
 def test_bad_parameters(hip):
     with pytest.raises(RuntimeError):
         hip.decode_batch_host(1, 17, 13, np.zeros((1, 68 * 17), np.int8))       # 17 is not a lifting size
