@@ -15,16 +15,18 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_core.h"
 
-struct ldpc_block_io {
-  const uint32_t *src32;   /* the block's channel LLRs: ncols*Z int8, 4-byte aligned, device memory (re-read every pass) */
-  int8_t *out;             /* output row (packed bits: 4-byte aligned) */
-  int max_pass;            /* numMaxIter + 1 */
-  int use_crc, crcE;       /* CRC stop mode and the bits it covers */
-  const uint32_t *crc_pow; /* x^j mod g, left aligned */
-  int out_mode;            /* 0 packed bits, else one bit per byte */
-  int *tb_abort;           /* optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559) */
-  uint32_t *stamps = nullptr; /* optional (LDS): wall_clock64 after the prologue and after the last pass (server diagnostics) */
-};
+/* The caller's view of a block is a type IO with these (wave-uniform) accessors, evaluated where the value is needed --
+ * not up front -- so that what is only used after the last pass (output row, CRC table) or once per pass (abort flag)
+ * is not carried in registers through the check-node loops (the kernel sits at the VGPR limit and already keeps part of
+ * its scalar state in VGPR lanes):
+ *   const uint32_t *src32()   the block's channel LLRs: ncols*Z int8, 4-byte aligned, device memory (re-read every pass)
+ *   int8_t *out()             output row (packed bits: 4-byte aligned)
+ *   int max_pass()            numMaxIter + 1
+ *   int use_crc(), crcE()     CRC stop mode and the bits it covers
+ *   const uint32_t *crc_pow() x^j mod g, left aligned
+ *   int out_mode()            0 packed bits, else one bit per byte
+ *   int *tb_abort()           optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559)
+ *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics) */
 
 /* next ticket of a task queue (wave-uniform) */
 __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
@@ -36,7 +38,8 @@ __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
 }
 
 /* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
-__device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_block_io &io)
+template <class IO>
+__device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const IO &io)
 {
   const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
   const uint32_t zq_magic = code->f_zq_magic;
@@ -55,7 +58,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
-  const uint32_t *__restrict__ src32 = io.src32;
+  const uint32_t *__restrict__ src32 = io.src32();
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
   const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
@@ -117,13 +120,11 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   for (int i = tid + 4 * nt; i < n_ext; i += nt)
     e32[i] = src32[n_app + i] ^ 0x80808080u;
   __syncthreads();
-  if (io.stamps && tid == 0)
-    io.stamps[0] = (uint32_t)wall_clock64();
+  if (io.stamps() && tid == 0)
+    io.stamps()[0] = (uint32_t)wall_clock64();
 
   /* ---- passes ------------------------------------------------------------------------------------------ */
-  const int max_pass = io.max_pass;
-  const int crcE = io.crcE;
-  const uint32_t *crc_pow = io.crc_pow;
+  const int max_pass = io.max_pass();
   int n_iter = max_pass;
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
   for (int p = 1; p <= max_pass; ++p) {
@@ -158,15 +159,15 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       flags[2] = 0;
       flags[5] = 0; /* nobody draws bit-node tasks now */
       /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
-      if (io.tb_abort && p >= 2 && __hip_atomic_load(io.tb_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      if (io.tb_abort() && p >= 2 && __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         flags[3] = 1;
     }
     __syncthreads();
-    if (io.tb_abort && flags[3]) {
+    if (io.tb_abort() && flags[3]) {
       n_iter = max_pass + 1;
       break;
     }
-    if (!io.use_crc && p >= 3 && flags[p & 1] == 0) {
+    if (!io.use_crc() && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;
       break;
     }
@@ -192,8 +193,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       flags[4] = 0; /* nobody draws check-node tasks now */
     }
     __syncthreads();
-    if (io.use_crc && p >= 3) { /* see ldpc_dec_generic_block.h for the CRC argument */
+    if (io.use_crc() && p >= 3) { /* see ldpc_dec_generic_block.h for the CRC argument */
       uint32_t x = 0;
+      const int crcE = io.crcE();
+      const uint32_t *crc_pow = io.crc_pow();
       /* four hard decisions (one APP dword: Zc % 4 == 0 keeps them in one column) and their four table entries per
        * step, the loads unconditional and masked afterwards: independent loads in flight instead of a chain of
        * bit test -> load -> wait (E is a multiple of 8) */
@@ -219,15 +222,15 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       }
     }
   }
-  if (io.stamps && tid == 0)
-    io.stamps[1] = (uint32_t)wall_clock64();
-  if (io.tb_abort && n_iter == max_pass && tid == 0) /* decoder.c:190-193: a failed segment gives the whole TB up */
-    __hip_atomic_store(io.tb_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (io.stamps() && tid == 0)
+    io.stamps()[1] = (uint32_t)wall_clock64();
+  if (io.tb_abort() && n_iter == max_pass && tid == 0) /* decoder.c:190-193: a failed segment gives the whole TB up */
+    __hip_atomic_store(io.tb_abort(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   /* ---- hard decision ------------------------------------------------------------------------------------- */
-  if ((!io.use_crc || n_iter >= 3) && n_iter <= max_pass) {
-    if (io.out_mode == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(io.out);
+  if ((!io.use_crc() || n_iter >= 3) && n_iter <= max_pass) {
+    if (io.out_mode() == 0) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(io.out());
       const int nwords = (num_llr + 31) >> 5;
       for (int w = tid; w < nwords; w += nt) {
         uint32_t word = 0;
@@ -244,7 +247,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         o[w] = word;
       }
     } else {
-      int8_t *o = io.out;
+      int8_t *o = io.out();
       for (int i = tid; i < num_llr; i += nt)
         o[i] = (i < ncz) ? (int8_t)ldpc_fast_hd(L, i, Z, z_magic, astride) : (int8_t)0;
     }

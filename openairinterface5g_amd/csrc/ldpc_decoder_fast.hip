@@ -12,49 +12,68 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_block.h"
 
-template <int MAX_THREADS>
+/* a block of a batch launch: addressed by strides (homogeneous batch) or by its job record; everything is read from
+ * the kernel arguments / the job record where it is needed (scalar loads), see ldpc_dec_fast_block.h */
+typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t;
+template <bool JOBS> struct ldpc_batch_io {
+  const ldpc_dec_args &a;
+  ldpc_job_ptr_t job; /* nullptr without JOBS: known at compile time, so the selects below fold away */
+  __device__ __forceinline__ const uint32_t *src32() const
+  {
+    return reinterpret_cast<const uint32_t *>(a.llr + (job ? (size_t)job->llr_off : (size_t)blockIdx.x * a.llr_stride));
+  }
+  __device__ __forceinline__ int8_t *out() const { return a.out + (job ? (size_t)job->out_off : (size_t)blockIdx.x * a.out_stride); }
+  __device__ __forceinline__ int max_pass() const { return (job ? job->num_max_iter : a.num_max_iter) + 1; }
+  __device__ __forceinline__ int use_crc() const { return a.use_crc; }
+  __device__ __forceinline__ int crcE() const { return job ? job->E : a.E; }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow; }
+  __device__ __forceinline__ int out_mode() const { return a.out_mode; }
+  __device__ __forceinline__ int *tb_abort() const
+  {
+    return (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
+  }
+  __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
+};
+
+/* JOBS = heterogeneous batch (one job record per workgroup, optional transport-block abort flags); the homogeneous
+ * variant carries none of that through its loops */
+template <int MAX_THREADS, bool JOBS>
 __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   /* job records and descriptors are read through the constant address space: uniform address -> scalar loads,
    * so everything derived from them stays in SGPRs */
-  typedef const ldpc_dec_job LDPC_CONST_AS *job_ptr_t;
-  const job_ptr_t job = a.jobs ? (job_ptr_t)a.jobs + blockIdx.x : (job_ptr_t) nullptr;
+  const ldpc_job_ptr_t job = JOBS ? (ldpc_job_ptr_t)a.jobs + blockIdx.x : (ldpc_job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
-  const uint32_t blk = blockIdx.x;
-  ldpc_block_io io;
-  io.src32 = reinterpret_cast<const uint32_t *>(a.llr + (job ? (size_t)job->llr_off : (size_t)blk * a.llr_stride));
-  io.out = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
-  io.max_pass = (job ? job->num_max_iter : a.num_max_iter) + 1;
-  io.use_crc = a.use_crc;
-  io.crcE = job ? job->E : a.E;
-  io.crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
-  io.out_mode = a.out_mode;
-  io.tb_abort = (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
+  const ldpc_batch_io<JOBS> io{a, job};
   const int n_iter = ldpc_dec_fast_block(fsm, code, io);
   if (threadIdx.x == 0)
-    a.n_iter[job ? (uint32_t)job->iter_idx : blk] = n_iter;
+    a.n_iter[job ? (uint32_t)job->iter_idx : blockIdx.x] = n_iter;
 }
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess)
-    return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void *k[4] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024, false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768, false>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768, true>)};
+  for (int i = 0; i < 4; i++) {
+    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t stream)
 {
   if (n_blocks == 0)
     return hipSuccess;
-  /* up to 12 waves: 168 VGPRs per lane available (no spills in the degree-19 rows); 13..16 waves: 128 */
+  if (a.jobs)
+    return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
+  /* up to 12 waves: 168 VGPRs per lane available; 13..16 waves: 128 */
   if (hc.f_n_threads <= 768)
-    hipLaunchKernelGGL(ldpc_dec_fast_kernel<768>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<768, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else
-    hipLaunchKernelGGL(ldpc_dec_fast_kernel<1024>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<1024, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 
@@ -63,8 +82,8 @@ hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int 
   if (n_blocks == 0)
     return hipSuccess;
   if (n_threads <= 768)
-    hipLaunchKernelGGL(ldpc_dec_fast_kernel<768>, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<768, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   else
-    hipLaunchKernelGGL(ldpc_dec_fast_kernel<1024>, dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<1024, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

@@ -46,6 +46,23 @@ __device__ __forceinline__ void srv_st_sys(uint32_t *p, uint32_t v)
  * stack.  Either way scratch memory, which a resident kernel had better not depend on. */
 typedef const srv_args LDPC_CONST_AS *srv_args_ptr_t;
 
+struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_dec_fast_block.h) */
+  const srv_req *rq;
+  const uint8_t *payload;
+  uint8_t *hout;
+  srv_args_ptr_t a;
+  uint32_t *st;
+  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(payload); }
+  __device__ __forceinline__ int8_t *out() const { return reinterpret_cast<int8_t *>(hout); }
+  __device__ __forceinline__ int max_pass() const { return LDPC_UNIFORM((int)rq->max_pass); }
+  __device__ __forceinline__ int use_crc() const { return LDPC_UNIFORM((int)rq->use_crc); }
+  __device__ __forceinline__ int crcE() const { return LDPC_UNIFORM((int)rq->crcE); }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u]; }
+  __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)rq->out_mode); }
+  __device__ __forceinline__ int *tb_abort() const { return nullptr; }
+  __device__ __forceinline__ uint32_t *stamps() const { return st; }
+};
+
 __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -139,16 +156,7 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
     uint8_t *hout = a->out_host + (size_t)blockIdx.x * SRV_OUT_STRIDE;
     int n_iter = 0;
     if (kind == SRV_KIND_DEC_FAST) {
-      ldpc_block_io io;
-      io.src32 = reinterpret_cast<const uint32_t *>(payload);
-      io.out = reinterpret_cast<int8_t *>(hout);
-      io.max_pass = LDPC_UNIFORM((int)rq->max_pass);
-      io.use_crc = LDPC_UNIFORM((int)rq->use_crc);
-      io.crcE = LDPC_UNIFORM((int)rq->crcE);
-      io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u];
-      io.out_mode = LDPC_UNIFORM((int)rq->out_mode);
-      io.tb_abort = nullptr;
-      io.stamps = bc + 24;
+      const srv_fast_io io{rq, payload, hout, a, bc + 24};
       n_iter = ldpc_dec_fast_block(fsm, code, io);
     } else if (kind == SRV_KIND_DEC_GENERIC) {
       ldpc_gblock_io io;
