@@ -58,33 +58,91 @@ struct CodeEntry {
   }
 };
 
-struct Library {
-  std::mutex mu;
+#define NRLDPC_HIP_MAX_DEVICES 16
+
+/* One per logical device: everything that lives in a GPU's memory.  NRLDPC_HIP_DEVICES=0,1,... lists the GPUs the
+ * host-buffer entry points shard their batches over (whole code blocks / whole transport blocks per GPU, no data-path
+ * exchange: SURVEY 8e); without it there is one, NRLDPC_HIP_DEVICE (default 0).  Device-buffer calls run on the GPU that
+ * owns the buffers.  The same ordinal may be listed twice (two independent contexts on one GPU: used by the tests). */
+struct Device {
+  int id = 0, n_cus = 256; /* HIP ordinal */
   bool ready = false;
-  int device = 0, n_cus = 256;
-  std::map<uint32_t, CodeEntry *> codes;      /* under mu: the builder's view */
+  std::map<uint32_t, CodeEntry *> codes;      /* under Library::mu: the builder's view */
   std::atomic<CodeEntry *> code_tbl[2][385][3]; /* published entries, [BG-1][Z][rate index]: read without a lock */
-  const int *opp_enabled = nullptr;           /* the host executable's meter switch (common/utils/time_meas.h), if it has one */
   uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8: x^j mod g, j < 8448 */
   uint32_t *crc_pow_24a_long = nullptr;                        /* CRC24_A up to a whole transport block */
+};
+
+struct Library {
+  std::mutex mu;
+  std::atomic<bool> ready{false};
+  int n_dev = 0;     /* logical devices in use */
+  int n_shard = 1;   /* the first n_shard of them take part in sharding host-buffer batches */
+  Device dev[NRLDPC_HIP_MAX_DEVICES];
+  const int *opp_enabled = nullptr;           /* the host executable's meter switch (common/utils/time_meas.h), if it has one */
 } g;
+
+/* the device the calling thread is working on (set by the entry points through UseDevice) */
+thread_local Device *tls_dev = nullptr;
+inline Device &G() { return tls_dev ? *tls_dev : g.dev[0]; }
+struct UseDevice { /* selects a logical device for this thread and leaves the caller's HIP device as it found it */
+  Device *prev;
+  int prev_id = -1;
+  bool ok;
+  explicit UseDevice(Device &d) : prev(tls_dev)
+  {
+    (void)hipGetDevice(&prev_id);
+    tls_dev = &d;
+    ok = hipSetDevice(d.id) == hipSuccess;
+  }
+  ~UseDevice()
+  {
+    tls_dev = prev;
+    if (prev_id >= 0)
+      (void)hipSetDevice(prev_id);
+  }
+};
 
 /* x^j mod g(x), left aligned in 32 bits, for the polynomials of crc_byte.c:46-58 */
 void fill_crc_pow(uint32_t poly, std::vector<uint32_t> &t, size_t len = LDPC_CRC_POW_LEN)
 {
-  /* degree from the lowest set bit position of the left-aligned polynomial is not needed: the left-aligned
-   * register arithmetic of crcbit() (crc_byte.c:65-84) already works modulo g for any degree. */
-  t.resize(len);
-  /* x^0 as "remainder register" = the CRC of a single 1 bit followed by nothing is poly itself only after
-   * the degree shift; build it as: rem(j) = register after clocking a 1 followed by j zeros ... */
   /* A message bit at distance j from the end of an E-bit word contributes x^j (mod g) to word(x) mod g.
-   * With the left-aligned register, word(x)*x^deg mod g is what crcbit computes; divisibility is the same
-   * question, so tabulate r_j = (x^j * x^deg) mod g: r_0 = poly (one 1 bit clocked in), r_{j+1} = r_j * x mod g */
+   * With the left-aligned register, word(x)*x^deg mod g is what crcbit() (crc_byte.c:65-84) computes; divisibility is
+   * the same question, so tabulate r_j = (x^j * x^deg) mod g: r_0 = poly (one 1 bit clocked in), r_{j+1} = r_j * x mod g */
+  t.resize(len);
   uint32_t r = poly;
   for (size_t j = 0; j < len; j++) {
     t[j] = r;
     r = (r & 0x80000000u) ? ((r << 1) ^ poly) : (r << 1);
   }
+}
+
+int device_init_locked(Device &d, int ordinal)
+{
+  d.id = ordinal;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  HIP_TRY(hipSetDevice(ordinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+  d.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  static const uint32_t polys[4] = {0x864cfb00u, 0x80006300u, 0x10210000u, 0x9B000000u};
+  for (int i = 0; i < 4; i++) {
+    std::vector<uint32_t> t;
+    fill_crc_pow(polys[i], t);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.crc_pow[i]), t.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d.crc_pow[i], t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<uint32_t> t;
+    fill_crc_pow(polys[0], t, TB_CRC24A_POW_LEN);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.crc_pow_24a_long), t.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d.crc_pow_24a_long, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  d.ready = true;
+  if (prev >= 0)
+    (void)hipSetDevice(prev);
+  return 0;
 }
 
 int ensure_ready_locked()
@@ -95,31 +153,30 @@ int ensure_ready_locked()
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
     return set_error("no HIP device available (libldpc_hip.so has no CPU fallback)", e);
-  const char *env = getenv("NRLDPC_HIP_DEVICE");
-  g.device = env ? atoi(env) : 0;
-  if (g.device < 0 || g.device >= ndev)
-    return set_error("NRLDPC_HIP_DEVICE out of range");
-  HIP_TRY(hipSetDevice(g.device));
-  {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
-    g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int list[NRLDPC_HIP_MAX_DEVICES], n = 0;
+  if (const char *env = getenv("NRLDPC_HIP_DEVICES")) {
+    for (const char *p = env; *p && n < NRLDPC_HIP_MAX_DEVICES;) {
+      char *end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p)
+        break;
+      list[n++] = (int)v;
+      p = *end == ',' ? end + 1 : end;
+    }
   }
+  if (n == 0) {
+    const char *env = getenv("NRLDPC_HIP_DEVICE");
+    list[n++] = env ? atoi(env) : 0;
+  }
+  for (int i = 0; i < n; i++)
+    if (list[i] < 0 || list[i] >= ndev)
+      return set_error("NRLDPC_HIP_DEVICE(S) out of range");
   HIP_TRY(ldpc_kernels_init());
   HIP_TRY(ldpc_fast_kernel_init());
-  static const uint32_t polys[4] = {0x864cfb00u, 0x80006300u, 0x10210000u, 0x9B000000u};
-  for (int i = 0; i < 4; i++) {
-    std::vector<uint32_t> t;
-    fill_crc_pow(polys[i], t);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow[i]), t.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(g.crc_pow[i], t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
-  {
-    std::vector<uint32_t> t;
-    fill_crc_pow(polys[0], t, TB_CRC24A_POW_LEN);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.crc_pow_24a_long), t.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(g.crc_pow_24a_long, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
+  for (int i = 0; i < n; i++)
+    if (device_init_locked(g.dev[i], list[i]) != 0)
+      return -1;
+  g.n_dev = g.n_shard = n;
   g.opp_enabled = static_cast<const int *>(dlsym(RTLD_DEFAULT, "opp_enabled"));
   g.ready = true;
   return 0;
@@ -131,6 +188,34 @@ int ensure_ready()
   return ensure_ready_locked();
 }
 
+/* the logical device for buffers that live on HIP device `ordinal` (a device outside the configured list is set up on
+ * first use); nullptr + error when that fails */
+Device *device_for_ordinal(int ordinal)
+{
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (ensure_ready_locked() != 0)
+    return nullptr;
+  for (int i = 0; i < g.n_dev; i++)
+    if (g.dev[i].id == ordinal)
+      return &g.dev[i];
+  if (g.n_dev >= NRLDPC_HIP_MAX_DEVICES) {
+    set_error("too many devices");
+    return nullptr;
+  }
+  if (device_init_locked(g.dev[g.n_dev], ordinal) != 0)
+    return nullptr;
+  return &g.dev[g.n_dev++];
+}
+/* the logical device that owns device pointer p (the primary one if the runtime does not know the pointer) */
+Device *device_of_pointer(const void *p)
+{
+  hipPointerAttribute_t at;
+  if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice)
+    return device_for_ordinal(at.device);
+  (void)hipGetLastError();
+  return ensure_ready() == 0 ? &g.dev[0] : nullptr;
+}
+
 int rate_index(int BG, int R)
 {
   if (BG == 1)
@@ -138,8 +223,9 @@ int rate_index(int BG, int R)
   return R == 15 ? 0 : R == 13 ? 1 : R == 23 ? 2 : -1;
 }
 
-/* descriptor cache: built on first use of a (BG, Z, R), uploaded once, never modified afterwards.  The per-segment
- * entry points come through here on every call: a published entry is found without taking the library mutex. */
+/* descriptor cache of the current device: built on first use of a (BG, Z, R), uploaded once, never modified afterwards.
+ * The per-segment entry points come through here on every call: a published entry is found without taking the library
+ * mutex. */
 const CodeEntry *get_code(int BG, int Z, int R)
 {
   const int ri = (BG == 1 || BG == 2) ? rate_index(BG, R) : -1;
@@ -147,14 +233,16 @@ const CodeEntry *get_code(int BG, int Z, int R)
     set_error("invalid (BG, Z, R)");
     return nullptr;
   }
-  if (CodeEntry *hit = g.code_tbl[BG - 1][Z][ri].load(std::memory_order_acquire))
-    return hit;
+  if (g.ready) /* (read without the lock: set once, after everything it guards) */
+    if (CodeEntry *hit = G().code_tbl[BG - 1][Z][ri].load(std::memory_order_acquire))
+      return hit;
   const uint32_t key = ((uint32_t)BG << 24) | ((uint32_t)Z << 8) | (uint32_t)R;
   std::lock_guard<std::mutex> lk(g.mu);
   if (ensure_ready_locked() != 0)
     return nullptr;
-  auto it = g.codes.find(key);
-  if (it != g.codes.end())
+  Device &d = G();
+  auto it = d.codes.find(key);
+  if (it != d.codes.end())
     return it->second;
   CodeEntry *ce = new CodeEntry();
   if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_THROUGHPUT, &ce->host) != 0 ||
@@ -163,7 +251,9 @@ const CodeEntry *get_code(int BG, int Z, int R)
     set_error("invalid (BG, Z, R)");
     return nullptr;
   }
-  hipError_t e = hipSetDevice(g.device);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(d.id);
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void **>(&ce->dev), 2 * sizeof(ldpc_code_desc_t));
   if (e == hipSuccess)
@@ -172,15 +262,18 @@ const CodeEntry *get_code(int BG, int Z, int R)
     ce->dev_lat = ce->dev + 1;
     e = hipMemcpy(ce->dev_lat, &ce->host_lat, sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
   }
+  if (prev >= 0)
+    (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     set_error("descriptor upload", e);
     delete ce;
     return nullptr;
   }
   if (getenv("NRLDPC_HIP_SRV_DEBUG"))
-    fprintf(stderr, "[libldpc_hip] code BG%d Z%d R%d: descriptors at %p (2 x %zu B)\n", BG, Z, R, (void *)ce->dev, sizeof(ldpc_code_desc_t));
-  g.codes[key] = ce;
-  g.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
+    fprintf(stderr, "[libldpc_hip] code BG%d Z%d R%d on device %d: descriptors at %p (2 x %zu B)\n", BG, Z, R, d.id, (void *)ce->dev,
+            sizeof(ldpc_code_desc_t));
+  d.codes[key] = ce;
+  d.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
   return ce;
 }
 
@@ -210,9 +303,8 @@ struct ThreadCtx {
   uint8_t *h_in = nullptr, *h_out = nullptr; /* pinned */
   uint8_t *d_in = nullptr, *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
-  int ensure(size_t in_bytes, size_t out_bytes)
+  int ensure(size_t in_bytes, size_t out_bytes) /* on the current device (UseDevice) */
   {
-    HIP_TRY(hipSetDevice(g.device));
     if (!stream) {
       HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
@@ -262,29 +354,35 @@ template <typename T> struct CtxPool {
     idle.push_back(c);
   }
 };
-template <typename T> struct CtxHolder { /* thread_local: takes a context on first use, hands it back when the thread ends */
-  static CtxPool<T> &pool()
+template <typename T> struct CtxHolder { /* thread_local, one per logical device: takes a context of that device on first
+                                              use, hands it back when the thread ends */
+  static CtxPool<T> &pool(int dev)
   {
-    static CtxPool<T> *p = new CtxPool<T>(); /* never destroyed: threads may end after the static destructors ran */
-    return *p;
+    static CtxPool<T> *p = new CtxPool<T>[NRLDPC_HIP_MAX_DEVICES]; /* never destroyed: threads may end after the static destructors ran */
+    return p[dev];
   }
   T *c = nullptr;
-  T &get()
+  int dev = 0;
+  T &get(int dev_index)
   {
-    if (!c)
-      c = pool().take();
+    if (!c) {
+      dev = dev_index;
+      c = pool(dev).take();
+    }
     return *c;
   }
   ~CtxHolder()
   {
     if (c) {
+      UseDevice use(g.dev[dev]);
       c->drain();
-      pool().give(c);
+      pool(dev).give(c);
     }
   }
 };
-thread_local CtxHolder<ThreadCtx> tls_ctx_holder;
-#define tls_ctx (tls_ctx_holder.get())
+inline int cur_dev_index() { return (int)(&G() - g.dev); }
+thread_local CtxHolder<ThreadCtx> tls_ctx_holder[NRLDPC_HIP_MAX_DEVICES];
+#define tls_ctx (tls_ctx_holder[cur_dev_index()].get(cur_dev_index()))
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -309,7 +407,7 @@ int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_
   if (kernel >= 2 && !fast_ok)
     return set_error("fast kernel not applicable (needs Zc % 4 == 0, Zc >= 8, 4-byte aligned LLR rows)");
   if (kernel != 1 && fast_ok) {
-    const bool lat = ce->use_latency(batch_blocks, g.n_cus, kernel == 3 ? 1 : (kernel == 4 ? 2 : 0));
+    const bool lat = ce->use_latency(batch_blocks, G().n_cus, kernel == 3 ? 1 : (kernel == 4 ? 2 : 0));
     a.code = lat ? ce->dev_lat : ce->dev;
     HIP_TRY(ldpc_launch_dec_fast(a, lat ? ce->host_lat : ce->host, n_blocks, s));
   } else {
@@ -329,7 +427,7 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
   a.crc_pow = nullptr;
   a.jobs = nullptr;
   for (int i = 0; i < 4; i++)
-    a.crc_pow_tbl[i] = g.crc_pow[i];
+    a.crc_pow_tbl[i] = G().crc_pow[i];
   if (a.use_crc) {
     if (p.crc_type < 0 || p.crc_type > 3)
       return set_error("invalid crc_type");
@@ -338,7 +436,7 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
     if (p.outMode != nrLDPC_outMode_BIT)
       return set_error("CRC mode needs outMode BIT (the reference checks the packed bytes)");
     a.E = p.E;
-    a.crc_pow = g.crc_pow[p.crc_type];
+    a.crc_pow = G().crc_pow[p.crc_type];
   }
   return 0;
 }
@@ -453,24 +551,124 @@ int32_t LDPCshutdown(void)
   return 0;
 }
 
-int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
+} /* extern "C" */
+
+namespace {
+
+/* contiguous, balanced [lo, hi) of n items for part k of parts */
+inline void shard_range(uint32_t n, int k, int parts, uint32_t &lo, uint32_t &hi)
 {
-  if (!b || !b->llr || !b->out || !b->n_iter)
-    return set_error("null argument");
+  const uint32_t base = n / (uint32_t)parts, rem = n % (uint32_t)parts;
+  lo = (uint32_t)k * base + std::min<uint32_t>((uint32_t)k, rem);
+  hi = lo + base + ((uint32_t)k < rem ? 1u : 0u);
+}
+
+/* Host-buffer decode of blocks [i0, i0+n) of b on the CURRENT device: everything is enqueued on this thread's two
+ * streams of that device; dec_host_finish() waits and hands the results over.  Large batches go in chunks alternating
+ * between the two streams, so that the CPU copy of chunk k+1 into pinned memory (pageable source only), the PCIe
+ * transfer of chunk k and the kernel of chunk k-1 overlap; every chunk has its own staging region (no intermediate
+ * waits).  LLRs that already live in page-locked memory (hipHostMalloc / hipHostRegister) are fetched by the copy
+ * engine in place, rows and padding alike, in one linear copy per chunk. */
+int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_part, bool pinned)
+{
   const t_nrLDPC_dec_params &p = b->params;
   const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
   if (!ce)
     return -1;
   const ldpc_code_desc_t &hc = ce->host;
-  const int ob = out_bytes_of(hc, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
-  if (b->llr_stride < (uint32_t)hc.num_llr || b->out_stride < (uint32_t)ob || (b->out_stride & 3))
-    return set_error("bad stride");
   ldpc_dec_args a;
   if (fill_dec_args(p, ce, a) != 0)
     return -1;
-  if (b->n_blocks == 0)
-    return 0;
+  const int ob = out_bytes_of(hc, a.out_mode);
+  ThreadCtx &c = tls_ctx;
+  /* page-locked source with a sane stride: the device copy keeps the caller's row pitch */
+  const bool direct = pinned && n_part >= 16 && b->llr_stride <= 2u * (uint32_t)hc.num_llr;
+  const size_t in_stride = direct ? b->llr_stride : align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
+  /* the pass counts travel behind the output rows in the same buffers: one device->host copy for a one-chunk call */
+  const size_t iter_off = out_stride * n_part;
+  if (c.ensure(in_stride * n_part, iter_off + sizeof(int32_t) * n_part) != 0)
+    return -1;
+  int32_t *d_iter = reinterpret_cast<int32_t *>(c.d_out + iter_off);
+  const size_t chunk_bytes = direct ? ((size_t)8 << 20) : ((size_t)2 << 20);
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1, chunk_bytes / in_stride);
+  int lane = 0;
+  for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {
+    const uint32_t n = std::min(chunk, n_part - k0);
+    hipStream_t s = lane ? c.stream2 : c.stream;
+    const int8_t *src = b->llr + (size_t)(i0 + k0) * b->llr_stride;
+    if (direct) {
+      const size_t bytes = (size_t)(n - 1) * in_stride + (size_t)hc.num_llr; /* not past the last row's LLRs */
+      HIP_TRY(hipMemcpyAsync(c.d_in + k0 * in_stride, src, bytes, hipMemcpyHostToDevice, s));
+    } else {
+      for (uint32_t i = 0; i < n; i++)
+        memcpy(c.h_in + (k0 + i) * in_stride, src + (size_t)i * b->llr_stride, hc.num_llr);
+      HIP_TRY(hipMemcpyAsync(c.d_in + k0 * in_stride, c.h_in + k0 * in_stride, in_stride * n, hipMemcpyHostToDevice, s));
+    }
+    a.llr = reinterpret_cast<const int8_t *>(c.d_in + k0 * in_stride); a.llr_stride = (uint32_t)in_stride;
+    a.out = reinterpret_cast<int8_t *>(c.d_out + k0 * out_stride); a.out_stride = (uint32_t)out_stride;
+    a.n_iter = d_iter + k0;
+    if (launch_decoder(b->kernel, a, ce, n, s, n_part) != 0)
+      return -1;
+    if (n == n_part) {
+      HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, iter_off + sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    } else {
+      HIP_TRY(hipMemcpyAsync(c.h_out + k0 * out_stride, c.d_out + k0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * k0, c.d_out + iter_off + sizeof(int32_t) * k0,
+                             sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    }
+  }
+  return 0;
+}
+
+int dec_host_finish(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_part)
+{
+  const t_nrLDPC_dec_params &p = b->params;
+  const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
+  if (!ce)
+    return -1;
+  const int ob = out_bytes_of(ce->host, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
+  const size_t out_stride = align_up(ob, 16), iter_off = out_stride * n_part;
+  ThreadCtx &c = tls_ctx;
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream2));
+  const int32_t *h_iter = reinterpret_cast<const int32_t *>(c.h_out + iter_off);
+  const bool use_crc = p.check_crc != nullptr;
+  for (uint32_t i = 0; i < n_part; i++) {
+    const int32_t n = h_iter[i];
+    b->n_iter[i0 + i] = n;
+    if (!use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+      memcpy(b->out + (size_t)(i0 + i) * b->out_stride, c.h_out + i * out_stride, ob);
+  }
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
+{
+  if (!b || !b->llr || !b->out || !b->n_iter)
+    return set_error("null argument");
   if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
+    /* the buffers' own GPU does the work, whatever device is current in the calling thread (and stays current) */
+    Device *d = device_of_pointer(b->llr);
+    if (!d)
+      return -1;
+    UseDevice use(*d);
+    const t_nrLDPC_dec_params &p = b->params;
+    const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
+    if (!ce)
+      return -1;
+    const ldpc_code_desc_t &hc = ce->host;
+    const int ob = out_bytes_of(hc, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
+    if (b->llr_stride < (uint32_t)hc.num_llr || b->out_stride < (uint32_t)ob || (b->out_stride & 3))
+      return set_error("bad stride");
+    ldpc_dec_args a;
+    if (fill_dec_args(p, ce, a) != 0)
+      return -1;
+    if (b->n_blocks == 0)
+      return 0;
     if ((reinterpret_cast<uintptr_t>(b->out) & 3))
       return set_error("out must be 4-byte aligned");
     a.llr = b->llr; a.llr_stride = b->llr_stride;
@@ -479,56 +677,45 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     hipStream_t s = static_cast<hipStream_t>(b->stream); /* NULL = the legacy default stream */
     return launch_decoder(b->kernel, a, ce, b->n_blocks, s);
   }
-  /* host buffers: stage through this thread's pinned buffers, synchronous.  Large batches go in chunks of ~2 MiB of
-   * LLRs alternating between two streams: the CPU copy of chunk k+1 into pinned memory, the PCIe transfer of chunk k
-   * and the kernel of chunk k-1 overlap (every chunk has its own staging region, so no intermediate waits). */
-  ThreadCtx &c = tls_ctx;
-  const size_t in_stride = align_up(hc.num_llr, 16), out_stride = align_up(ob, 16);
-  /* the pass counts travel behind the output rows in the same buffers: one device->host copy for a one-chunk call */
-  const size_t iter_off = out_stride * b->n_blocks;
-  if (c.ensure(in_stride * b->n_blocks, iter_off + sizeof(int32_t) * b->n_blocks) != 0)
+  if (ensure_ready() != 0)
     return -1;
-  int32_t *d_iter = reinterpret_cast<int32_t *>(c.d_out + iter_off);
-  const int32_t *h_iter = reinterpret_cast<const int32_t *>(c.h_out + iter_off);
-  const uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)2 << 20) / in_stride);
-  /* LLRs that already live in page-locked memory (hipHostMalloc / hipHostRegister) are fetched by the copy engine
-   * directly; the CPU staging copy, which bounds the pageable case at memcpy speed, disappears */
-  const bool direct = b->n_blocks >= 16 && host_ptr_is_pinned(b->llr);
-  int lane = 0;
-  for (uint32_t i0 = 0; i0 < b->n_blocks; i0 += chunk, lane ^= 1) {
-    const uint32_t n = std::min(chunk, b->n_blocks - i0);
-    hipStream_t s = lane ? c.stream2 : c.stream;
-    if (direct) {
-      HIP_TRY(hipMemcpy2DAsync(c.d_in + i0 * in_stride, in_stride, b->llr + (size_t)i0 * b->llr_stride, b->llr_stride,
-                               (size_t)hc.num_llr, n, hipMemcpyHostToDevice, s));
-    } else {
-      for (uint32_t i = i0; i < i0 + n; i++)
-        memcpy(c.h_in + i * in_stride, b->llr + (size_t)i * b->llr_stride, hc.num_llr);
-      HIP_TRY(hipMemcpyAsync(c.d_in + i0 * in_stride, c.h_in + i0 * in_stride, in_stride * n, hipMemcpyHostToDevice, s));
-    }
-    a.llr = reinterpret_cast<const int8_t *>(c.d_in + i0 * in_stride); a.llr_stride = (uint32_t)in_stride;
-    a.out = reinterpret_cast<int8_t *>(c.d_out + i0 * out_stride); a.out_stride = (uint32_t)out_stride;
-    a.n_iter = d_iter + i0;
-    if (launch_decoder(b->kernel, a, ce, n, s, b->n_blocks) != 0)
+  {
+    /* parameter checks once, against the primary device's descriptor */
+    UseDevice use(g.dev[0]);
+    const t_nrLDPC_dec_params &p = b->params;
+    const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
+    if (!ce)
       return -1;
-    if (n == b->n_blocks) {
-      HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, iter_off + sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    } else {
-      HIP_TRY(hipMemcpyAsync(c.h_out + i0 * out_stride, c.d_out + i0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * i0, c.d_out + iter_off + sizeof(int32_t) * i0,
-                             sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    }
+    const int ob = out_bytes_of(ce->host, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
+    if (b->llr_stride < (uint32_t)ce->host.num_llr || b->out_stride < (uint32_t)ob || (b->out_stride & 3))
+      return set_error("bad stride");
+    ldpc_dec_args a;
+    if (fill_dec_args(p, ce, a) != 0)
+      return -1;
   }
-  HIP_TRY(hipStreamSynchronize(c.stream));
-  if (b->n_blocks > chunk)
-    HIP_TRY(hipStreamSynchronize(c.stream2));
-  for (uint32_t i = 0; i < b->n_blocks; i++) {
-    const int32_t n = h_iter[i];
-    b->n_iter[i] = n;
-    if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
-      memcpy(b->out + (size_t)i * b->out_stride, c.h_out + i * out_stride, ob);
+  if (b->n_blocks == 0)
+    return 0;
+  /* host buffers: contiguous block ranges over the sharding devices (code blocks are independent, nothing is
+   * exchanged), every device fed over its own link; a handful of blocks stays on the primary device */
+  const int parts = b->n_blocks >= 64u * (uint32_t)g.n_shard ? g.n_shard : 1;
+  const bool pinned = b->n_blocks >= 16 && host_ptr_is_pinned(b->llr);
+  int rc = 0;
+  for (int k = 0; k < parts && rc == 0; k++) {
+    uint32_t lo, hi;
+    shard_range(b->n_blocks, k, parts, lo, hi);
+    UseDevice use(g.dev[k]);
+    rc = dec_host_enqueue(b, lo, hi - lo, pinned);
   }
-  return 0;
+  for (int k = 0; k < parts; k++) { /* also after an error: nothing stays in flight */
+    uint32_t lo, hi;
+    shard_range(b->n_blocks, k, parts, lo, hi);
+    UseDevice use(g.dev[k]);
+    if (rc == 0)
+      rc = dec_host_finish(b, lo, hi - lo);
+    else
+      tls_ctx.drain();
+  }
+  return rc;
 }
 
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
@@ -590,6 +777,12 @@ int32_t LDPCencoder_batch(const nrLDPC_hip_enc_batch_t *b)
 {
   if (!b || !b->in || !b->out)
     return set_error("null argument");
+  /* device buffers: their own GPU; host buffers: the primary device (the call is bound by the 8x larger, one byte per
+   * bit, output crossing the link -- use nrLDPC_hip_dlsch_encode to shard transport blocks over GPUs) */
+  Device *dv = b->mem == NRLDPC_HIP_MEM_DEVICE ? device_of_pointer(b->in) : (ensure_ready() == 0 ? &g.dev[0] : nullptr);
+  if (!dv)
+    return -1;
+  UseDevice use(*dv);
   const CodeEntry *ce = get_code(b->BG, b->Zc, b->BG == 1 ? 13 : 15);
   if (!ce)
     return -1;
@@ -658,6 +851,7 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
     if (rc <= 0)
       return rc;
   }
+  UseDevice use(g.dev[0]);
   ThreadCtx &c = tls_ctx;
   const size_t in_stride = align_up(in_bytes, 16), out_stride = align_up(N, 16);
   if (c.ensure(in_stride * n, out_stride * n) != 0)

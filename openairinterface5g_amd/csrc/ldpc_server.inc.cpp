@@ -61,12 +61,12 @@ int srv_init_locked()
   int n = 64;
   if ((e = getenv("NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
     n = atoi(e);
-  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.n_cus / 2)));
+  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / 2)));
   int idle_us = 20000;
   if ((e = getenv("NRLDPC_HIP_SRV_IDLE_US")) && atoi(e) >= 1)
     idle_us = atoi(e);
   srv.status = 1; /* until everything below has worked */
-  HIP_TRY(hipSetDevice(g.device));
+  UseDevice use(g.dev[0]); /* the server lives on the primary device */
   HIP_TRY(ldpc_server_init());
   const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
   uint8_t *small = nullptr;
@@ -96,7 +96,7 @@ int srv_init_locked()
   HIP_TRY(hipMemset(a.gctl, 0, sizeof(srv_gctl)));
   a.idle_ticks = (uint32_t)idle_us * 100u; /* wall_clock64: 100 MHz */
   for (int i = 0; i < 4; i++)
-    a.crc_pow_tbl[i] = g.crc_pow[i];
+    a.crc_pow_tbl[i] = g.dev[0].crc_pow[i];
   /* its own hardware queue: a kernel that stays resident must not sit in front of other streams' launches */
   int lo = 0, hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -141,7 +141,7 @@ int srv_ensure_running()
     return 0;
   srv_args a = srv.args;
   a.gen = gcur + 1;
-  HIP_TRY(hipSetDevice(g.device));
+  UseDevice use(g.dev[0]);
   HIP_TRY(ldpc_server_launch(a, (uint32_t)srv.n_slots, srv.stream));
   srv.gen.store(gcur + 1, std::memory_order_release);
   return 0;
@@ -158,7 +158,7 @@ void srv_stop()
   if (!gcur)
     return;
   __atomic_store_n(srv.host_stop, gcur, __ATOMIC_RELEASE);
-  (void)hipSetDevice(g.device);
+  UseDevice use(g.dev[0]);
   (void)hipStreamSynchronize(srv.stream);
 }
 void srv_stop_at_exit() { srv_stop(); }

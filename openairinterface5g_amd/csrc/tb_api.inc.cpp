@@ -47,24 +47,27 @@ struct TbPlan {
   std::vector<uint8_t> key;
   DevBuf jobs_d;
   bool valid = false;
-  size_t n_seg = 0, n_aux = 0, scratch_top = 0, payload_end = 0, coded_end = 0, harq_end = 0;
+  size_t n_seg = 0, n_aux = 0, scratch_top = 0;
+  size_t ext[6] = {0, 0, 0, 0, 0, 0}; /* [lo, hi) of the payload, coded and harq ranges the blocks touch */
+  bool out_dense = true; /* the blocks' outputs tile their range: one copy back; else one per block (nothing between them is touched) */
   size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int threads[2] = {64, 64}, lds[2] = {0, 0};
   size_t n_fast = 0, n_gen = 0;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
-  bool matches(const nrLDPC_hip_tb_batch_t *b, uint32_t salt) const
+  /* the descriptors tb[0 .. n_tb) of a call (one device's share of the batch) */
+  bool matches(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, uint32_t salt) const
   {
-    const size_t n = (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t);
-    return valid && key.size() == n + 8 && memcmp(key.data(), &b->n_tb, 4) == 0 && memcmp(key.data() + 4, &salt, 4) == 0 &&
-           memcmp(key.data() + 8, b->tb, n) == 0;
+    const size_t n = (size_t)n_tb * sizeof(nrLDPC_hip_tb_t);
+    return valid && key.size() == n + 8 && memcmp(key.data(), &n_tb, 4) == 0 && memcmp(key.data() + 4, &salt, 4) == 0 &&
+           memcmp(key.data() + 8, tb, n) == 0;
   }
-  void remember(const nrLDPC_hip_tb_batch_t *b, uint32_t salt)
+  void remember(const void *tb_bytes, uint32_t n_tb, uint32_t salt)
   {
-    const size_t n = (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t);
+    const size_t n = (size_t)n_tb * sizeof(nrLDPC_hip_tb_t);
     key.resize(n + 8);
-    memcpy(key.data(), &b->n_tb, 4);
+    memcpy(key.data(), &n_tb, 4);
     memcpy(key.data() + 4, &salt, 4);
-    memcpy(key.data() + 8, b->tb, n);
+    memcpy(key.data() + 8, tb_bytes, n);
     valid = true;
   }
 };
@@ -83,8 +86,8 @@ struct TbCtx {
     pending = false;
   }
 };
-thread_local CtxHolder<TbCtx> tls_tb_holder; /* pooled like ThreadCtx: contexts outlive their threads */
-#define tls_tb (tls_tb_holder.get())
+thread_local CtxHolder<TbCtx> tls_tb_holder[NRLDPC_HIP_MAX_DEVICES]; /* pooled like ThreadCtx, one per logical device */
+#define tls_tb (tls_tb_holder[cur_dev_index()].get(cur_dev_index()))
 
 struct Arena { /* bump allocator over the scratch buffer, 16-byte granules */
   size_t top = 0;
@@ -96,14 +99,10 @@ struct Arena { /* bump allocator over the scratch buffer, 16-byte granules */
   }
 };
 
+/* on the current device (UseDevice) */
 int tb_begin(const nrLDPC_hip_tb_batch_t *b, hipStream_t &s)
 {
-  if (!b || !b->tb || !b->payload || !b->coded)
-    return set_error("null argument");
-  if (ensure_ready() != 0)
-    return -1;
   TbCtx &c = tls_tb;
-  HIP_TRY(hipSetDevice(g.device));
   if (!c.own) {
     HIP_TRY(hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c.uploaded, hipEventDisableTiming));
@@ -178,121 +177,144 @@ int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int3
   return nr_hip_get_R_ldpc_decoder(rvidx, E, BG, Z, llrLen, round);
 }
 
-int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
+} /* extern "C" */
+
+namespace {
+
+/* [lo, hi) ranges of the caller's buffers that the transport blocks tb[0 .. n) touch (bytes / int16 elements) */
+struct TbExtent {
+  size_t pay_lo = SIZE_MAX, pay_hi = 0, cod_lo = SIZE_MAX, cod_hi = 0, harq_lo = SIZE_MAX, harq_hi = 0;
+  size_t pay_sum = 0, cod_sum = 0; /* bytes / elements the blocks own: == hi - lo when they tile their range */
+  void add(size_t &lo, size_t &hi, size_t a, size_t b)
+  {
+    lo = std::min(lo, a);
+    hi = std::max(hi, b);
+  }
+};
+
+/* ---- TX: transport blocks [tb0, tb0+ntb) of b on the current device -------------------------------------------------
+ * host buffers: the device works on copies of exactly the byte ranges its blocks touch (job offsets stay the caller's:
+ * the device pointers are biased by the range start); enqueue only, tb_tx_finish() copies back and waits */
+int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
 {
   hipStream_t s;
   if (tb_begin(b, s) != 0)
     return -1;
-  if (b->n_tb == 0)
+  if (ntb == 0)
     return 0;
+  const nrLDPC_hip_tb_t *tbs = b->tb + tb0;
   TbCtx &c = tls_tb;
   TbPlan &pl = c.tx;
   const bool fused = ldpc_enc_is_packed() != 0;
-  if (!pl.matches(b, fused ? 1u : 0u)) {
-  pl.valid = false;
-  std::vector<tb_tx_tb_job> tbj(b->n_tb);
-  std::vector<tb_tx_seg_job> sj;
-  std::vector<ldpc_enc_job> ej;
-  std::vector<tb_crc_chunk_job> cj;
-  Arena ar;
-  int enc_threads = 64, enc_lds = 0;
-  size_t payload_end = 0, coded_end = 0;
-  for (uint32_t i = 0; i < b->n_tb; i++) {
-    const nrLDPC_hip_tb_t &t = b->tb[i];
-    if (tb_validate(t) != 0)
-      return -1;
-    /* nr_dlsch_coding.c:300-331 */
-    const uint32_t B = t.A + (t.A > NR_HIP_MAX_PDSCH_TBS ? 24 : 16);
-    nr_hip_seg_t sg;
-    if (nr_hip_segmentation(B, t.BG, &sg) != 0)
-      return set_error("nr_segmentation: unsupported block size");
-    const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
-    if (!ce)
-      return -1;
-    tbj[i].payload_off = t.payload_off;
-    tbj[i].b_off = ar.take(B / 8 + 4);
-    tbj[i].A = t.A;
-    tbj[i].B = B;
-    tbj[i].crc_type = t.A > NR_HIP_MAX_PDSCH_TBS ? NR_HIP_CRC24_A : NR_HIP_CRC16;
-    payload_end = std::max(payload_end, (size_t)t.payload_off + t.A / 8);
-    coded_end = std::max(coded_end, (size_t)t.coded_off + t.G);
-    for (uint32_t fb = 0; fb < t.A / 8; fb += TB_CRC_CHUNK)
-      cj.push_back(tb_crc_chunk_job{i, fb});
-    const ldpc_code_desc_t &hc = ce->host;
-    const int N = (hc.ncols - 2) * hc.Z;
-    int nthr, nlds;
-    ldpc_enc_launch_shape(hc, &nthr, &nlds);
-    enc_threads = std::max(enc_threads, nthr);
-    enc_lds = std::max(enc_lds, nlds);
-    uint32_t r_offset = 0;
-    for (uint32_t r = 0; r < sg.C; r++) {
-      tb_tx_seg_job j;
-      memset(&j, 0, sizeof(j));
-      j.b_off = tbj[i].b_off;
-      if (!fused) { /* the fused kernel keeps c and d in LDS */
-        j.c_off = ar.take(sg.K / 8 + 4);
-        j.d_off = ar.take(N);
+  if (!pl.matches(tbs, ntb, fused ? 1u : 0u)) {
+    pl.valid = false;
+    std::vector<tb_tx_tb_job> tbj(ntb);
+    std::vector<tb_tx_seg_job> sj;
+    std::vector<ldpc_enc_job> ej;
+    std::vector<tb_crc_chunk_job> cj;
+    Arena ar;
+    int enc_threads = 64, enc_lds = 0;
+    TbExtent ex;
+    for (uint32_t i = 0; i < ntb; i++) {
+      const nrLDPC_hip_tb_t &t = tbs[i];
+      if (tb_validate(t) != 0)
+        return -1;
+      /* nr_dlsch_coding.c:300-331 */
+      const uint32_t B = t.A + (t.A > NR_HIP_MAX_PDSCH_TBS ? 24 : 16);
+      nr_hip_seg_t sg;
+      if (nr_hip_segmentation(B, t.BG, &sg) != 0)
+        return set_error("nr_segmentation: unsupported block size");
+      const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
+      if (!ce)
+        return -1;
+      tbj[i].payload_off = t.payload_off;
+      tbj[i].b_off = ar.take(B / 8 + 4);
+      tbj[i].A = t.A;
+      tbj[i].B = B;
+      tbj[i].crc_type = t.A > NR_HIP_MAX_PDSCH_TBS ? NR_HIP_CRC24_A : NR_HIP_CRC16;
+      ex.add(ex.pay_lo, ex.pay_hi, (size_t)t.payload_off, (size_t)t.payload_off + t.A / 8);
+      ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
+      ex.cod_sum += t.G;
+      for (uint32_t fb = 0; fb < t.A / 8; fb += TB_CRC_CHUNK)
+        cj.push_back(tb_crc_chunk_job{i, fb});
+      const ldpc_code_desc_t &hc = ce->host;
+      const int N = (hc.ncols - 2) * hc.Z;
+      int nthr, nlds;
+      ldpc_enc_launch_shape(hc, &nthr, &nlds);
+      enc_threads = std::max(enc_threads, nthr);
+      enc_lds = std::max(enc_lds, nlds);
+      uint32_t r_offset = 0;
+      for (uint32_t r = 0; r < sg.C; r++) {
+        tb_tx_seg_job j;
+        memset(&j, 0, sizeof(j));
+        j.b_off = tbj[i].b_off;
+        if (!fused) { /* the fused kernel keeps c and d in LDS */
+          j.c_off = ar.take(sg.K / 8 + 4);
+          j.d_off = ar.take(N);
+        }
+        j.out_off = t.coded_off + r_offset;
+        j.r = r; j.C = sg.C; j.Kprime = sg.Kprime; j.L = sg.L; j.K = sg.K;
+        j.E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
+        j.Qm = t.Qm;
+        nr_hip_rm_t rm;
+        if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, j.E, &rm) != 0)
+          return set_error("nr_rate_matching: invalid parameters");
+        j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+        r_offset += j.E;
+        sj.push_back(j);
+        ldpc_enc_job e;
+        e.code = ce->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
+        ej.push_back(e);
       }
-      j.out_off = t.coded_off + r_offset;
-      j.r = r; j.C = sg.C; j.Kprime = sg.Kprime; j.L = sg.L; j.K = sg.K;
-      j.E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
-      j.Qm = t.Qm;
-      nr_hip_rm_t rm;
-      if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, j.E, &rm) != 0)
-        return set_error("nr_rate_matching: invalid parameters");
-      j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
-      r_offset += j.E;
-      sj.push_back(j);
-      ldpc_enc_job e;
-      e.code = ce->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
-      ej.push_back(e);
     }
-  }
-  const size_t n_seg = sj.size();
-  const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_tx_tb_job), 16),
-               o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
-               o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
-               o_acc = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16),
-               jobs_bytes = o_acc + align_up((size_t)b->n_tb * sizeof(uint32_t), 16); /* CRC accumulators: uploaded as zeros */
-  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes) != 0)
-    return -1;
-  memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
-  memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
-  memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
-  memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
-  memcpy(c.jobs_h.p + o_enc, ej.data(), n_seg * sizeof(ldpc_enc_job));
-  if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
-    return -1;
-  pl.n_seg = n_seg; pl.n_aux = cj.size(); pl.scratch_top = ar.top; pl.payload_end = payload_end; pl.coded_end = coded_end;
-  pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_enc; pl.off[3] = o_chk; pl.off[4] = o_acc;
-  pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
-  pl.remember(b, fused ? 1u : 0u);
+    const size_t n_seg = sj.size();
+    const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_tx_tb_job), 16),
+                 o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
+                 o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
+                 o_acc = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16),
+                 jobs_bytes = o_acc + align_up((size_t)ntb * sizeof(uint32_t), 16); /* CRC accumulators: uploaded as zeros */
+    if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes) != 0)
+      return -1;
+    memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
+    memcpy(c.jobs_h.p + o_chk, cj.data(), cj.size() * sizeof(tb_crc_chunk_job));
+    memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_tx_tb_job));
+    memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_tx_seg_job));
+    memcpy(c.jobs_h.p + o_enc, ej.data(), n_seg * sizeof(ldpc_enc_job));
+    if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
+      return -1;
+    pl.n_seg = n_seg; pl.n_aux = cj.size(); pl.scratch_top = ar.top;
+    pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi;
+    pl.out_dense = ex.cod_sum == ex.cod_hi - ex.cod_lo;
+    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_enc; pl.off[3] = o_chk; pl.off[4] = o_acc;
+    pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
+    pl.remember(tbs, ntb, fused ? 1u : 0u);
   }
   if (c.scratch.ensure(pl.scratch_top) != 0)
     return -1;
-  const size_t n_seg = pl.n_seg, payload_end = pl.payload_end, coded_end = pl.coded_end;
+  const size_t n_seg = pl.n_seg;
   const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_enc = pl.off[2], o_chk = pl.off[3], o_acc = pl.off[4];
   const int enc_threads = pl.threads[0], enc_lds = pl.lds[0];
   const uint8_t *payload = b->payload;
   uint8_t *coded = static_cast<uint8_t *>(b->coded);
   if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
-    if (c.io_payload.ensure(payload_end) != 0 || c.io_coded.ensure(coded_end) != 0)
+    const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
+    if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload, payload_end, hipMemcpyHostToDevice, s));
-    payload = c.io_payload.p;
-    coded = c.io_coded.p;
+    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload + pay_lo, pay_n, hipMemcpyHostToDevice, s));
+    payload = c.io_payload.p - pay_lo;
+    coded = c.io_coded.p - cod_lo;
   }
   const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(pl.jobs_d.p + o_tb);
   const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(pl.jobs_d.p + o_seg);
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
-  HIP_TRY(tb_launch_tx_crc(d_tb, b->n_tb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
-                           payload, c.scratch.p, d_acc, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+  HIP_TRY(tb_launch_tx_crc(d_tb, ntb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
+                           payload, c.scratch.p, d_acc, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
   const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(pl.jobs_d.p + o_enc);
   if (fused) {
     HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, enc_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
-                               g.crc_pow[NR_HIP_CRC24_B], s));
+                               G().crc_pow[NR_HIP_CRC24_B], s));
   } else {
-    HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, g.crc_pow[NR_HIP_CRC24_B], s));
+    HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, G().crc_pow[NR_HIP_CRC24_B], s));
     ldpc_enc_args ea;
     memset(&ea, 0, sizeof(ea));
     ea.in = c.scratch.p;
@@ -302,181 +324,192 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
     HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
   }
   if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
-    HIP_TRY(hipMemcpyAsync(b->coded, coded, coded_end, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    uint8_t *hc = static_cast<uint8_t *>(b->coded);
+    if (pl.out_dense) {
+      HIP_TRY(hipMemcpyAsync(hc + pl.ext[2], c.io_coded.p, pl.ext[3] - pl.ext[2], hipMemcpyDeviceToHost, s));
+    } else {
+      for (uint32_t i = 0; i < ntb; i++)
+        HIP_TRY(hipMemcpyAsync(hc + tbs[i].coded_off, c.io_coded.p + (tbs[i].coded_off - pl.ext[2]), tbs[i].G, hipMemcpyDeviceToHost, s));
+    }
   }
   return 0;
 }
 
-int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
+int tb_tx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t ntb)
+{
+  if (b->mem == NRLDPC_HIP_MEM_DEVICE || ntb == 0)
+    return 0;
+  HIP_TRY(hipStreamSynchronize(tls_tb.own));
+  return 0;
+}
+
+/* ---- RX: transport blocks [tb0, tb0+ntb) of b on the current device ---------------------------------------------------- */
+int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
 {
   hipStream_t s;
   if (tb_begin(b, s) != 0)
     return -1;
-  if (!b->harq || !b->ack || !b->iter_max || b->harq_stride < 66 * 384)
-    return set_error("decode needs harq (stride >= 66*384), ack and iter_max buffers");
-  if (b->n_tb == 0)
+  if (ntb == 0)
     return 0;
+  nrLDPC_hip_tb_t *tbs = b->tb + tb0;
   TbCtx &c = tls_tb;
   TbPlan &pl = c.rx;
-  if (pl.matches(b, (uint32_t)b->harq_stride)) {
-    for (uint32_t i = 0; i < b->n_tb; i++) /* nr_get_R_ldpc_decoder's state leaves the call as it did the first time */
-      b->tb[i].llrLen = pl.llr_len[i];
+  if (pl.matches(tbs, ntb, (uint32_t)b->harq_stride)) {
+    for (uint32_t i = 0; i < ntb; i++) /* nr_get_R_ldpc_decoder's state leaves the call as it did the first time */
+      tbs[i].llrLen = pl.llr_len[i];
   } else {
-  pl.valid = false;
-  std::vector<uint8_t> key_tb((const uint8_t *)b->tb, (const uint8_t *)b->tb + (size_t)b->n_tb * sizeof(nrLDPC_hip_tb_t));
-  std::vector<tb_rx_tb_job> tbj(b->n_tb);
-  std::vector<tb_rx_seg_job> sj;
-  std::vector<ldpc_dec_job> fast_jobs, gen_jobs;
-  Arena ar;
-  int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
-  size_t payload_end = 0, llr_end = 0, harq_end = 0;
-  /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
-  uint32_t n_seg_total = 0;
-  for (uint32_t i = 0; i < b->n_tb; i++) {
-    nr_hip_seg_t sg;
-    if (b->tb[i].A && (b->tb[i].BG == 1 || b->tb[i].BG == 2) &&
-        nr_hip_segmentation((uint32_t)nr_hip_len_with_crc(1, (int)b->tb[i].A), b->tb[i].BG, &sg) == 0)
-      n_seg_total += sg.C;
-  }
-  const bool lat_shape = n_seg_total <= (uint32_t)g.n_cus;
-  for (uint32_t i = 0; i < b->n_tb; i++) {
-    nrLDPC_hip_tb_t &t = b->tb[i];
-    if (tb_validate(t) != 0)
-      return -1;
-    /* nr_ulsch_decoding.c:386-395: segmentation parameters from lenWithCrc(1, A) */
-    const uint32_t B = (uint32_t)nr_hip_len_with_crc(1, (int)t.A);
-    nr_hip_seg_t sg;
-    if (nr_hip_segmentation(B, t.BG, &sg) != 0)
-      return set_error("nr_segmentation: unsupported block size");
-    const CodeEntry *full = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
-    if (!full)
-      return -1;
-    const uint32_t cstride = (uint32_t)align_up(out_bytes_of(full->host, 0), 16);
-    tb_rx_tb_job &tj = tbj[i];
-    memset(&tj, 0, sizeof(tj));
-    tj.payload_off = t.payload_off;
-    tj.b_off = ar.take(B / 8 + 4);
-    tj.c_off0 = ar.take((size_t)cstride * sg.C);
-    tj.c_stride = cstride;
-    tj.seg0 = (uint32_t)sj.size();
-    tj.C = sg.C;
-    tj.A = t.A;
-    tj.B = B;
-    tj.crc_type = (uint32_t)nr_hip_crc_type(1, (int)t.A);
-    tj.num_max_iter = t.numMaxIter;
-    tj.seg_bytes = sg.K / 8 - sg.F / 8 - (sg.C > 1 ? 3 : 0); /* phy_procedures_nr_gNB.c:287 */
-    payload_end = std::max(payload_end, (size_t)t.payload_off + t.A / 8);
-    llr_end = std::max(llr_end, (size_t)t.coded_off + t.G);
-    harq_end = std::max(harq_end, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
-    uint32_t r_offset = 0;
-    int llrLen = t.llrLen;
-    for (uint32_t r = 0; r < sg.C; r++) {
-      const uint32_t E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
-      /* nr_ulsch_decoding.c:439-444: decoder rate mode, stateful in llrLen */
-      const int R = nr_hip_get_R_ldpc_decoder(t.rv, (int)E, t.BG, (int)sg.Zc, &llrLen, t.round);
-      const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, R);
-      if (!ce)
-        return -1;
-      const ldpc_code_desc_t &hc = ce->host;
-      nr_hip_rm_t rm;
-      if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, E, &rm) != 0)
-        return set_error("nr_rate_matching_rx: invalid parameters");
-      tb_rx_seg_job j;
-      memset(&j, 0, sizeof(j));
-      j.llr_off = t.coded_off + r_offset;
-      j.harq_off = t.harq_off + (uint64_t)r * b->harq_stride;
-      j.l_off = ar.take(hc.num_llr);
-      j.E = E; j.Qm = t.Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
-      j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
-      j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
-      j.c_off = tj.c_off0 + (uint64_t)r * cstride;
-      j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
-      ldpc_dec_job dj;
-      const ldpc_code_desc_t &shape = lat_shape ? ce->host_lat : ce->host;
-      dj.code = (hc.f_ok && lat_shape) ? ce->dev_lat : ce->dev;
-      dj.llr_off = j.l_off;
-      dj.out_off = tj.c_off0 + (uint64_t)r * cstride;
-      dj.num_max_iter = t.numMaxIter;
-      dj.E = nr_hip_len_with_crc((int)sg.C, (int)t.A); /* nr_ulsch_decoding.c:190 */
-      dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
-      dj.iter_idx = (int32_t)sj.size();
-      dj.abort_idx = tb_abort_enabled() ? (int32_t)i : -1;
-      dj.pad = 0;
-      if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
-        return set_error("CRC length outside the code block");
-      if (hc.f_ok) {
-        fast_jobs.push_back(dj);
-        fast_threads = std::max(fast_threads, shape.f_n_threads);
-        fast_lds = std::max(fast_lds, shape.f_lds_total);
-      } else {
-        gen_jobs.push_back(dj);
-        gen_threads = std::max(gen_threads, hc.n_threads);
-        gen_lds = std::max(gen_lds, hc.lds_total);
-      }
-      sj.push_back(j);
-      r_offset += E;
+    pl.valid = false;
+    std::vector<uint8_t> key_tb((const uint8_t *)tbs, (const uint8_t *)tbs + (size_t)ntb * sizeof(nrLDPC_hip_tb_t));
+    std::vector<tb_rx_tb_job> tbj(ntb);
+    std::vector<tb_rx_seg_job> sj;
+    std::vector<ldpc_dec_job> fast_jobs, gen_jobs;
+    Arena ar;
+    int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
+    TbExtent ex;
+    /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
+    uint32_t n_seg_total = 0;
+    for (uint32_t i = 0; i < ntb; i++) {
+      nr_hip_seg_t sg;
+      if (tbs[i].A && (tbs[i].BG == 1 || tbs[i].BG == 2) &&
+          nr_hip_segmentation((uint32_t)nr_hip_len_with_crc(1, (int)tbs[i].A), tbs[i].BG, &sg) == 0)
+        n_seg_total += sg.C;
     }
-    t.llrLen = llrLen;
-  }
-  const size_t n_seg = sj.size();
-  const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
-               o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
-               o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
-               o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators, then the per-TB
-                                                                                         abort flags: uploaded as zeros */
-               jobs_bytes = o_acc + align_up((size_t)b->n_tb * 2 * sizeof(uint32_t), 16),
-               o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
-  if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
-      pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
-    return -1;
-  memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
-  memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
-  memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
-  memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
-  memcpy(c.jobs_h.p + o_gen, gen_jobs.data(), gen_jobs.size() * sizeof(ldpc_dec_job));
-  if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
-    return -1;
-  pl.n_seg = n_seg; pl.scratch_top = ar.top; pl.payload_end = payload_end; pl.coded_end = llr_end; pl.harq_end = harq_end;
-  pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
-  pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
-  pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
-  pl.llr_len.resize(b->n_tb);
-  for (uint32_t i = 0; i < b->n_tb; i++)
-    pl.llr_len[i] = b->tb[i].llrLen;
-  /* the key is the descriptor array as it ARRIVED (llrLen is updated by the loop above) */
-  pl.key.resize(key_tb.size() + 8);
-  {
-    const uint32_t salt = (uint32_t)b->harq_stride;
-    memcpy(pl.key.data(), &b->n_tb, 4);
-    memcpy(pl.key.data() + 4, &salt, 4);
-    memcpy(pl.key.data() + 8, key_tb.data(), key_tb.size());
-    pl.valid = true;
-  }
+    const bool lat_shape = n_seg_total <= (uint32_t)G().n_cus;
+    for (uint32_t i = 0; i < ntb; i++) {
+      nrLDPC_hip_tb_t &t = tbs[i];
+      if (tb_validate(t) != 0)
+        return -1;
+      /* nr_ulsch_decoding.c:386-395: segmentation parameters from lenWithCrc(1, A) */
+      const uint32_t B = (uint32_t)nr_hip_len_with_crc(1, (int)t.A);
+      nr_hip_seg_t sg;
+      if (nr_hip_segmentation(B, t.BG, &sg) != 0)
+        return set_error("nr_segmentation: unsupported block size");
+      const CodeEntry *full = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
+      if (!full)
+        return -1;
+      const uint32_t cstride = (uint32_t)align_up(out_bytes_of(full->host, 0), 16);
+      tb_rx_tb_job &tj = tbj[i];
+      memset(&tj, 0, sizeof(tj));
+      tj.payload_off = t.payload_off;
+      tj.b_off = ar.take(B / 8 + 4);
+      tj.c_off0 = ar.take((size_t)cstride * sg.C);
+      tj.c_stride = cstride;
+      tj.seg0 = (uint32_t)sj.size();
+      tj.C = sg.C;
+      tj.A = t.A;
+      tj.B = B;
+      tj.crc_type = (uint32_t)nr_hip_crc_type(1, (int)t.A);
+      tj.num_max_iter = t.numMaxIter;
+      tj.seg_bytes = sg.K / 8 - sg.F / 8 - (sg.C > 1 ? 3 : 0); /* phy_procedures_nr_gNB.c:287 */
+      ex.add(ex.pay_lo, ex.pay_hi, (size_t)t.payload_off, (size_t)t.payload_off + t.A / 8);
+      ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
+      ex.add(ex.harq_lo, ex.harq_hi, (size_t)t.harq_off, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
+      ex.pay_sum += t.A / 8;
+      uint32_t r_offset = 0;
+      int llrLen = t.llrLen;
+      for (uint32_t r = 0; r < sg.C; r++) {
+        const uint32_t E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
+        /* nr_ulsch_decoding.c:439-444: decoder rate mode, stateful in llrLen */
+        const int R = nr_hip_get_R_ldpc_decoder(t.rv, (int)E, t.BG, (int)sg.Zc, &llrLen, t.round);
+        const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, R);
+        if (!ce)
+          return -1;
+        const ldpc_code_desc_t &hc = ce->host;
+        nr_hip_rm_t rm;
+        if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, E, &rm) != 0)
+          return set_error("nr_rate_matching_rx: invalid parameters");
+        tb_rx_seg_job j;
+        memset(&j, 0, sizeof(j));
+        j.llr_off = t.coded_off + r_offset;
+        j.harq_off = t.harq_off + (uint64_t)r * b->harq_stride;
+        j.l_off = ar.take(hc.num_llr);
+        j.E = E; j.Qm = t.Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+        j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
+        j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
+        j.c_off = tj.c_off0 + (uint64_t)r * cstride;
+        j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
+        ldpc_dec_job dj;
+        const ldpc_code_desc_t &shape = lat_shape ? ce->host_lat : ce->host;
+        dj.code = (hc.f_ok && lat_shape) ? ce->dev_lat : ce->dev;
+        dj.llr_off = j.l_off;
+        dj.out_off = tj.c_off0 + (uint64_t)r * cstride;
+        dj.num_max_iter = t.numMaxIter;
+        dj.E = nr_hip_len_with_crc((int)sg.C, (int)t.A); /* nr_ulsch_decoding.c:190 */
+        dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
+        dj.iter_idx = (int32_t)sj.size();
+        dj.abort_idx = tb_abort_enabled() ? (int32_t)i : -1;
+        dj.pad = 0;
+        if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
+          return set_error("CRC length outside the code block");
+        if (hc.f_ok) {
+          fast_jobs.push_back(dj);
+          fast_threads = std::max(fast_threads, shape.f_n_threads);
+          fast_lds = std::max(fast_lds, shape.f_lds_total);
+        } else {
+          gen_jobs.push_back(dj);
+          gen_threads = std::max(gen_threads, hc.n_threads);
+          gen_lds = std::max(gen_lds, hc.lds_total);
+        }
+        sj.push_back(j);
+        r_offset += E;
+      }
+      t.llrLen = llrLen;
+    }
+    const size_t n_seg = sj.size();
+    const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
+                 o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
+                 o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
+                 o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators, then the per-TB
+                                                                                           abort flags: uploaded as zeros */
+                 jobs_bytes = o_acc + align_up((size_t)ntb * 2 * sizeof(uint32_t), 16),
+                 o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
+    if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
+        pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
+      return -1;
+    memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
+    memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
+    memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
+    memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
+    memcpy(c.jobs_h.p + o_gen, gen_jobs.data(), gen_jobs.size() * sizeof(ldpc_dec_job));
+    if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
+      return -1;
+    pl.n_seg = n_seg; pl.scratch_top = ar.top;
+    pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi; pl.ext[4] = ex.harq_lo; pl.ext[5] = ex.harq_hi;
+    pl.out_dense = ex.pay_sum == ex.pay_hi - ex.pay_lo;
+    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
+    pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
+    pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
+    pl.llr_len.resize(ntb);
+    for (uint32_t i = 0; i < ntb; i++)
+      pl.llr_len[i] = tbs[i].llrLen;
+    /* the key is the descriptor array as it ARRIVED (llrLen is updated by the loop above) */
+    pl.remember(key_tb.data(), ntb, (uint32_t)b->harq_stride);
   }
   if (c.scratch.ensure(pl.scratch_top) != 0)
     return -1;
-  const size_t n_seg = pl.n_seg, payload_end = pl.payload_end, llr_end = pl.coded_end, harq_end = pl.harq_end;
+  const size_t n_seg = pl.n_seg;
   const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_fast = pl.off[2], o_gen = pl.off[3], o_iter = pl.off[4], o_acc = pl.off[5];
   const int fast_threads = pl.threads[0], fast_lds = pl.lds[0], gen_threads = pl.threads[1], gen_lds = pl.lds[1];
   int32_t *d_iter = reinterpret_cast<int32_t *>(pl.jobs_d.p + o_iter);
   uint8_t *payload = b->payload;
   const int16_t *llr = static_cast<const int16_t *>(b->coded);
   int16_t *harq = b->harq;
-  uint8_t *ack = b->ack;
-  int32_t *iter_max = b->iter_max;
+  uint8_t *ack = b->ack + tb0;
+  int32_t *iter_max = b->iter_max + tb0;
   const bool host = b->mem != NRLDPC_HIP_MEM_DEVICE;
   if (host) {
-    if (c.io_payload.ensure(payload_end) != 0 || c.io_coded.ensure(llr_end * 2) != 0 || c.io_harq.ensure(harq_end * 2) != 0 ||
-        c.io_small.ensure((size_t)b->n_tb * 8 + 64) != 0 || c.small_h.ensure((size_t)b->n_tb * 8 + 64) != 0)
+    const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2],
+                 harq_lo = pl.ext[4], harq_n = pl.ext[5] - pl.ext[4];
+    if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n * 2) != 0 || c.io_harq.ensure(harq_n * 2) != 0 ||
+        c.io_small.ensure((size_t)ntb * 8 + 64) != 0 || c.small_h.ensure((size_t)ntb * 8 + 64) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.io_coded.p, b->coded, llr_end * 2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq, harq_end * 2, hipMemcpyHostToDevice, s));
-    payload = c.io_payload.p;
-    llr = reinterpret_cast<const int16_t *>(c.io_coded.p);
-    harq = reinterpret_cast<int16_t *>(c.io_harq.p);
+    HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq + harq_lo, harq_n * 2, hipMemcpyHostToDevice, s));
+    payload = c.io_payload.p - pay_lo;
+    llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
+    harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
-    ack = c.io_small.p + (size_t)b->n_tb * 4;
+    ack = c.io_small.p + (size_t)ntb * 4;
   }
   HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, llr, harq,
                                reinterpret_cast<int8_t *>(c.scratch.p), s));
@@ -488,9 +521,9 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   da.out_mode = 0;
   da.use_crc = 1;
   for (int k = 0; k < 4; k++)
-    da.crc_pow_tbl[k] = g.crc_pow[k];
-  da.crc_pow_tbl[NR_HIP_CRC24_A] = g.crc_pow_24a_long;
-  int *d_abort = reinterpret_cast<int *>(pl.jobs_d.p + o_acc) + b->n_tb; /* zero on entry, left zero by the verdict kernel */
+    da.crc_pow_tbl[k] = G().crc_pow[k];
+  da.crc_pow_tbl[NR_HIP_CRC24_A] = G().crc_pow_24a_long;
+  int *d_abort = reinterpret_cast<int *>(pl.jobs_d.p + o_acc) + ntb; /* zero on entry, left zero by the verdict kernel */
   da.tb_abort = d_abort;
   if (pl.n_fast) {
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_fast);
@@ -501,18 +534,114 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
     HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)pl.n_gen, s));
   }
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
-  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), b->n_tb,
+  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), ntb,
                                 reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
-                                c.scratch.p, payload, ack, iter_max, d_acc, d_abort, g.crc_pow_24a_long, g.crc_pow[NR_HIP_CRC16], s));
+                                c.scratch.p, payload, ack, iter_max, d_acc, d_abort, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
   if (host) {
-    HIP_TRY(hipMemcpyAsync(b->payload, payload, payload_end, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(b->harq, harq, harq_end * 2, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)b->n_tb * 5, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    memcpy(b->iter_max, c.small_h.p, (size_t)b->n_tb * 4);
-    memcpy(b->ack, c.small_h.p + (size_t)b->n_tb * 4, b->n_tb);
+    if (pl.out_dense) {
+      HIP_TRY(hipMemcpyAsync(b->payload + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDeviceToHost, s));
+    } else {
+      for (uint32_t i = 0; i < ntb; i++)
+        HIP_TRY(hipMemcpyAsync(b->payload + tbs[i].payload_off, c.io_payload.p + (tbs[i].payload_off - pl.ext[0]), tbs[i].A / 8,
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(b->harq + pl.ext[4], c.io_harq.p, (pl.ext[5] - pl.ext[4]) * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)ntb * 5, hipMemcpyDeviceToHost, s));
   }
   return 0;
+}
+
+int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
+{
+  if (b->mem == NRLDPC_HIP_MEM_DEVICE || ntb == 0)
+    return 0;
+  TbCtx &c = tls_tb;
+  HIP_TRY(hipStreamSynchronize(c.own));
+  memcpy(b->iter_max + tb0, c.small_h.p, (size_t)ntb * 4);
+  memcpy(b->ack + tb0, c.small_h.p + (size_t)ntb * 4, ntb);
+  return 0;
+}
+
+/* Whole transport blocks per device, contiguous index ranges, balanced by decoder work ~ segments x edges x Zc (SURVEY
+ * 8e: a TB stays on one GPU so that its CRC, its abort flag and its HARQ buffers stay local).  cut[k] .. cut[k+1] = the
+ * share of part k. */
+void tb_partition(const nrLDPC_hip_tb_batch_t *b, int parts, uint32_t *cut)
+{
+  std::vector<double> cost(b->n_tb, 1.0);
+  double total = 0;
+  for (uint32_t i = 0; i < b->n_tb; i++) {
+    const nrLDPC_hip_tb_t &t = b->tb[i];
+    nr_hip_seg_t sg;
+    if (t.A && (t.BG == 1 || t.BG == 2) && nr_hip_segmentation((uint32_t)nr_hip_len_with_crc(1, (int)t.A), t.BG, &sg) == 0)
+      cost[i] = (double)sg.C * sg.Zc * (t.BG == 1 ? 316.0 : 197.0);
+    total += cost[i];
+  }
+  cut[0] = 0;
+  double acc = 0;
+  uint32_t i = 0;
+  for (int k = 1; k < parts; k++) {
+    const double target = total * k / parts;
+    while (i < b->n_tb && acc + cost[i] * 0.5 <= target)
+      acc += cost[i++];
+    cut[k] = i;
+  }
+  cut[parts] = b->n_tb;
+}
+
+/* run enqueue on every part, then finish on every part (so that the devices work concurrently) */
+template <typename Enq, typename Fin> int tb_run_sharded(const nrLDPC_hip_tb_batch_t *b, Enq enq, Fin fin)
+{
+  if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
+    Device *d = device_of_pointer(b->coded);
+    if (!d)
+      return -1;
+    UseDevice use(*d);
+    return enq(0u, b->n_tb) != 0 ? -1 : fin(0u, b->n_tb);
+  }
+  if (ensure_ready() != 0)
+    return -1;
+  const int parts = (b->n_tb >= 2u * (uint32_t)g.n_shard) ? g.n_shard : 1;
+  uint32_t cut[NRLDPC_HIP_MAX_DEVICES + 1];
+  tb_partition(b, parts, cut);
+  int rc = 0;
+  for (int k = 0; k < parts && rc == 0; k++) {
+    UseDevice use(g.dev[k]);
+    rc = enq(cut[k], cut[k + 1] - cut[k]);
+  }
+  for (int k = 0; k < parts; k++) { /* also after an error: nothing stays in flight */
+    UseDevice use(g.dev[k]);
+    if (rc == 0)
+      rc = fin(cut[k], cut[k + 1] - cut[k]);
+    else
+      tls_tb.drain();
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
+{
+  if (!b || !b->tb || !b->payload || !b->coded)
+    return set_error("null argument");
+  if (b->n_tb == 0)
+    return ensure_ready();
+  return tb_run_sharded(
+      b, [&](uint32_t tb0, uint32_t n) { return tb_tx_enqueue(b, tb0, n); }, [&](uint32_t, uint32_t n) { return tb_tx_finish(b, n); });
+}
+
+int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
+{
+  if (!b || !b->tb || !b->payload || !b->coded)
+    return set_error("null argument");
+  if (!b->harq || !b->ack || !b->iter_max || b->harq_stride < 66 * 384)
+    return set_error("decode needs harq (stride >= 66*384), ack and iter_max buffers");
+  if (b->n_tb == 0)
+    return ensure_ready();
+  return tb_run_sharded(
+      b, [&](uint32_t tb0, uint32_t n) { return tb_rx_enqueue(b, tb0, n); }, [&](uint32_t tb0, uint32_t n) { return tb_rx_finish(b, tb0, n); });
 }
 
 } /* extern "C" */

@@ -1,12 +1,14 @@
-"""Sharding of independent code blocks over the GPUs of one node (one process per GPU, torch.distributed).
+"""Sharding of independent code blocks / transport blocks over the GPUs of one node (one process per GPU,
+torch.distributed; the single-process, many-GPU form of the same split lives inside the library: NRLDPC_HIP_DEVICES).
 
 The reference parallelises this path by handing every code segment to a CPU thread-pool worker
-(openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:435-468); segments never exchange data, and the only
-coupling is the transport-block-wide abort flag.  The multi-GPU analogue therefore needs NO collective on
-the data path: each rank decodes its own contiguous range of blocks (whole transport blocks stay on one
-rank so that TB-level CRC/abort stays local).  Collectives appear only at the edges, when a batch arrives
-on one rank: one scatter of the LLR shards out (root -> peers over the direct xGMI links) and one gather of
-the packed bits / pass counts back.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+(openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:435-468, pull loop SCHED_NR/phy_procedures_nr_gNB.c:911-917); segments
+never exchange data, and the only coupling is the transport-block-wide abort flag.  The multi-GPU analogue therefore
+needs NO collective on the data path: each rank works on a contiguous range of blocks, whole transport blocks staying on
+one rank so that TB CRC, abort flag and HARQ soft buffers stay local.  Communication appears only at the edges, when a
+slot's data arrives on one rank: the LLR ranges go out root -> peers (point-to-point, exact sizes: over the direct xGMI
+links, no padding, no staging copies) and the payload bytes / ACKs / pass counts come back the same way.  Backend
+"nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -22,7 +24,8 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def shard_transport_blocks(segments_per_tb: Sequence[int], world: int) -> List[List[int]]:
     """Assign whole transport blocks to ranks, balancing the number of code segments (LPT greedy).
-    Returns per rank the list of TB indices (ascending)."""
+    Returns per rank the list of TB indices (ascending).  (Scattered ownership: for data that is already distributed;
+    a slot that arrives on one rank is cut into contiguous ranges instead, see partition_transport_blocks.)"""
     order = sorted(range(len(segments_per_tb)), key=lambda i: (-segments_per_tb[i], i))
     load = [0] * world
     owner: List[List[int]] = [[] for _ in range(world)]
@@ -33,73 +36,159 @@ def shard_transport_blocks(segments_per_tb: Sequence[int], world: int) -> List[L
     return [sorted(o) for o in owner]
 
 
-def scatter_blocks(llr_root, n_blocks: int, row_bytes: int, root: int = 0, group=None, device=None):
-    """Distribute an [n_blocks, row_bytes] int8 batch that lives on `root` (pass None elsewhere).
-    Returns this rank's [hi-lo, row_bytes] shard."""
+def partition_transport_blocks(costs: Sequence[float], parts: int) -> List[int]:
+    """Contiguous ranges of whole transport blocks balanced by cost; returns parts + 1 cut points.  Same rule as the
+    library's in-process split (csrc/tb_api.inc.cpp tb_partition): a block goes to the part whose target its centre
+    falls under."""
+    total = float(sum(costs))
+    cut, acc, i = [0], 0.0, 0
+    for k in range(1, parts):
+        target = total * k / parts
+        while i < len(costs) and acc + costs[i] * 0.5 <= target:
+            acc += costs[i]
+            i += 1
+        cut.append(i)
+    cut.append(len(costs))
+    return cut
+
+
+def tb_cost(tb: dict) -> float:
+    """Decoder work of a transport block ~ segments x edges x Zc."""
+    from . import ldpc
+    s = ldpc.nr_segmentation(tb["A"] + (24 if tb["A"] > 3824 else 16), tb["BG"])
+    return float(s["C"] * s["Z"] * (316 if tb["BG"] == 1 else 197))
+
+
+def _rank_world(group=None):
+    """(rank, world); (0, 1) without an initialised process group, so that the same code runs on a single GPU."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+# ---- edges: exact-size point-to-point -------------------------------------------------------------------------------
+def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: int = 0, group=None, device=None):
+    """`flat_root`: 1-D tensor on `root` (None elsewhere); rank r receives elements [ranges[r][0], ranges[r][1]).
+    Slices of the root tensor are sent as they are (views), every receiver allocates exactly its share."""
     import torch
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_range(n_blocks, rank, world)
-    if device is None:
-        device = llr_root.device if llr_root is not None else torch.device("cpu")
-    shard = torch.empty((hi - lo, row_bytes), dtype=torch.int8, device=device)
+    rank, world = _rank_world(group)
+    lo, hi = ranges[rank]
     if world == 1:
-        shard.copy_(llr_root)
-        return shard
-    # ranks hold shards of (at most one row) different length: pad to the longest for dist.scatter
-    longest = shard_range(n_blocks, 0, world)[1]
-    buf = torch.zeros((longest, row_bytes), dtype=torch.int8, device=device)
-    parts = None
+        return flat_root[lo:hi]
     if rank == root:
-        parts = []
-        for r in range(world):
-            a, b = shard_range(n_blocks, r, world)
-            p = torch.zeros((longest, row_bytes), dtype=torch.int8, device=device)
-            p[:b - a] = llr_root[a:b]
-            parts.append(p)
-    dist.scatter(buf, parts, src=root, group=group)
-    shard.copy_(buf[:hi - lo])
+        device = flat_root.device if device is None else device
+        ops = [dist.P2POp(dist.isend, flat_root[a:b], dist.get_global_rank(group, r) if group is not None else r, group)
+               for r, (a, b) in enumerate(ranges) if r != root and b > a]
+        mine = flat_root[lo:hi]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return mine
+    shard = torch.empty((hi - lo,), dtype=dtype, device=device if device is not None else "cpu")
+    if hi > lo:
+        src = dist.get_global_rank(group, root) if group is not None else root
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, shard, src, group)]):
+            w.wait()
     return shard
 
 
-def gather_results(out_local, n_iter_local, n_blocks: int, root: int = 0, group=None):
-    """Collect every rank's [n_local, out_bytes] uint8 bits and [n_local] int32 pass counts on `root`
-    (returns (out, n_iter) there, (None, None) elsewhere)."""
+def gather_ranges(local, ranges: Sequence[Tuple[int, int]], total: int, root: int = 0, group=None):
+    """Inverse of scatter_ranges: returns the assembled [total] tensor on `root` (None elsewhere)."""
     import torch
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = _rank_world(group)
+    lo, hi = ranges[rank]
     if world == 1:
-        return out_local, n_iter_local
-    longest = shard_range(n_blocks, 0, world)[1]
-    ob = out_local.shape[1]
-    pad_out = torch.zeros((longest, ob), dtype=out_local.dtype, device=out_local.device)
-    pad_it = torch.zeros((longest,), dtype=n_iter_local.dtype, device=n_iter_local.device)
-    pad_out[:out_local.shape[0]] = out_local
-    pad_it[:n_iter_local.shape[0]] = n_iter_local
-    outs = [torch.empty_like(pad_out) for _ in range(world)] if rank == root else None
-    its = [torch.empty_like(pad_it) for _ in range(world)] if rank == root else None
-    dist.gather(pad_out, outs, dst=root, group=group)
-    dist.gather(pad_it, its, dst=root, group=group)
-    if rank != root:
-        return None, None
-    out = torch.cat([outs[r][:shard_range(n_blocks, r, world)[1] - shard_range(n_blocks, r, world)[0]] for r in range(world)])
-    it = torch.cat([its[r][:shard_range(n_blocks, r, world)[1] - shard_range(n_blocks, r, world)[0]] for r in range(world)])
-    return out, it
+        return local[:hi - lo] if hi - lo == total else torch.cat([local[:hi - lo], local.new_zeros(total - (hi - lo))])
+    if rank == root:
+        out = torch.empty((total,), dtype=local.dtype, device=local.device)
+        out[lo:hi] = local[:hi - lo]
+        ops = [dist.P2POp(dist.irecv, out[a:b], dist.get_global_rank(group, r) if group is not None else r, group)
+               for r, (a, b) in enumerate(ranges) if r != root and b > a]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return out
+    if hi > lo:
+        dst = dist.get_global_rank(group, root) if group is not None else root
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:hi - lo].contiguous(), dst, group)]):
+            w.wait()
+    return None
 
 
+# ---- raw code blocks ---------------------------------------------------------------------------------------------------
 def decode_sharded(BG: int, Z: int, R: int, llr_root, n_blocks: int, numMaxIter: int = 8, root: int = 0, group=None,
                    decode_fn: Optional[Callable] = None, device=None):
-    """Scatter -> local decode -> gather.  `decode_fn(llr_shard) -> (n_iter, out)` defaults to the HIP batch
-    decoder on this rank's GPU (openairinterface5g_amd.ldpc.decode_batch_device); the CPU tests inject their own."""
+    """[n_blocks, ncols*Z] int8 LLRs on `root` -> contiguous block ranges to the ranks -> local decode -> packed bits and
+    pass counts back on `root`.  `decode_fn(llr_shard) -> (n_iter, out)` defaults to the HIP batch decoder on this
+    rank's GPU (the library runs on the GPU that owns the tensors); the CPU tests inject their own."""
     import torch
     from . import ldpc
-    row = ldpc.num_llr(BG, Z, R)
-    shard = scatter_blocks(llr_root, n_blocks, row, root, group, device)
+    rank, world = _rank_world(group)
+    row, ob = ldpc.num_llr(BG, Z, R), ldpc.out_bytes(BG, Z, R)
+    blocks = [shard_range(n_blocks, r, world) for r in range(world)]
+    flat = llr_root.reshape(-1) if llr_root is not None else None
+    shard = scatter_ranges(flat, [(a * row, b * row) for a, b in blocks], torch.int8, root, group, device).reshape(-1, row)
     if decode_fn is None:
-        out = torch.zeros((shard.shape[0], ldpc.out_bytes(BG, Z, R)), dtype=torch.uint8, device=shard.device)
+        out = torch.zeros((shard.shape[0], ob), dtype=torch.uint8, device=shard.device)
         it = torch.zeros((shard.shape[0],), dtype=torch.int32, device=shard.device)
         if shard.shape[0]:
             ldpc.decode_batch_device(BG, Z, R, shard, out, it, numMaxIter=numMaxIter)
     else:
         it, out = decode_fn(shard)
-    return gather_results(out, it, n_blocks, root, group)
+    out_all = gather_ranges(out.reshape(-1), [(a * ob, b * ob) for a, b in blocks], n_blocks * ob, root, group)
+    it_all = gather_ranges(it, blocks, n_blocks, root, group)
+    if rank != root:
+        return None, None
+    return out_all.reshape(n_blocks, ob), it_all
+
+
+# ---- a slot's transport blocks (BASELINE configs[4]) -------------------------------------------------------------------
+class ShardedUlsch:
+    """A slot's PUSCH transport blocks decoded on the GPUs of all ranks: the UL-SCH chain of the library
+    (nrLDPC_hip_ulsch_decode: de-interleave, rate de-match with HARQ combining, LDPC decode with CRC stop, reassembly,
+    TB CRC) runs on every rank for its contiguous range of whole transport blocks; the HARQ soft buffers of a block live
+    on the rank that owns it and stay there from round to round.
+
+    All ranks construct it with the same descriptor list (broadcast it first if only the root has it) and call decode()
+    together; the LLRs -- one flat int16 tensor in the layout of ldpc.tb_layout(tbs) -- are needed on `root` only."""
+
+    def __init__(self, tbs: Sequence[dict], root: int = 0, group=None, device=None, numMaxIter: int = 8,
+                 decode_fn: Optional[Callable] = None):
+        import torch
+        from . import ldpc
+        self.ldpc, self.root, self.group, self.numMaxIter, self.decode_fn = ldpc, root, group, numMaxIter, decode_fn
+        self.rank, self.world = _rank_world(group)
+        self.tbs = [dict(t) for t in tbs]
+        self.po, self.co, self.ho, self.segs = ldpc.tb_layout(self.tbs)
+        self.cut = partition_transport_blocks([tb_cost(t) for t in self.tbs], self.world)
+        t0, t1 = self.cut[self.rank], self.cut[self.rank + 1]
+        self.t0, self.t1 = t0, t1
+        self.local = self.tbs[t0:t1]          # offsets of the local layout = global offsets minus the range start
+        self.device = torch.device("cpu") if device is None else device
+        n_h = int(self.ho[t1] - self.ho[t0])
+        self.harq = torch.zeros((max(n_h, 1),), dtype=torch.int16, device=self.device)
+        self.llr_ranges = [(int(self.co[a]), int(self.co[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
+        self.pay_ranges = [(int(self.po[a]), int(self.po[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
+        self.tb_ranges = list(zip(self.cut[:-1], self.cut[1:]))
+
+    def decode(self, llr_root, rnd: int = 0):
+        """Returns (payload uint8 flat in the tb_layout offsets, ack uint8[n_tb], iter_max int32[n_tb]) on root,
+        (None, None, None) elsewhere."""
+        import torch
+        n_loc = self.t1 - self.t0
+        llr = scatter_ranges(llr_root, self.llr_ranges, torch.int16, self.root, self.group, self.device)
+        pay = torch.zeros((max(int(self.po[self.t1] - self.po[self.t0]), 1),), dtype=torch.uint8, device=self.device)
+        ack = torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=self.device)
+        itm = torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device)
+        for t in self.local:
+            t["round"] = rnd
+        if n_loc:
+            if self.decode_fn is not None:
+                self.decode_fn(self.local, llr, self.harq, pay, ack, itm, self.numMaxIter)
+            else:
+                self.ldpc.ulsch_decode_device(self.local, llr, self.harq, pay, ack, itm, numMaxIter=self.numMaxIter)
+        pay_all = gather_ranges(pay, self.pay_ranges, int(self.po[-1]), self.root, self.group)
+        ack_all = gather_ranges(ack, self.tb_ranges, len(self.tbs), self.root, self.group)
+        itm_all = gather_ranges(itm, self.tb_ranges, len(self.tbs), self.root, self.group)
+        return pay_all, ack_all, itm_all

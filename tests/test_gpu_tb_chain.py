@@ -400,3 +400,30 @@ def test_unfused_tx_path_too():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_tb_chain.py"), "-m", "gpu", "-q", "-x",
                         "-k", "dlsch"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_host_batches_sharded_over_logical_devices(hip, tmp_path):
+    """NRLDPC_HIP_DEVICES=0,0,0: the host-buffer entry points (LDPCdecoder_batch, nrLDPC_hip_dlsch_encode,
+    nrLDPC_hip_ulsch_decode over two HARQ rounds) split their batch over three device contexts -- contiguous block ranges
+    resp. whole transport blocks per device, each with its own streams, staging and plan cache (here all on GPU 0: the
+    box has one) -- and every output byte, pass count, ACK, soft buffer and llrLen equals the single-device run's."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "multidev_script.py"
+    outs = []
+    for devs in (None, "0,0,0"):
+        env = dict(os.environ)
+        env.pop("NRLDPC_HIP_DEVICES", None)
+        if devs:
+            env["NRLDPC_HIP_DEVICES"] = devs
+        f = tmp_path / f"out_{devs or 'single'}.npz"
+        r = subprocess.run([sys.executable, str(script), str(f)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 13
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["rx1_ack"].all() and not a["rx0_ack"].all()          # the first round loses some blocks, combining recovers them
