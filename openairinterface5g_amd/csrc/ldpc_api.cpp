@@ -303,6 +303,20 @@ struct ThreadCtx {
   uint8_t *h_in = nullptr, *h_out = nullptr; /* pinned */
   uint8_t *d_in = nullptr, *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
+  /* chunks of the host-buffer decode in flight: [first block, blocks) and the event behind the chunk's last copy */
+  struct Chunk { uint32_t k0, n; };
+  std::vector<Chunk> chunks;
+  std::vector<hipEvent_t> events;
+  int event(size_t i, hipEvent_t *e)
+  {
+    while (events.size() <= i) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      events.push_back(ev);
+    }
+    *e = events[i];
+    return 0;
+  }
   int ensure(size_t in_bytes, size_t out_bytes) /* on the current device (UseDevice) */
   {
     if (!stream) {
@@ -592,6 +606,7 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
   const size_t chunk_bytes = direct ? ((size_t)8 << 20) : ((size_t)2 << 20);
   const uint32_t chunk = (uint32_t)std::max<size_t>(1, chunk_bytes / in_stride);
   int lane = 0;
+  c.chunks.clear();
   for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {
     const uint32_t n = std::min(chunk, n_part - k0);
     hipStream_t s = lane ? c.stream2 : c.stream;
@@ -616,6 +631,11 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
       HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * k0, c.d_out + iter_off + sizeof(int32_t) * k0,
                              sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     }
+    hipEvent_t ev;
+    if (c.event(c.chunks.size(), &ev) != 0)
+      return -1;
+    HIP_TRY(hipEventRecord(ev, s));
+    c.chunks.push_back(ThreadCtx::Chunk{k0, n});
   }
   return 0;
 }
@@ -629,16 +649,19 @@ int dec_host_finish(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_par
   const int ob = out_bytes_of(ce->host, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
   const size_t out_stride = align_up(ob, 16), iter_off = out_stride * n_part;
   ThreadCtx &c = tls_ctx;
-  HIP_TRY(hipStreamSynchronize(c.stream));
-  HIP_TRY(hipStreamSynchronize(c.stream2));
   const int32_t *h_iter = reinterpret_cast<const int32_t *>(c.h_out + iter_off);
   const bool use_crc = p.check_crc != nullptr;
-  for (uint32_t i = 0; i < n_part; i++) {
-    const int32_t n = h_iter[i];
-    b->n_iter[i0 + i] = n;
-    if (!use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
-      memcpy(b->out + (size_t)(i0 + i) * b->out_stride, c.h_out + i * out_stride, ob);
+  /* chunk by chunk: a chunk's results are handed over while the later chunks are still on the link / in the decoder */
+  for (size_t q = 0; q < c.chunks.size(); q++) {
+    HIP_TRY(hipEventSynchronize(c.events[q]));
+    for (uint32_t i = c.chunks[q].k0; i < c.chunks[q].k0 + c.chunks[q].n; i++) {
+      const int32_t n = h_iter[i];
+      b->n_iter[i0 + i] = n;
+      if (!use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+        memcpy(b->out + (size_t)(i0 + i) * b->out_stride, c.h_out + i * out_stride, ob);
+    }
   }
+  c.chunks.clear();
   return 0;
 }
 

@@ -36,9 +36,12 @@ template <bool JOBS> struct ldpc_batch_io {
 };
 
 /* JOBS = heterogeneous batch (one job record per workgroup, optional transport-block abort flags); the homogeneous
- * variant carries none of that through its loops */
-template <int MAX_THREADS, bool JOBS>
-__global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_dec_args a)
+ * variant carries none of that through its loops.  One register budget for every workgroup size -- 128 VGPRs, i.e. 16
+ * waves per CU: the throughput shapes put k workgroups of w <= 16 / k waves on a CU and count on all 16 wave slots
+ * (a variant compiled for <= 768 threads may take 129+ VGPRs and silently drop the CU to 12 waves: measured 180 -> 262 us
+ * on the 1664-segment slot). */
+template <bool JOBS>
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   /* job records and descriptors are read through the constant address space: uniform address -> scalar loads,
@@ -53,9 +56,8 @@ __global__ void __launch_bounds__(MAX_THREADS) ldpc_dec_fast_kernel(const ldpc_d
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[4] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024, false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768, false>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<1024, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<768, true>)};
-  for (int i = 0; i < 4; i++) {
+  const void *k[2] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>)};
+  for (int i = 0; i < 2; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -69,11 +71,7 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     return hipSuccess;
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
-  /* up to 12 waves: 168 VGPRs per lane available; 13..16 waves: 128 */
-  if (hc.f_n_threads <= 768)
-    hipLaunchKernelGGL((ldpc_dec_fast_kernel<768, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
-  else
-    hipLaunchKernelGGL((ldpc_dec_fast_kernel<1024, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  hipLaunchKernelGGL((ldpc_dec_fast_kernel<false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 
@@ -81,9 +79,6 @@ hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int 
 {
   if (n_blocks == 0)
     return hipSuccess;
-  if (n_threads <= 768)
-    hipLaunchKernelGGL((ldpc_dec_fast_kernel<768, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL((ldpc_dec_fast_kernel<1024, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+  hipLaunchKernelGGL((ldpc_dec_fast_kernel<true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

@@ -49,6 +49,7 @@ struct TbPlan {
   bool valid = false;
   size_t n_seg = 0, n_aux = 0, scratch_top = 0;
   size_t ext[6] = {0, 0, 0, 0, 0, 0}; /* [lo, hi) of the payload, coded and harq ranges the blocks touch */
+  uint32_t rx_lds_elems = 8; /* LDS the de-matching kernel needs per workgroup (int16 slots) */
   bool out_dense = true; /* the blocks' outputs tile their range: one copy back; else one per block (nothing between them is touched) */
   size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int threads[2] = {64, 64}, lds[2] = {0, 0};
@@ -366,6 +367,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     Arena ar;
     int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
     TbExtent ex;
+    uint32_t rx_lds_elems = 8;
     /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
     uint32_t n_seg_total = 0;
     for (uint32_t i = 0; i < ntb; i++) {
@@ -427,6 +429,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
         j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
         j.c_off = tj.c_off0 + (uint64_t)r * cstride;
+        rx_lds_elems = std::max(rx_lds_elems, tb_rx_lds_elems(E, rm.Fin, rm.Ncb));
         j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
         ldpc_dec_job dj;
         const ldpc_code_desc_t &shape = lat_shape ? ce->host_lat : ce->host;
@@ -479,6 +482,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
     pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
     pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
+    pl.rx_lds_elems = rx_lds_elems;
     pl.llr_len.resize(ntb);
     for (uint32_t i = 0; i < ntb; i++)
       pl.llr_len[i] = tbs[i].llrLen;
@@ -511,7 +515,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
     ack = c.io_small.p + (size_t)ntb * 4;
   }
-  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, llr, harq,
+  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, pl.rx_lds_elems, llr, harq,
                                reinterpret_cast<int8_t *>(c.scratch.p), s));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));

@@ -65,8 +65,14 @@ hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const u
 struct ldpc_enc_job;
 hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
                               const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s);
-hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
-                                hipStream_t s);
+/* lds_elems = the largest tb_rx_lds_elems() over the jobs (int16 slots of LDS a workgroup needs) */
+static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t Fin, uint32_t Ncb)
+{
+  const uint32_t span = E + Fin;
+  return ((span < Ncb ? span : Ncb) + 7u) & ~7u;
+}
+hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
+                                int8_t *scratch, hipStream_t s);
 /* reassembly per segment (payload copy + partial TB CRC into acc[tb], zero on entry and on exit), then per-TB verdict */
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,

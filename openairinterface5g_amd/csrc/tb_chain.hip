@@ -244,42 +244,151 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
   }
 }
 
-/* ---- RX 1: de-interleave + rate de-match (HARQ combining) + decoder input pack -------------------------------- */
+/* ---- RX 1: de-interleave + rate de-match (HARQ combining) + decoder input pack --------------------------------
+ * nr_deinterleaving_ldpc (nr_rate_matching.c:310-388): e[i*E/Qm + jj] = f[i + jj*Qm];
+ * nr_rate_matching_ldpc_rx (:507-603): w[pos(k)] += e[k] (int16, wrapping), pos = circular-buffer position of rank
+ * (rank0 + k) mod V among the non-filler positions, after clearing w[0..Ncb) on the first round;
+ * caller's pack (nr_ulsch_decoding.c:195-210): punctured columns 0, fillers +127, saturate to int8.
+ *
+ * One workgroup per code segment, the segment's received contributions transposed through LDS so that both sides move
+ * whole cache lines:
+ *   phase A  a thread per modulation symbol jj reads the symbol's Qm LLRs f[jj*Qm .. +Qm) in ONE load and drops each at
+ *            its soft-buffer position in LDS (e_lds[pos(i*E/Qm + jj)]); one lap of the circular buffer at a time, so that
+ *            every position receives at most one value per lap (plain read-modify-write, no atomics, no division);
+ *   phase B  a thread per 8 consecutive soft-buffer positions: w (16-byte load / store) + the lap sums from LDS, then the
+ *            saturated int8 decoder input (8-byte store) with the punctured zeros and +127 fillers.
+ * HBM traffic = E int16 in, Ncb int16 in (unless first round) and out, num_llr int8 out: the compulsory bytes. */
+typedef uint32_t tb_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tb_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int QM> struct tb_sym; /* the Qm LLRs of one modulation symbol as one load (4-byte aligned source) */
+template <> struct tb_sym<2> { uint32_t w[1]; };
+template <> struct tb_sym<4> { uint32_t w[2]; };
+template <> struct tb_sym<6> { uint32_t w[3]; };
+template <> struct tb_sym<8> { uint32_t w[4]; };
+
+/* LDS slot of soft-buffer position p: positions are visited in circular order starting at p_base = pos(rank0), so the
+ * slot is the circular distance from there; a segment touches min(Ncb, E + Fin) slots at most (tb_rx_lds_elems) */
+__device__ __forceinline__ uint32_t tb_rx_slot(uint32_t p, uint32_t p_base, uint32_t Ncb) { return p >= p_base ? p - p_base : p + Ncb - p_base; }
+
+template <int QM>
+__device__ __forceinline__ void tb_rx_scatter_laps(const int16_t *__restrict__ f, int16_t *e_lds, uint32_t E, uint32_t V, uint32_t rank0,
+                                                    uint32_t Foffset, uint32_t Fin, uint32_t p_base, uint32_t Ncb)
+{
+  const uint32_t EQ = E / QM, nlaps = (E + V - 1) / V;
+  const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
+  for (uint32_t lap = 0; lap < nlaps; lap++) {
+    const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
+    for (uint32_t jj = threadIdx.x; jj < EQ; jj += blockDim.x) {
+      int16_t v[QM];
+      if (vec) {
+        const tb_sym<QM> s = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+#pragma unroll
+        for (int i = 0; i < QM; i++)
+          v[i] = (int16_t)(s.w[i >> 1] >> (16 * (i & 1)));
+      } else {
+#pragma unroll
+        for (int i = 0; i < QM; i++)
+          v[i] = f[(size_t)jj * QM + i];
+      }
+#pragma unroll
+      for (int i = 0; i < QM; i++) {
+        const uint32_t k = (uint32_t)i * EQ + jj;
+        if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
+          uint32_t r = rank0 + (k - k_lo);
+          r = r >= V ? r - V : r;
+          const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_base, Ncb);
+          e_lds[q] = lap == 0 ? v[i] : (int16_t)(e_lds[q] + v[i]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
                                                                    int16_t *harq, int8_t *scratch)
 {
-  const tb_rx_seg_job j = jobs[blockIdx.x];
-  const int16_t *__restrict__ f = llr + j.llr_off;
-  int16_t *__restrict__ w = harq + j.harq_off;
-  int8_t *__restrict__ l = scratch + j.l_off;
-  const uint32_t EQ = j.E / j.Qm, twoZ = 2 * j.Z;
-  const uint32_t np = j.num_llr > twoZ ? j.num_llr - twoZ : 0;     /* soft-buffer positions the decoder reads */
-  const uint32_t n = j.Ncb > np ? j.Ncb : np;
-  for (uint32_t i = threadIdx.x; i < twoZ && i < j.num_llr; i += blockDim.x)
+  extern __shared__ __attribute__((aligned(16))) int16_t e_lds[];
+  typedef const tb_rx_seg_job LDPC_CONST_AS *job_ptr_t;
+  const job_ptr_t j = (job_ptr_t)jobs + blockIdx.x; /* uniform address: the job stays in SGPRs */
+  const int16_t *__restrict__ f = llr + j->llr_off;
+  int16_t *__restrict__ w = harq + j->harq_off;
+  int8_t *__restrict__ l = scratch + j->l_off;
+  const uint32_t E = j->E, Ncb = j->Ncb, Foffset = j->Foffset, Fin = j->Fin, V = j->V, rank0 = j->rank0, clear = j->clear;
+  const uint32_t twoZ = 2 * j->Z, num_llr = j->num_llr, Klo = j->K - j->F, Khi = j->K;
+  const uint32_t np = num_llr > twoZ ? num_llr - twoZ : 0;          /* soft-buffer positions the decoder reads */
+  const uint32_t n = Ncb > np ? Ncb : np;
+  const uint32_t p_base = rank0 < Foffset ? rank0 : rank0 + Fin;
+  switch (j->Qm) {
+    case 2: tb_rx_scatter_laps<2>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
+    case 4: tb_rx_scatter_laps<4>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
+    case 6: tb_rx_scatter_laps<6>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
+    default: tb_rx_scatter_laps<8>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
+  }
+  for (uint32_t i = threadIdx.x; i < twoZ && i < num_llr; i += blockDim.x)
     l[i] = 0;                                                       /* punctured columns (nr_ulsch_decoding.c:198) */
-  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
-    int16_t acc = 0;
-    const bool filler = p >= j.Foffset && p < j.Foffset + j.Fin;
-    if (p < j.Ncb) {
-      acc = j.clear ? (int16_t)0 : w[p];                            /* nr_rate_matching.c:554-555 */
-      if (!filler) {
-        const uint32_t rank = p < j.Foffset ? p : p - j.Fin;
-        uint32_t k = rank >= j.rank0 ? rank - j.rank0 : rank + j.V - j.rank0;
-        for (; k < j.E; k += j.V) {                                 /* every lap that reaches this position */
-          const uint32_t i = k / EQ, jj = k - i * EQ;
-          acc = (int16_t)(acc + f[i + jj * j.Qm]);                  /* nr_rate_matching.c:310-388 + :564 */
-        }
+  /* position p received something iff it is no filler, lies in the circular buffer and its first k is below E */
+  auto value_at = [&](uint32_t p, int16_t old, bool &store) -> int16_t {
+    int16_t acc = clear ? (int16_t)0 : old;                          /* nr_rate_matching.c:554-555; beyond Ncb the reference's
+                                                                       buffer is calloc'ed and never written: 0 on a first round */
+    store = clear != 0;
+    if (p < Ncb && !(p >= Foffset && p < Foffset + Fin)) {
+      const uint32_t rank = p < Foffset ? p : p - Fin;
+      const uint32_t k = rank >= rank0 ? rank - rank0 : rank + V - rank0;
+      if (k < E) {
+        acc = (int16_t)(acc + e_lds[tb_rx_slot(p, p_base, Ncb)]);
+        store = true;
       }
-      if (j.clear || !filler)
-        w[p] = acc;
-    } else {
-      acc = w[p];
     }
+    return acc;
+  };
+  auto pack = [&](uint32_t p, int16_t acc) -> int8_t {             /* nr_ulsch_decoding.c:200-210 */
     const uint32_t i = p + twoZ;
-    if (i < j.num_llr) {                                            /* nr_ulsch_decoding.c:200-210 */
-      const int v = (i >= j.K - j.F && i < j.K) ? 127 : (int)acc;
-      l[i] = (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
+    const int v = (i >= Klo && i < Khi) ? 127 : (int)acc;
+    return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
+  };
+  /* 16 positions per thread and step: two 16-byte loads / stores of w, one 16-byte store of the decoder input; the soft
+   * buffer is not read again by this call: streaming (non-temporal) stores */
+  const bool vec = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((reinterpret_cast<uintptr_t>(l + twoZ) & 15) == 0);
+  const uint32_t n16 = vec ? (n & ~15u) : 0;
+  for (uint32_t p0 = 16 * threadIdx.x; p0 < n16; p0 += 16 * blockDim.x) {
+    union { tb_u32x4 q[2]; int16_t h[16]; } in, out;
+    if (clear) {
+      in.q[0] = in.q[1] = (tb_u32x4){0u, 0u, 0u, 0u};
+    } else {
+      in.q[0] = *reinterpret_cast<const tb_u32x4 *>(w + p0);
+      in.q[1] = *reinterpret_cast<const tb_u32x4 *>(w + p0 + 8);
     }
+    union { tb_u32x4 q; int8_t b[16]; } lo;
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      bool st;
+      out.h[t] = value_at(p0 + t, in.h[t], st);
+      if (!st)
+        out.h[t] = in.h[t];
+      any |= st;
+      lo.b[t] = pack(p0 + t, out.h[t]);
+    }
+    if (any) {                                                       /* (unchanged lanes rewrite what was read) */
+      __builtin_nontemporal_store(out.q[0], reinterpret_cast<tb_u32x4 *>(w + p0));
+      __builtin_nontemporal_store(out.q[1], reinterpret_cast<tb_u32x4 *>(w + p0 + 8));
+    }
+    if (p0 + twoZ + 16 <= num_llr)
+      *reinterpret_cast<tb_u32x4 *>(l + twoZ + p0) = lo.q;
+    else
+      for (int t = 0; t < 16; t++)
+        if (p0 + t + twoZ < num_llr)
+          l[twoZ + p0 + t] = lo.b[t];
+  }
+  for (uint32_t p = n16 + threadIdx.x; p < n; p += blockDim.x) {
+    bool st;
+    const int16_t acc = value_at(p, clear ? (int16_t)0 : w[p], st);
+    if (st)
+      w[p] = acc;
+    if (p + twoZ < num_llr)
+      l[p + twoZ] = pack(p, acc);
   }
 }
 
@@ -376,10 +485,13 @@ hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejo
   hipLaunchKernelGGL(tb_tx_fused_kernel, dim3(n), dim3(n_threads), lds_bytes, s, jobs, ejobs, scratch, coded, pow24b);
   return hipGetLastError();
 }
-hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, const int16_t *llr, int16_t *harq, int8_t *scratch,
-                                hipStream_t s)
+hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
+                                int8_t *scratch, hipStream_t s)
 {
-  TB_LAUNCH(tb_rx_dematch_kernel, n, s, jobs, llr, harq, scratch);
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(tb_rx_dematch_kernel, dim3(n), dim3(TB_THREADS), (size_t)lds_elems * sizeof(int16_t), s, jobs, llr, harq, scratch);
+  return hipGetLastError();
 }
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,

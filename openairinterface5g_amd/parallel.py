@@ -68,9 +68,9 @@ def _rank_world(group=None):
 
 
 # ---- edges: exact-size point-to-point -------------------------------------------------------------------------------
-def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: int = 0, group=None, device=None):
+def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: int = 0, group=None, device=None, out=None):
     """`flat_root`: 1-D tensor on `root` (None elsewhere); rank r receives elements [ranges[r][0], ranges[r][1]).
-    Slices of the root tensor are sent as they are (views), every receiver allocates exactly its share."""
+    Slices of the root tensor are sent as they are (views); a receiver gets exactly its share, into `out` if given."""
     import torch
     import torch.distributed as dist
     rank, world = _rank_world(group)
@@ -85,7 +85,7 @@ def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: in
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return mine
-    shard = torch.empty((hi - lo,), dtype=dtype, device=device if device is not None else "cpu")
+    shard = out[:hi - lo] if out is not None else torch.empty((hi - lo,), dtype=dtype, device=device if device is not None else "cpu")
     if hi > lo:
         src = dist.get_global_rank(group, root) if group is not None else root
         for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, shard, src, group)]):
@@ -171,23 +171,34 @@ class ShardedUlsch:
         self.llr_ranges = [(int(self.co[a]), int(self.co[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.pay_ranges = [(int(self.po[a]), int(self.po[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.tb_ranges = list(zip(self.cut[:-1], self.cut[1:]))
+        self._buf, self._prepared = None, {}
 
     def decode(self, llr_root, rnd: int = 0):
         """Returns (payload uint8 flat in the tb_layout offsets, ack uint8[n_tb], iter_max int32[n_tb]) on root,
         (None, None, None) elsewhere."""
         import torch
         n_loc = self.t1 - self.t0
-        llr = scatter_ranges(llr_root, self.llr_ranges, torch.int16, self.root, self.group, self.device)
-        pay = torch.zeros((max(int(self.po[self.t1] - self.po[self.t0]), 1),), dtype=torch.uint8, device=self.device)
-        ack = torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=self.device)
-        itm = torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device)
-        for t in self.local:
-            t["round"] = rnd
+        if self._buf is None:     # persistent local buffers: the per-slot path allocates nothing
+            n_llr = max(int(self.co[self.t1] - self.co[self.t0]), 1)
+            self._buf = dict(llr=None if self.rank == self.root else torch.empty((n_llr,), dtype=torch.int16, device=self.device),
+                             pay=torch.zeros((max(int(self.po[self.t1] - self.po[self.t0]), 1),), dtype=torch.uint8, device=self.device),
+                             ack=torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=self.device),
+                             itm=torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device))
+        pay, ack, itm = self._buf["pay"], self._buf["ack"], self._buf["itm"]
+        llr = scatter_ranges(llr_root, self.llr_ranges, torch.int16, self.root, self.group, self.device, out=self._buf["llr"])
         if n_loc:
             if self.decode_fn is not None:
+                for t in self.local:
+                    t["round"] = rnd
                 self.decode_fn(self.local, llr, self.harq, pay, ack, itm, self.numMaxIter)
             else:
-                self.ldpc.ulsch_decode_device(self.local, llr, self.harq, pay, ack, itm, numMaxIter=self.numMaxIter)
+                # the descriptor array is marshalled once per (LLR buffer, round) and resubmitted slot after slot
+                key = (llr.data_ptr(), rnd)
+                if key not in self._prepared:
+                    for t in self.local:
+                        t["round"] = rnd
+                    self._prepared[key] = self.ldpc.PreparedTbBatch(self.local, pay, llr, self.harq, ack, itm, self.numMaxIter)
+                self._prepared[key].decode()
         pay_all = gather_ranges(pay, self.pay_ranges, int(self.po[-1]), self.root, self.group)
         ack_all = gather_ranges(ack, self.tb_ranges, len(self.tbs), self.root, self.group)
         itm_all = gather_ranges(itm, self.tb_ranges, len(self.tbs), self.root, self.group)
