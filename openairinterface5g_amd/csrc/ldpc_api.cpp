@@ -603,8 +603,17 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
   if (c.ensure(in_stride * n_part, iter_off + sizeof(int32_t) * n_part) != 0)
     return -1;
   int32_t *d_iter = reinterpret_cast<int32_t *>(c.d_out + iter_off);
-  const size_t chunk_bytes = direct ? ((size_t)8 << 20) : ((size_t)2 << 20);
-  const uint32_t chunk = (uint32_t)std::max<size_t>(1, chunk_bytes / in_stride);
+  /* page-locked source: a chunk = one full round of decoder workgroups on this GPU (a chunk that leaves a quarter round
+   * over pays a whole round for it), at least ~4 MiB so that the link runs near its streaming rate */
+  const size_t chunk_bytes = direct ? ((size_t)4 << 20) : ((size_t)3 << 20);
+  uint32_t chunk = (uint32_t)std::max<size_t>(1, chunk_bytes / in_stride);
+  if (hc.f_ok) { /* pageable source: half rounds (the CPU staging copy is the slower stage; measured in profiles/r02/host_path_sweep.txt) */
+    const uint32_t round = (uint32_t)(G().n_cus * std::max(1, hc.f_wg_per_cu)) / (direct ? 1u : 2u);
+    chunk = (chunk + round - 1) / round * round;
+  }
+  static const int chunk_env = [] { const char *e = getenv("NRLDPC_HIP_HOST_CHUNK"); return e ? atoi(e) : 0; }(); /* tuning knob: blocks per chunk */
+  if (chunk_env > 0)
+    chunk = (uint32_t)chunk_env;
   int lane = 0;
   c.chunks.clear();
   for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {

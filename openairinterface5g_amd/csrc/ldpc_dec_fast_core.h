@@ -189,6 +189,12 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
     sxl ^= 0x80008000u;
     sxh ^= 0x80008000u;
   }
+  /* Signs are applied to the four output bytes at once.  Bit 15 of a half of (sx ^ D1_k) says "negative"; the bytes
+   * that hold those bits (1 and 3 of each register) are gathered with one v_perm, for the row's xor once and per edge
+   * once.  With n = 0 / 1 per byte and a magnitude o <= 127, the biased byte is 128 + o = o ^ 0x80 for n = 0 and
+   * 128 - o = (o ^ 0x7f) + 1 for n = 1, i.e. (o ^ (0x80 - n)) + n: three plain 32-bit ops for four lanes, no carry
+   * between the bytes (the largest value is 0x80). */
+  const uint32_t sx4 = ldpc_perm(sxh, sxl, 0x07050301u);
 #pragma unroll
   for (int k = 0; k < D; k++) {
     uint32_t dl, dh;
@@ -205,10 +211,10 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
     }
     const ldpc_v2u ml = KEEP ? ldpc_as_v2u(g_lo[k]) : ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     const ldpc_v2u mh = KEEP ? ldpc_as_v2u(g_hi[k]) : ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
-    const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h));
-    const ldpc_v2i gl = ldpc_as_v2i(sxl ^ dl) >> 15, gh = ldpc_as_v2i(sxh ^ dh) >> 15;
-    const ldpc_v2i nl = ldpc_as_v2i(ol ^ ldpc_as_u32(gl)) - gl, nh = ldpc_as_v2i(oh ^ ldpc_as_u32(gh)) - gh;
-    const uint32_t w = ldpc_pack4(nl, nh) ^ 0x80808080u;
+    const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h)); /* magnitudes, 0..127 per half */
+    const uint32_t o4 = ldpc_perm(oh, ol, 0x06040200u);
+    const uint32_t n4 = ((sx4 ^ ldpc_perm(dh, dl, 0x07050301u)) >> 7) & 0x01010101u;
+    const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
     *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
     *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
   }

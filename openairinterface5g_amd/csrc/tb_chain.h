@@ -66,10 +66,10 @@ struct ldpc_enc_job;
 hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
                               const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s);
 /* lds_elems = the largest tb_rx_lds_elems() over the jobs (int16 slots of LDS a workgroup needs) */
-static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t Fin, uint32_t Ncb)
+__host__ __device__ static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t Fin, uint32_t Ncb)
 {
   const uint32_t span = E + Fin;
-  return ((span < Ncb ? span : Ncb) + 7u) & ~7u;
+  return ((span < Ncb ? span : Ncb) + 8u + 7u) & ~7u; /* + 8: the span starts up to 7 slots into its first aligned word */
 }
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
                                 int8_t *scratch, hipStream_t s);

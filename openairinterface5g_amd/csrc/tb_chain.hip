@@ -267,38 +267,54 @@ template <> struct tb_sym<4> { uint32_t w[2]; };
 template <> struct tb_sym<6> { uint32_t w[3]; };
 template <> struct tb_sym<8> { uint32_t w[4]; };
 
-/* LDS slot of soft-buffer position p: positions are visited in circular order starting at p_base = pos(rank0), so the
- * slot is the circular distance from there; a segment touches min(Ncb, E + Fin) slots at most (tb_rx_lds_elems) */
-__device__ __forceinline__ uint32_t tb_rx_slot(uint32_t p, uint32_t p_base, uint32_t Ncb) { return p >= p_base ? p - p_base : p + Ncb - p_base; }
+/* LDS slot of soft-buffer position p.  Positions are visited in circular order starting at p_base = pos(rank0); the slot
+ * is the circular distance from p_align = p_base rounded down to a multiple of 8, so that 8 consecutive positions that
+ * start at a multiple of 8 sit in one aligned 16-byte LDS word (as long as Ncb % 8 == 0 across the wrap).  A segment
+ * touches min(Ncb, E + Fin) + 8 slots at most (tb_rx_lds_elems); the slots are zeroed first, so a slot that receives
+ * nothing (filler positions, the tail of the last lap) simply contributes 0 -- no coverage logic on the way out. */
+__device__ __forceinline__ uint32_t tb_rx_slot(uint32_t p, uint32_t p_align, uint32_t Ncb) { return p >= p_align ? p - p_align : p + Ncb - p_align; }
 
 template <int QM>
 __device__ __forceinline__ void tb_rx_scatter_laps(const int16_t *__restrict__ f, int16_t *e_lds, uint32_t E, uint32_t V, uint32_t rank0,
-                                                    uint32_t Foffset, uint32_t Fin, uint32_t p_base, uint32_t Ncb)
+                                                    uint32_t Foffset, uint32_t Fin, uint32_t p_align, uint32_t Ncb)
 {
   const uint32_t EQ = E / QM, nlaps = (E + V - 1) / V;
   const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
   for (uint32_t lap = 0; lap < nlaps; lap++) {
     const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
-    for (uint32_t jj = threadIdx.x; jj < EQ; jj += blockDim.x) {
-      int16_t v[QM];
-      if (vec) {
-        const tb_sym<QM> s = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+    for (uint32_t jj0 = threadIdx.x; jj0 < EQ; jj0 += 2 * blockDim.x) {
+      /* two symbols per step: both loads are in flight before either is consumed */
+      int16_t v[2][QM];
 #pragma unroll
-        for (int i = 0; i < QM; i++)
-          v[i] = (int16_t)(s.w[i >> 1] >> (16 * (i & 1)));
-      } else {
+      for (int u = 0; u < 2; u++) {
+        const uint32_t jj = jj0 + (uint32_t)u * blockDim.x;
+        if (jj < EQ) {
+          if (vec) {
+            const tb_sym<QM> sy = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
 #pragma unroll
-        for (int i = 0; i < QM; i++)
-          v[i] = f[(size_t)jj * QM + i];
+            for (int i = 0; i < QM; i++)
+              v[u][i] = (int16_t)(sy.w[i >> 1] >> (16 * (i & 1)));
+          } else {
+#pragma unroll
+            for (int i = 0; i < QM; i++)
+              v[u][i] = f[(size_t)jj * QM + i];
+          }
+        }
       }
 #pragma unroll
-      for (int i = 0; i < QM; i++) {
-        const uint32_t k = (uint32_t)i * EQ + jj;
-        if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
-          uint32_t r = rank0 + (k - k_lo);
-          r = r >= V ? r - V : r;
-          const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_base, Ncb);
-          e_lds[q] = lap == 0 ? v[i] : (int16_t)(e_lds[q] + v[i]);
+      for (int u = 0; u < 2; u++) {
+        const uint32_t jj = jj0 + (uint32_t)u * blockDim.x;
+        if (jj < EQ) {
+#pragma unroll
+          for (int i = 0; i < QM; i++) {
+            const uint32_t k = (uint32_t)i * EQ + jj;
+            if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
+              uint32_t r = rank0 + (k - k_lo);
+              r = r >= V ? r - V : r;
+              const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_align, Ncb);
+              e_lds[q] = lap == 0 ? v[u][i] : (int16_t)(e_lds[q] + v[u][i]);
+            }
+          }
         }
       }
     }
@@ -319,75 +335,82 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_s
   const uint32_t twoZ = 2 * j->Z, num_llr = j->num_llr, Klo = j->K - j->F, Khi = j->K;
   const uint32_t np = num_llr > twoZ ? num_llr - twoZ : 0;          /* soft-buffer positions the decoder reads */
   const uint32_t n = Ncb > np ? Ncb : np;
-  const uint32_t p_base = rank0 < Foffset ? rank0 : rank0 + Fin;
-  switch (j->Qm) {
-    case 2: tb_rx_scatter_laps<2>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
-    case 4: tb_rx_scatter_laps<4>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
-    case 6: tb_rx_scatter_laps<6>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
-    default: tb_rx_scatter_laps<8>(f, e_lds, E, V, rank0, Foffset, Fin, p_base, Ncb); break;
-  }
+  const uint32_t p_base = rank0 < Foffset ? rank0 : rank0 + Fin, p_align = p_base & ~7u;
+  const uint32_t span = tb_rx_lds_elems(E, Fin, Ncb);               /* slots in use, a multiple of 8 */
+  for (uint32_t i = threadIdx.x; i < span / 8; i += blockDim.x)
+    reinterpret_cast<tb_u32x4 *>(e_lds)[i] = (tb_u32x4){0u, 0u, 0u, 0u};
   for (uint32_t i = threadIdx.x; i < twoZ && i < num_llr; i += blockDim.x)
     l[i] = 0;                                                       /* punctured columns (nr_ulsch_decoding.c:198) */
-  /* position p received something iff it is no filler, lies in the circular buffer and its first k is below E */
-  auto value_at = [&](uint32_t p, int16_t old, bool &store) -> int16_t {
-    int16_t acc = clear ? (int16_t)0 : old;                          /* nr_rate_matching.c:554-555; beyond Ncb the reference's
-                                                                       buffer is calloc'ed and never written: 0 on a first round */
-    store = clear != 0;
-    if (p < Ncb && !(p >= Foffset && p < Foffset + Fin)) {
-      const uint32_t rank = p < Foffset ? p : p - Fin;
-      const uint32_t k = rank >= rank0 ? rank - rank0 : rank + V - rank0;
-      if (k < E) {
-        acc = (int16_t)(acc + e_lds[tb_rx_slot(p, p_base, Ncb)]);
-        store = true;
-      }
-    }
-    return acc;
+  __syncthreads();
+  switch (j->Qm) {
+    case 2: tb_rx_scatter_laps<2>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
+    case 4: tb_rx_scatter_laps<4>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
+    case 6: tb_rx_scatter_laps<6>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
+    default: tb_rx_scatter_laps<8>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
+  }
+  /* what position p received in this call (all laps), 0 if nothing */
+  auto received = [&](uint32_t p) -> int16_t {
+    const uint32_t q = tb_rx_slot(p, p_align, Ncb);
+    return (p < Ncb && q < span) ? e_lds[q] : (int16_t)0;
   };
   auto pack = [&](uint32_t p, int16_t acc) -> int8_t {             /* nr_ulsch_decoding.c:200-210 */
     const uint32_t i = p + twoZ;
     const int v = (i >= Klo && i < Khi) ? 127 : (int)acc;
     return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
   };
-  /* 16 positions per thread and step: two 16-byte loads / stores of w, one 16-byte store of the decoder input; the soft
-   * buffer is not read again by this call: streaming (non-temporal) stores */
-  const bool vec = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((reinterpret_cast<uintptr_t>(l + twoZ) & 15) == 0);
-  const uint32_t n16 = vec ? (n & ~15u) : 0;
-  for (uint32_t p0 = 16 * threadIdx.x; p0 < n16; p0 += 16 * blockDim.x) {
-    union { tb_u32x4 q[2]; int16_t h[16]; } in, out;
-    if (clear) {
-      in.q[0] = in.q[1] = (tb_u32x4){0u, 0u, 0u, 0u};
+  /* 8 positions per thread and step, lanes side by side: one 16-byte load / store of w, one aligned 16-byte LDS read, one
+   * 8-byte store of the decoder input.  w[p] = (first round ? 0 : w[p]) + received (nr_rate_matching.c:554-603; beyond
+   * Ncb the reference's buffer is calloc'ed and never written: 0 on a first round); a position that received nothing
+   * keeps its value, so the store is skipped unless something changes. */
+  const bool vec = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((reinterpret_cast<uintptr_t>(l + twoZ) & 7) == 0);
+  const uint32_t n8 = vec ? (n & ~7u) : 0;
+  const uint32_t fill_lo = Klo > twoZ ? Klo - twoZ : 0, fill_hi = Khi > twoZ ? Khi - twoZ : 0; /* decoder-input fillers in p */
+  for (uint32_t p0 = 8 * threadIdx.x; p0 < n8; p0 += 8 * blockDim.x) {
+    union { tb_u32x4 q; int16_t h[8]; uint32_t u[4]; } old, e, acc;
+    old.q = clear ? (tb_u32x4){0u, 0u, 0u, 0u} : *reinterpret_cast<const tb_u32x4 *>(w + p0);
+    const uint32_t q0 = tb_rx_slot(p0, p_align, Ncb);
+    if (p0 + 8 <= Ncb && (p0 >= p_align || (Ncb & 7u) == 0)) {       /* the chunk is one aligned LDS word (or outside the span) */
+      e.q = q0 < span ? *reinterpret_cast<const tb_u32x4 *>(e_lds + q0) : (tb_u32x4){0u, 0u, 0u, 0u};
     } else {
-      in.q[0] = *reinterpret_cast<const tb_u32x4 *>(w + p0);
-      in.q[1] = *reinterpret_cast<const tb_u32x4 *>(w + p0 + 8);
-    }
-    union { tb_u32x4 q; int8_t b[16]; } lo;
-    bool any = false;
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      bool st;
-      out.h[t] = value_at(p0 + t, in.h[t], st);
-      if (!st)
-        out.h[t] = in.h[t];
-      any |= st;
-      lo.b[t] = pack(p0 + t, out.h[t]);
+      for (int t = 0; t < 8; t++)
+        e.h[t] = received(p0 + t);
     }
-    if (any) {                                                       /* (unchanged lanes rewrite what was read) */
-      __builtin_nontemporal_store(out.q[0], reinterpret_cast<tb_u32x4 *>(w + p0));
-      __builtin_nontemporal_store(out.q[1], reinterpret_cast<tb_u32x4 *>(w + p0 + 8));
+    bool any = clear != 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {                                    /* int16 wrapping add, two lanes per op */
+      acc.u[t] = ((old.u[t] & 0x7fff7fffu) + (e.u[t] & 0x7fff7fffu)) ^ ((old.u[t] ^ e.u[t]) & 0x80008000u);
+      any |= e.u[t] != 0;
     }
-    if (p0 + twoZ + 16 <= num_llr)
-      *reinterpret_cast<tb_u32x4 *>(l + twoZ + p0) = lo.q;
-    else
-      for (int t = 0; t < 16; t++)
-        if (p0 + t + twoZ < num_llr)
-          l[twoZ + p0 + t] = lo.b[t];
+    if (any)
+      *reinterpret_cast<tb_u32x4 *>(w + p0) = acc.q;
+    if (p0 < np) {
+      union { tb_u32x2 q; int8_t b[8]; } lo;
+      if (p0 + 8 <= fill_lo || p0 >= fill_hi) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          const int v = acc.h[t];
+          lo.b[t] = (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+          lo.b[t] = pack(p0 + t, acc.h[t]);
+      }
+      if (p0 + 8 <= np)
+        *reinterpret_cast<tb_u32x2 *>(l + twoZ + p0) = lo.q;
+      else
+        for (int t = 0; t < 8; t++)
+          if (p0 + t < np)
+            l[twoZ + p0 + t] = lo.b[t];
+    }
   }
-  for (uint32_t p = n16 + threadIdx.x; p < n; p += blockDim.x) {
-    bool st;
-    const int16_t acc = value_at(p, clear ? (int16_t)0 : w[p], st);
-    if (st)
+  for (uint32_t p = n8 + threadIdx.x; p < n; p += blockDim.x) {
+    const int16_t ev = received(p);
+    const int16_t acc = (int16_t)((clear ? 0 : w[p]) + ev);
+    if (clear || ev != 0)
       w[p] = acc;
-    if (p + twoZ < num_llr)
+    if (p < np)
       l[p + twoZ] = pack(p, acc);
   }
 }

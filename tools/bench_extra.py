@@ -191,36 +191,18 @@ res["config5_ulsch_decode_64tb_273prb_64qam"] = {
     "coded_gbps": n_tb * G / dt_dec / 1e9, "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
 
 progress('config5 done')
-# ---- per-segment reference ABI (LDPCdecoder, host buffers): latency and multi-thread throughput ------------------------
-BG, Z, R = 1, 384, 13
-_, llr_d = noisy_llr(BG, Z, R, 64, 1.0, 99)
-llr_h = llr_d.cpu().numpy()
-p = pkg.make_dec_params(BG, Z, R, 8)
-
-
-def one(i):
-    return pkg.LDPCdecoder(p, llr_h[i % 64])[0]
-
-
-one(0)
-t0 = time.perf_counter()
-for i in range(200):
-    one(i)
-lat = (time.perf_counter() - t0) / 200
-res["abi_LDPCdecoder_single_thread"] = {"us_per_call": lat * 1e6, "coded_gbps": 66 * Z / lat / 1e9}
-for T in (4, 16, 64):
-    per = 100
-
-    def worker(k):
-        pp = pkg.make_dec_params(BG, Z, R, 8)
-        for i in range(per):
-            pkg.LDPCdecoder(pp, llr_h[(k + i) % 64])
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    res[f"abi_LDPCdecoder_{T}_threads"] = {"blocks_per_s": T * per / dt, "coded_gbps": T * per * 66 * Z / dt / 1e9}
+# ---- per-segment reference ABI (LDPCdecoder, host buffers) from C threads: tests/abi_threads.c ------------------------
+import subprocess  # noqa: E402
+exe = ROOT / "tests" / "abi_threads.bin"
+if not exe.exists():
+    subprocess.run(["gcc", "-O2", "-I", str(ROOT / "include"), str(ROOT / "tests" / "abi_threads.c"), "-o", str(exe), "-ldl", "-lpthread"], check=True)
+for name, T, n, case in (("latency_bg1_z384_2iter", 1, 3000, "1"), ("latency_bg1_z384_9pass", 1, 2000, "0"), ("mixed_1_thread", 1, 1200, None),
+                         ("mixed_16_threads", 16, 600, None), ("mixed_32_threads", 32, 600, None), ("mixed_64_threads", 64, 300, None)):
+    cmd = [str(exe), str(m.LIB_PATH), str(T), str(n)] + ([case] if case else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    try:
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        res[f"abi_LDPCdecoder_{name}"] = {k: d[k] for k in ("threads", "calls", "calls_per_s", "failures", "us_per_call_per_thread", "srv_us", "served")}
+    except Exception:
+        res[f"abi_LDPCdecoder_{name}"] = {"error": (r.stdout + r.stderr)[-300:]}
 print(json.dumps(res, indent=1))
