@@ -870,14 +870,21 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
     return -1;
   const ldpc_code_desc_t &hc = ce->host;
   const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
-  if ((uint32_t)K != impp->K)
-    return set_error("K must be 22*Zc (BG1) or 10*Zc (BG2)");
+  /* impp->K = bits the caller supplies per segment.  Every caller in the stack passes the full K = 22*Zc / 10*Zc
+   * (nr_dlsch_coding.c:366); ldpctest passes its -l block length, which may be shorter: the missing bits are zeros and
+   * the code word is cut to the mother rate, out = c[2Zc..K') || d[0 .. rate*K' - K' + 2Zc)  (ldpc_encoder.c:82-92,
+   * 248-251; ldpc_encoder_optim8segmulti.c:112-118,175-208). */
+  const int Kp = (int)impp->K, rate = impp->BG == 1 ? 3 : 5;
+  if (Kp > K || Kp <= 2 * hc.Z)
+    return set_error("K must be in (2*Zc, 22*Zc] (BG1) or (2*Zc, 10*Zc] (BG2)");
+  const bool shortened = Kp != K;
+  const int n_info = Kp - 2 * hc.Z, n_par = rate * Kp - n_info; /* bytes of the two output parts */
   if ((int)impp->Kb < 1 || (int)impp->Kb > hc.kb_full)
     return set_error("bad Kb");
   const unsigned n = last - first;
   /* the reference's four meters (ldpc_encoder_optim8segmulti.c:120-210), with this library's phases: tinput = staging
    * the segments, tprep = nothing, tparity = the encode on the GPU, toutput = handing the code words back */
-  if (srv_ready() == 0) {
+  if (!shortened && srv_ready() == 0) {
     meter_start(impp->tinput);
     const int rc = srv_encode(ce, (int)impp->Kb, input, output, first, n, impp->tinput, impp->tprep, impp->tparity, impp->toutput);
     if (rc <= 0)
@@ -889,8 +896,16 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
   if (c.ensure(in_stride * n, out_stride * n) != 0)
     return -1;
   meter_start(impp->tinput);
-  for (unsigned j = 0; j < n; j++)
-    memcpy(c.h_in + j * in_stride, input[first + j], in_bytes);
+  for (unsigned j = 0; j < n; j++) {
+    uint8_t *dst = c.h_in + j * in_stride;
+    const int nb = (Kp + 7) / 8;
+    memcpy(dst, input[first + j], nb);
+    if (shortened) {
+      if (Kp & 7)
+        dst[nb - 1] &= (uint8_t)(0xff << (8 - (Kp & 7)));
+      memset(dst + nb, 0, in_bytes - nb);
+    }
+  }
   meter_stop(impp->tinput);
   meter_start(impp->tprep);
   meter_stop(impp->tprep);
@@ -911,8 +926,15 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
   if (e != hipSuccess || e2 != hipSuccess)
     return set_error("LDPCencoder", e != hipSuccess ? e : e2);
   meter_start(impp->toutput);
-  for (unsigned j = 0; j < n; j++)
-    memcpy(output[first + j], c.h_out + j * out_stride, N);
+  for (unsigned j = 0; j < n; j++) {
+    const uint8_t *src = c.h_out + j * out_stride;
+    if (!shortened) {
+      memcpy(output[first + j], src, N);
+    } else {
+      memcpy(output[first + j], src, n_info);
+      memcpy(output[first + j] + n_info, src + (K - 2 * hc.Z), n_par);
+    }
+  }
   meter_stop(impp->toutput);
   return 0;
 }

@@ -190,13 +190,14 @@ def LDPCdecoder(p_decParams, p_llr, p_out=None, ab=None, harq_pid=0, ulsch_id=0,
     return n, p_out
 
 
-def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=None):
+def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=None, block_length=None):
     """Up to 8 segments through the reference entry point (ldpc_encoder_optim8segmulti.c:46).
     inputs: list of uint8[K/8]; returns list of uint8[(66|50)*Zc] (one bit per byte) for ALL n_segments
-    (entries outside this macro group are left zero)."""
+    (entries outside this macro group are left zero).  block_length: ldpctest's -l when it is shorter than K = 22|10 * Zc
+    (impp->K; the code word is then cut to 3|5 * block_length bytes, ldpc_encoder.c:82-92,248-251)."""
     L = load_library()
     kbf = 22 if BG == 1 else 10
-    K = kbf * Zc
+    K = kbf * Zc if block_length is None else block_length
     n_segments = len(inputs) if n_segments is None else n_segments
     ins = [np.ascontiguousarray(np.concatenate([np.asarray(i, dtype=np.uint8), np.zeros(8, np.uint8)])) for i in inputs]
     outs = [np.zeros(68 * 384, dtype=np.uint8) for _ in range(n_segments)]
@@ -208,7 +209,7 @@ def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=No
         impp.tinput, impp.tprep, impp.tparity, impp.toutput = (C.addressof(m) for m in meters)
     rc = L.LDPCencoder(ip, op, C.byref(impp))
     _check(rc, "LDPCencoder")
-    N = (66 if BG == 1 else 50) * Zc
+    N = (66 if BG == 1 else 50) * Zc if block_length is None else (3 if BG == 1 else 5) * block_length
     return [o[:N] for o in outs]
 
 

@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle_nr_coding.h"
-#include "../openairinterface5g_amd/csrc/nr_ldpc_bg_tables.h" /* 38.212 tables (data only) */
+#include "oracle_bg_tables.h" /* the oracle's own copy of the 38.212 tables (tools/gen_oracle_tables.py) */
 
 int oracle_ldpc_ils(int Z)
 {
@@ -46,11 +46,11 @@ int oracle_ldpc_graph(int BG, int Z, int R, oracle_graph_t *g)
   const uint16_t *sh;
   int nrows_all;
   if (BG == 1) {
-    deg = nr_ldpc_bg1_row_deg; col = nr_ldpc_bg1_col; sh = nr_ldpc_bg1_shift[ils];
+    deg = oracle_bg1_row_deg; col = oracle_bg1_col; sh = oracle_bg1_shift[ils];
     nrows_all = 46; g->ncore = 26;
     if (R == 13) g->ncols = 68; else if (R == 23) g->ncols = 35; else if (R == 89) g->ncols = 27; else return -1;
   } else if (BG == 2) {
-    deg = nr_ldpc_bg2_row_deg; col = nr_ldpc_bg2_col; sh = nr_ldpc_bg2_shift[ils];
+    deg = oracle_bg2_row_deg; col = oracle_bg2_col; sh = oracle_bg2_shift[ils];
     nrows_all = 42; g->ncore = 14;
     if (R == 15) g->ncols = 52; else if (R == 13) g->ncols = 32; else if (R == 23) g->ncols = 17; else return -1;
   } else

@@ -13,7 +13,7 @@
  */
 #include <string.h>
 #include "oracle_nr_coding.h"
-#include "../openairinterface5g_amd/csrc/nr_ldpc_bg_tables.h"
+#include "oracle_bg_tables.h"
 
 /* y[t] ^= x[(t + s) mod Z] */
 static void xor_rot(uint8_t *y, const uint8_t *x, int s, int Z)

@@ -53,11 +53,21 @@ def run(args, out=sys.stdout):
     n_coded = (Kb + nrows - no_punctured_columns) * Zc - removed_bit - 2 * Zc   # transmitted positions 2Zc .. To
     print(f"ldpc_test: codeword_length {args.S * block_length}, n_segments {args.S}, block_length {block_length}, "
           f"BG {BG}, Zc {Zc}, Kb {Kb}", file=out)
-    if block_length != K:
-        raise SystemExit("this harness handles the CI lengths (block_length == Kb*Zc), like the reference's test list")
+    rate = 3 if BG == 1 else 5
+
+    def oracle_encode(x):
+        """ldpc_encoder.c with K = block_length: missing bits are zeros, the code word is cut to rate * block_length bytes
+        (:82-92, :248-251): c[2Zc..block_length) || d[0 .. rate*block_length - block_length + 2Zc)"""
+        if block_length == K:
+            return O.encode(BG, Zc, x, Kb)
+        bits = np.concatenate([np.unpackbits(np.asarray(x, np.uint8))[:block_length], np.zeros(K - block_length, np.uint8)])
+        full = O.encode(BG, Zc, np.packbits(bits), Kb)
+        n_info = block_length - 2 * Zc
+        return np.concatenate([full[:n_info], full[K - 2 * Zc:K - 2 * Zc + rate * block_length - n_info]])
+
     if args.oracle:
         decode_one = lambda llr: O.decode(BG, Zc, R, llr, args.i)
-        encode_many = lambda infos: [O.encode(BG, Zc, x, Kb) for x in infos]
+        encode_many = lambda infos: [oracle_encode(x) for x in infos]
     else:
         import openairinterface5g_amd as pkg
         pkg.LDPCinit()
@@ -66,7 +76,8 @@ def run(args, out=sys.stdout):
         def encode_many(infos):
             outs = [None] * len(infos)
             for macro in range((len(infos) + 7) // 8):
-                part = pkg.LDPCencoder(infos, BG, Zc, Kb, n_segments=len(infos), macro_num=macro)
+                part = pkg.LDPCencoder(infos, BG, Zc, Kb, n_segments=len(infos), macro_num=macro,
+                                       block_length=None if block_length == K else block_length)
                 for j in range(8 * macro, min(len(infos), 8 * macro + 8)):
                     outs[j] = part[j]
             return outs
@@ -83,18 +94,27 @@ def run(args, out=sys.stdout):
         iters = []
         t_dec = 0.0
         for _ in range(args.n):
-            infos = [data_rng.integers(0, 256, block_length // 8, dtype=np.uint8) for _ in range(args.S)]
+            infos = [data_rng.integers(0, 256, (block_length + 7) // 8, dtype=np.uint8) for _ in range(args.S)]
             coded = encode_many(infos)
+            if args.n == 1 and not args.oracle:             # ldpctest.c:286-292: one trial = encoder cross-check (orig vs optim)
+                for j, x in enumerate(infos):
+                    ref = oracle_encode(x)
+                    if not np.array_equal(ref, coded[j][:ref.size]):
+                        pos = int(np.flatnonzero(ref != coded[j][:ref.size])[0])
+                        print(f"differ in seg {j} pos {pos} ({ref[pos]},{coded[j][pos]})", file=out)
+                        return results
             for j in range(args.S):
+                # ldpctest.c:295-305: decoder position i (2Zc <= i < To) takes code-word byte i - 2Zc -- also when
+                # block_length < Kb*Zc, where the reference does NOT re-insert the shortened columns
                 llr = rng.ldpctest_channel(coded[j][:n_coded], Zc, sigma, args.q)
-                llr = np.concatenate([llr, np.zeros(ncols * Zc - llr.size, np.int8)])[:ncols * Zc]
+                llr = np.concatenate([llr, np.zeros(max(0, ncols * Zc - llr.size), np.int8)])[:ncols * Zc]
                 t0 = time.perf_counter()
                 n_iter, est = decode_one(llr)
                 t_dec += time.perf_counter() - t0
                 iters.append(n_iter)
-                if not np.array_equal(est[:block_length // 8], infos[j]):
+                if not np.array_equal(est[:block_length // 8], infos[j][:block_length // 8]):
                     errors += 1
-                bit_errors += int(np.unpackbits(est[:block_length // 8] ^ infos[j]).sum())
+                bit_errors += int(np.unpackbits(est[:block_length // 8] ^ infos[j][:block_length // 8]).sum())
         it = np.array(iters, dtype=np.float64)
         bler = errors / args.n
         print(f"SNR {snr:f}, BLER {bler:f} ({errors}/{args.n})", file=out)

@@ -86,6 +86,50 @@ int main(void) {
     assert got["t_nrLDPC_dec_params"] == "40" and got["t_nrLDPC_dec_params.check_crc"] == "24"
 
 
+REF = Path("/root/reference")
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree not present (development container only)")
+def test_layouts_against_the_reference_headers(built, tmp_path):
+    """The plugin ABI structures as the REFERENCE's own headers declare them vs include/nrLDPC_hip.h, compiler against
+    compiler.  nrLDPC_decoder/nrLDPC_types.h (t_nrLDPC_dec_params, e_nrLDPC_outMode, t_nrLDPC_time_stats, time_stats_t via
+    common/utils/time_meas.h) compiles on its own: tests/abi_offsets.c is built once against it and once against our
+    header and the printed sizes / offsets / enum values must be identical.  encoder_implemparams_t (nrLDPC_defs.h:40-66)
+    and decode_abort_t (defs_common.h:998-1001) sit in headers that pull in the un-vendored SIMDE: their typedef TEXT is
+    read from the reference at test time (nothing is copied into the repository) and compiled next to nrLDPC_types.h."""
+    inc = ["-I", str(REF / "openair1"), "-I", str(REF / "common" / "utils"), "-I", str(REF)]
+    outs = []
+    for name, flags in (("ref", ["-DUSE_REFERENCE"] + inc), ("ours", ["-I", str(ROOT / "include")])):
+        exe = tmp_path / f"abi_{name}"
+        subprocess.run(["gcc"] + flags + [str(ROOT / "tests" / "abi_offsets.c"), "-o", str(exe)], check=True)
+        outs.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") >= 30, (outs[0], outs[1])
+
+    def typedef_text(path, name):
+        txt = (REF / path).read_text()
+        end = txt.index("} %s;" % name)
+        start = txt.rindex("typedef struct", 0, end)
+        return txt[start:end + len("} %s;" % name)]
+
+    enc = typedef_text("openair1/PHY/CODING/nrLDPC_defs.h", "encoder_implemparams_t")
+    ab = typedef_text("openair1/PHY/defs_common.h", "decode_abort_t")
+    fields_enc = re.findall(r"(\w+)\s*;", re.sub(r"/\*.*?\*/|//[^\n]*", "", enc[enc.index("{") + 1:enc.rindex("}")], flags=re.S))
+    prog = ("#include <stddef.h>\n#include <stdio.h>\n#include <stdbool.h>\n#include <pthread.h>\n%s\n%s\n%s\n"
+            "#define F(T, f) printf(#T \".\" #f \" %%zu %%zu\\n\", offsetof(T, f), sizeof(((T *)0)->f))\n"
+            "int main(void) { printf(\"%%zu %%zu\\n\", sizeof(encoder_implemparams_t), sizeof(decode_abort_t)); %s F(decode_abort_t, mutex_failure); F(decode_abort_t, failed); return 0; }\n")
+    body = " ".join("F(encoder_implemparams_t, %s);" % f for f in fields_enc)
+    res = []
+    for name, head, decl_enc, decl_ab, flags in (
+            ("ref", '#include "PHY/CODING/nrLDPC_decoder/nrLDPC_types.h"', enc, ab, inc),
+            ("ours", '#include "nrLDPC_hip.h"', "", "", ["-I", str(ROOT / "include")])):
+        src = tmp_path / f"enc_{name}.c"
+        src.write_text(prog % (head, decl_enc, decl_ab, body))
+        exe = tmp_path / f"enc_{name}"
+        subprocess.run(["gcc"] + flags + [str(src), "-o", str(exe)], check=True)
+        res.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert res[0] == res[1] and len(fields_enc) >= 19, (res[0], res[1])
+
+
 def test_no_cpu_fallback_without_gpu(built):
     """On a machine without a HIP device every entry point must fail loudly (this container); on the GPU box the
     call simply succeeds."""

@@ -258,6 +258,26 @@ def test_ldpctest_acceptance_and_seed_identical_bler(hip):
     assert gpu == cpu and gpu[0]["errors"] > 0
 
 
+def test_ldpctest_beyond_the_ci_lengths(hip):
+    """What ldpctest does outside the CI list (TESTBENCH/ldpctest.c:177-305): block lengths that are not Kb*Zc (the
+    encoder is handed K = block_length, pads with zeros and cuts the code word to the mother rate), the punctured rates
+    -r 2 -d 3 and -r 22 -d 25 (decoder modes R23 / R89), several segments per trial, and the one-trial encoder
+    cross-check.  On identical seeds the library and the CPU oracle produce the same result records -- pass counts,
+    block and bit errors -- whatever the reference's own bookkeeping makes of those lengths."""
+    import io
+    import ldpctest_hip as T
+    for extra in (["-l", "6000"], ["-l", "3000"], ["-l", "500", "-S", "3"], ["-l", "8448", "-r", "2", "-d", "3", "-s", "4"],
+                  ["-l", "8448", "-r", "22", "-d", "25", "-s", "7"], ["-l", "3872", "-r", "2", "-d", "3", "-s", "5", "-S", "9"],
+                  ["-l", "1000", "-r", "1", "-d", "5", "-s", "1"]):
+        args = extra + (["-s", "2"] if "-s" not in extra else []) + ["-t", "4", "-n", "6", "-i", "8", "--seed", "11"]
+        gpu = T.run(T.parser().parse_args(args), out=io.StringIO())
+        cpu = T.run(T.parser().parse_args(args + ["--oracle"]), out=io.StringIO())
+        assert gpu == cpu and len(gpu) >= 1, (extra, gpu, cpu)
+    buf = io.StringIO()                                      # -n 1: encoder cross-check, nothing may differ
+    T.run(T.parser().parse_args(["-l", "6000", "-s", "10", "-n", "1", "-S", "9"]), out=buf)
+    assert "differ in seg" not in buf.getvalue() and "BLER" in buf.getvalue()
+
+
 def test_concurrent_callers_of_the_reference_entry_point(hip, tmp_path):
     """16 pthreads calling LDPCdecoder() at once with different codes / caps / stop modes (the reference's thread-pool
     usage): every concurrent call must return what it returned single-threaded -- through the resident server kernel

@@ -78,3 +78,29 @@ def test_byte_per_lane_kernel_too():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_encoder.py"), "-m", "gpu", "-q", "-x",
                         "-k", "every_lifting_size or survey_stage"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_meters_are_filled(hip):
+    """The encoder's four optional meters (nrLDPC_defs.h:44-47) and the decoder's profiler are written the way the
+    reference's start_meas()/stop_meas() write them (common/utils/time_meas.h:148-176): trials counted, ticks accumulated,
+    flag cleared -- nr_dlsim's "encoder timing" lines read them."""
+    m = hip.ldpc
+    BG, Z = 1, 384
+    rng = np.random.default_rng(3)
+    infos = [rng.integers(0, 256, 22 * Z // 8, dtype=np.uint8) for _ in range(8)]
+    meters = [m.time_stats_t() for _ in range(4)]
+    for rep in range(3):
+        out = m.LDPCencoder(infos, BG, Z, meters=meters)
+    assert np.array_equal(out[0], O.encode(BG, Z, infos[0]))
+    for k, ts in enumerate(meters):
+        assert ts.trials == 3 and ts.meas_flag == 0 and ts.diff >= 0 and ts.max <= ts.diff, (k, ts.trials, ts.diff)
+    assert meters[0].diff > 0 and meters[2].diff > 0 and meters[3].diff > 0 and meters[2].p_time > 0
+    assert meters[2].diff_square > 0
+    prof = m.t_nrLDPC_time_stats()
+    llr = np.zeros(68 * Z, np.int8)
+    llr[2 * Z:] = 20
+    p = hip.make_dec_params(BG, Z, 13, 8)
+    for _ in range(2):
+        n, _ = hip.LDPCdecoder(p, llr, profiler=prof)
+    assert n == 2 and prof.total.trials == 2 and prof.total.diff > 0 and prof.total.meas_flag == 0
+    assert prof.cnProc.trials == 0                             # only `total` is written (include/nrLDPC_hip.h)

@@ -118,3 +118,67 @@ def test_tables_against_reference_lut(emul):
             deg = np.diff(p["row_ptr"])
             assert [int((deg == d).sum()) for d in groups[BG]] == ncn[(BG, R)], (BG, R)
     assert checked == 51 * (316 + 197)
+
+
+def _header_arrays(path, prefix):
+    txt = Path(path).read_text()
+    return {m.group(1)[len(prefix):]: [int(v) for v in re.findall(r"-?\d+", m.group(2))]
+            for m in re.finditer(r"(%s\w+)\s*(?:\[\d+\])+\s*=\s*\{(.*?)\};" % prefix, txt, re.S)}
+
+
+ROOT = Path(__file__).resolve().parent.parent
+PRODUCT_TABLES = ROOT / "openairinterface5g_amd" / "csrc" / "nr_ldpc_bg_tables.h"
+ORACLE_TABLES = ROOT / "oracle" / "oracle_bg_tables.h"
+
+
+def test_product_and_oracle_tables_come_from_two_routes_and_agree():
+    """The product's table header (generated from nrLDPC_decoder_LYC/bgs/BG*_I*, tools/gen_bg_tables.py) and the oracle's
+    own (generated from nrLDPC_lut.h + the .cu row-degree lists, tools/gen_oracle_tables.py) are different files that
+    hold the same numbers; both are the validated ones (sha256 recorded in the development container, where
+    test_tables_against_reference_lut and the generators' own cross-checks run) -- this part also runs on the GPU box."""
+    import hashlib
+    import json
+    a, b = _header_arrays(PRODUCT_TABLES, "nr_ldpc_"), _header_arrays(ORACLE_TABLES, "oracle_")
+    assert sorted(a) == sorted(b) == ["bg1_col", "bg1_row_deg", "bg1_shift", "bg2_col", "bg2_row_deg", "bg2_shift", "lift_sizes"]
+    for k in a:
+        assert a[k] == b[k], k
+    assert "nr_ldpc_bg_tables.h" not in "".join((ROOT / "oracle" / f).read_text() for f in
+                                                ("oracle_ldpc_decoder.c", "oracle_ldpc_encoder.c", "oracle_ldpc_decoder_vec.c"))
+    pinned = json.loads((GOLDEN_DIR / "table_hashes.json").read_text())
+    for name, path in (("product", PRODUCT_TABLES), ("oracle", ORACLE_TABLES)):
+        assert hashlib.sha256(path.read_bytes()).hexdigest() == pinned[name]["sha256"], name
+
+
+GOLDEN_DIR = ROOT / "tests" / "golden"
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree not present (development container only)")
+def test_bit_node_side_and_k0_against_reference_data(emul):
+    """The bit-node side of the reference's tables, read as data: lut_numBnInBnGroups_BG*_R* (nrLDPCdecoder_defs.h: how
+    many columns of each degree a rate mode has) against the column degrees of the oracle's / product's graph, and
+    index_k0 (nr_rate_matching.c:34) against the k0 the oracle and the product compute."""
+    defs = (REF / "nrLDPC_decoder" / "nrLDPCdecoder_defs.h").read_text()
+    for m in re.finditer(r"lut_numBnInBnGroups_BG(\d)_R(\d+)\[[^\]]*\]\s*=\s*\{([^}]*)\}", defs):
+        BG, R = int(m.group(1)), int(m.group(2))
+        ref = [int(v) for v in re.findall(r"\d+", m.group(3))]           # ref[d-1] = columns of degree d
+        for Z in (384, 208, 6):
+            g = O.graph(BG, Z, R)
+            deg = np.bincount(np.asarray(g.col[:g.nedges]), minlength=g.ncols)
+            got = [int((deg == d).sum()) for d in range(1, len(ref) + 1)]
+            assert got == ref, (BG, R, Z)
+            p = product_graph(emul, BG, Z, R)
+            assert np.array_equal(np.bincount(p["col"], minlength=p["ncols"]), deg)
+    rm = (REF / "nr_rate_matching.c").read_text()
+    m = re.search(r"index_k0\[2\]\[4\]\s*=\s*\{\{([^}]*)\},\s*\{([^}]*)\}\}", rm)
+    k0 = [[int(v) for v in re.findall(r"\d+", m.group(i))] for i in (1, 2)]
+    assert k0 == [[0, 17, 33, 56], [0, 13, 25, 43]]
+    import openairinterface5g_amd as pkg
+    for BG in (1, 2):
+        for rv in range(4):
+            for Z in (384, 96, 7):
+                N = (66 if BG == 1 else 50) * Z
+                E = 4 * Z
+                # nr_get_R_ldpc_decoder's infoBits = k0 index * Z + E (nr_rate_matching.c:399) is llrLen on round 0
+                for f in (O.get_R, lambda rv_, E_, BG_, Z_, a, b: pkg.ldpc.nr_get_R_ldpc_decoder(rv_, E_, BG_, Z_, a, b)):
+                    _, llrlen = f(rv, E, BG, Z, 0, 0)
+                    assert llrlen == min(k0[BG - 1][rv] * Z + E, N), (BG, rv, Z)
