@@ -26,7 +26,13 @@
  *   const uint32_t *crc_pow() x^j mod g, left aligned
  *   int out_mode()            0 packed bits, else one bit per byte
  *   int *tb_abort()           optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559)
- *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics) */
+ *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics)
+ *   int tid()                 threadIdx.x
+ *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
+ *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
+ *                             check-node phase when the block has converged); same results, same pass counts */
+
+#define LDPC_EAGER_MAX_BAD_LANES 96
 
 /* next ticket of a task queue (wave-uniform) */
 __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
@@ -56,7 +62,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   uint32_t *coltbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_coltbl);
   L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
   int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int tid = io.tid(), nt = blockDim.x, lane = tid & 63;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
   const uint32_t *__restrict__ src32 = io.src32();
 
@@ -153,8 +159,13 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       }
     }
 #endif
-    if (__any(syn != 0) && lane == 0)
-      flags[p & 1] = 1;
+    {
+      /* flags[p & 1] = how many lanes saw an unsatisfied check of the previous pass (0 = none: the stop criterion; the
+       * count itself only steers the eager check below) */
+      const unsigned long long bad_lanes = __ballot(syn != 0);
+      if (bad_lanes && lane == 0)
+        atomicAdd(&flags[p & 1], (int)__popcll(bad_lanes));
+    }
     if (tid == 0) {
       flags[2] = 0;
       flags[5] = 0; /* nobody draws bit-node tasks now */
@@ -167,6 +178,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       n_iter = max_pass + 1;
       break;
     }
+    const int bad_prev = flags[p & 1]; /* unsatisfied lanes after pass p - 1 (after the channel's hard decisions for p = 1) */
     if (!io.use_crc() && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;
       break;
@@ -193,6 +205,44 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       flags[4] = 0; /* nobody draws check-node tasks now */
     }
     __syncthreads();
+    if (io.eager_check() && !io.use_crc() && p >= 2 && p < max_pass && bad_prev <= LDPC_EAGER_MAX_BAD_LANES) {
+      /* the check the next pass would make first thing (decoder.c:842-848: cnProcPc on this pass' results; p + 1 >= 3 and
+       * p + 1 <= max_pass as there), as a sweep of its own over the same task list -- when the previous pass was already
+       * close (few unsatisfied lanes): a block that is far from converging does not pay for sweeps that cannot succeed,
+       * and a missed chance only means the stop is noticed one check-node phase later, with the same pass count */
+      uint32_t esyn = 0;
+      for (;;) {
+        const int task = ldpc_draw(&flags[4], lane);
+        if (task >= n_cn_tasks)
+          break;
+        const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+        const int item = code->f_cn_task[task][2] + lane;
+        const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
+        if (item < gend) {
+          const int gi = item - gstart;
+          const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
+          const uint32_t rowrec = rowtbl[srow0 + rig];
+          const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j;
+          const uint32_t m = ldpc_fast_pc(L, deg, ext, e0, j, rstride);
+          const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+          esyn |= m & mask;
+        }
+      }
+      if (__any(esyn != 0) && lane == 0)
+        flags[6] = 1;
+      __syncthreads();
+      const int bad = flags[6];
+      __syncthreads();
+      if (tid == 0) {
+        flags[6] = 0;
+        flags[4] = 0;
+      }
+      if (!bad) {
+        n_iter = p;
+        break;
+      }
+      __syncthreads();
+    }
     if (io.use_crc() && p >= 3) { /* see ldpc_dec_generic_block.h for the CRC argument */
       uint32_t x = 0;
       const int crcE = io.crcE();

@@ -230,6 +230,32 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
+/* Parity check of one check-node item on its own (no message update): the same 4-bit mask ldpc_fast_cn returns, from the
+ * APP signs of the row's core columns and, for an extension row, sat8(llr + r) of its degree-1 column (cnProc.h:940).
+ * Used by the latency path (ldpc_dec_fast_block.h, eager check): ~6 VALU per edge instead of a check-node update. */
+LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, int j, int rstride)
+{
+  const int t = 4 * j;
+  uint32_t parw = 0;
+  const int ncore_edges = ext ? D - 1 : D;
+  for (int k = 0; k < ncore_edges; k++)
+    parw ^= ldpc_window(L.base, L.etbl[e0 + k] + (uint32_t)t);
+  uint32_t np = (parw >> 7) & 0x01010101u;
+  if (ext) {
+    const uint32_t info = L.etbl[e0 + D - 1];
+    const uint32_t lw = L.ext_global ? (*reinterpret_cast<const uint32_t *>(L.gllr + info + (uint32_t)t) ^ 0x80808080u)
+                                     : ldpc_lds_ld32(L.base, info + (uint32_t)t);
+    const uint32_t rw = *reinterpret_cast<const uint32_t *>(L.r + (e0 + D - 1) * rstride + t);
+    const uint32_t extl = ldpc_perm(0x80808080u, lw, 0x05010400u) + ldpc_perm(0u, rw, 0x0c010c00u);
+    const uint32_t exth = ldpc_perm(0x80808080u, lw, 0x05030402u) + ldpc_perm(0u, rw, 0x0c030c02u);
+    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
+    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
+  }
+  if (D & 1)
+    np ^= 0x01010101u;
+  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+}
+
 #ifndef LDPC_F_MODE_D19
 #define LDPC_F_MODE_D19 2
 #endif

@@ -33,6 +33,8 @@ template <bool JOBS> struct ldpc_batch_io {
     return (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
   }
   __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ bool eager_check() const { return false; }
 };
 
 /* JOBS = heterogeneous batch (one job record per workgroup, optional transport-block abort flags); the homogeneous

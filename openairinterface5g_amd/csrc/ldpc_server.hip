@@ -18,14 +18,16 @@
 #include "ldpc_dec_generic_block.h"
 #include "ldpc_enc_packed_core.h"
 
-/* 12 waves: 168 VGPRs per lane, which is what the loop below needs to hold the fast decoder (127 VGPRs on its own)
- * without spilling -- a resident kernel had better not depend on scratch memory.  With 16 waves (128 VGPRs) it spills
- * 36-45 registers; with the encoder's phases compiled in as well (SRV_WITH_ENCODER) 7 even at 12 waves, so LDPCencoder
- * calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
+/* 16 waves (128 VGPRs per lane), like the batch kernel's workgroup for the large codes: a pass is ~9 % faster than with 12
+ * waves and 168 VGPRs (measured, profiles/r02/README.md).  Around the inlined decoders the server loop does not fit in
+ * 128 VGPRs: ~20 registers spill, all of them per-thread addresses of the request fetch that are stored before the loop
+ * and reloaded once per request -- there is no scratch access inside the decoder's phases (checked in the
+ * disassembly).  With the encoder's phases compiled in as well (SRV_WITH_ENCODER) the spills reach the hot loops, so
+ * LDPCencoder calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
 #ifndef SRV_THREADS
-#define SRV_THREADS 768
+#define SRV_THREADS 1024
 #endif
-#define SRV_ENC_GROUP 96 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
+#define SRV_ENC_GROUP 128 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
 #define SRV_FETCH ((SRV_IN_STRIDE / 16 + SRV_THREADS - 1) / SRV_THREADS)
 #ifndef SRV_WITH_ENCODER
 #define SRV_WITH_ENCODER 0
@@ -46,6 +48,14 @@ __device__ __forceinline__ void srv_st_sys(uint32_t *p, uint32_t v)
  * stack.  Either way scratch memory, which a resident kernel had better not depend on. */
 typedef const srv_args LDPC_CONST_AS *srv_args_ptr_t;
 
+/* a wave-uniform pointer the compiler has put (or might put) in VGPRs, back in SGPRs: what is derived from it then is
+ * scalar too and does not compete with the decoder for vector registers */
+template <typename T> __device__ __forceinline__ T *srv_sgpr(T *p)
+{
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  return reinterpret_cast<T *>(((uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)v));
+}
+
 struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_dec_fast_block.h) */
   const srv_req *rq;
   const uint8_t *payload;
@@ -61,6 +71,9 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)rq->out_mode); }
   __device__ __forceinline__ int *tb_abort() const { return nullptr; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
+  int tid_;
+  __device__ __forceinline__ int tid() const { return tid_; }
+  __device__ __forceinline__ bool eager_check() const { return true; }
 };
 
 __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
@@ -152,11 +165,13 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
     /* (readfirstlane returns int: widen as unsigned, or a low dword >= 2^31 smears ones over the high dword) */
     ldpc_code_ptr_t code = (ldpc_code_ptr_t)(((uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)(rq->code >> 32)) << 32) |
                                              (uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)rq->code));
-    const uint8_t *payload = a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE + SRV_REQ_BYTES;
-    uint8_t *hout = a->out_host + (size_t)blockIdx.x * SRV_OUT_STRIDE;
+    const uint8_t *payload = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE + SRV_REQ_BYTES);
+    uint8_t *hout = srv_sgpr(a->out_host + (size_t)blockIdx.x * SRV_OUT_STRIDE);
     int n_iter = 0;
     if (kind == SRV_KIND_DEC_FAST) {
-      const srv_fast_io io{rq, payload, hout, a, bc + 24};
+      int tid_l = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid_l)); /* per iteration: nothing derived from it is hoisted out of the server loop */
+      const srv_fast_io io{rq, payload, hout, a, bc + 24, tid_l};
       n_iter = ldpc_dec_fast_block(fsm, code, io);
     } else if (kind == SRV_KIND_DEC_GENERIC) {
       ldpc_gblock_io io;
