@@ -20,6 +20,9 @@
  * is not carried in registers through the check-node loops (the kernel sits at the VGPR limit and already keeps part of
  * its scalar state in VGPR lanes):
  *   const uint32_t *src32()   the block's channel LLRs: ncols*Z int8, 4-byte aligned, device memory (re-read every pass)
+ *   const uint32_t *src32_prologue()   where the prologue reads them (the same, or host memory in the server path)
+ *   uint32_t *stage_core()    nullptr, or: the prologue also writes the core columns' LLRs there (= src32(), a device
+ *                             copy of what it read from host memory), made visible before the first bit-node phase
  *   int8_t *out()             output row (packed bits: 4-byte aligned)
  *   int max_pass()            numMaxIter + 1
  *   int use_crc(), crcE()     CRC stop mode and the bits it covers
@@ -65,33 +68,47 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   const int tid = io.tid(), nt = blockDim.x, lane = tid & 63;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
   const uint32_t *__restrict__ src32 = io.src32();
+  const uint32_t *__restrict__ srcp = io.src32_prologue();
+  uint32_t *stage = io.stage_core();
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
   const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
   const int ext_global = code->f_ext_global;
   L.gllr = reinterpret_cast<const uint8_t *>(src32);
   L.ext_global = ext_global;
-  /* The block's LLRs come from HBM: the first four dwords per thread of the core and of the extension columns are
-   * requested before anything else and consumed after the table copies and the message initialisation, so that their
-   * latency runs in the background (a 1024-thread workgroup needs 3 + 4 such loads per thread for Zc = 384). */
+  /* The block's LLRs: the first four dwords per thread of the core and of the extension columns are requested early and
+   * consumed after the message initialisation, so that their latency runs in the background (a 1024-thread workgroup
+   * needs 3 + 4 such loads per thread for Zc = 384).  From HBM they go out before anything else; from host memory (the
+   * server path, `stage`) only after the table copies -- loads retire in order, and the tables' device loads would
+   * otherwise sit behind a trip over the link. */
   const int n_app = ncore * zq, n_ext = ext_global ? 0 : (code->ncols - ncore) * zq;
   uint32_t va[4], ve[4];
+  if (!stage) {
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int ia = tid + k * nt;
-    va[k] = ia < n_app ? src32[ia] : 0u;
-    ve[k] = ia < n_ext ? src32[n_app + ia] : 0u;
+    for (int k = 0; k < 4; k++) {
+      const int ia = tid + k * nt;
+      va[k] = ia < n_app ? srcp[ia] : 0u;
+      ve[k] = ia < n_ext ? srcp[n_app + ia] : 0u;
+    }
   }
   for (int i = tid; i < nedges; i += nt)
     etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
   for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
     ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
-  for (int i = tid; i < (Z + 4) >> 2; i += nt)
-    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   for (int i = tid; i < code->nrows; i += nt)
     rowtbl[i] = code->f_rowtbl[i];
   for (int i = tid; i < ncore; i += nt)
     coltbl[i] = code->f_coltbl[i];
+  if (stage) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ia = tid + k * nt;
+      va[k] = ia < n_app ? srcp[ia] : 0u;
+      ve[k] = ia < n_ext ? srcp[n_app + ia] : 0u;
+    }
+  }
+  for (int i = tid; i < (Z + 4) >> 2; i += nt)
+    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   if (tid < 8)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen,
                        [4], [5] task queues of the two phases */
@@ -112,19 +129,23 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
       dst[0] = w;
       dst[zq] = w;
+      if (stage)
+        stage[i] = va[k];
     }
     if (i < n_ext)
       e32[i] = ve[k] ^ 0x80808080u;
   }
   for (int i = tid + 4 * nt; i < n_app; i += nt) { /* small workgroups: the rest */
     const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
-    const uint32_t w = src32[i] ^ 0x80808080u;
+    const uint32_t v = srcp[i], w = v ^ 0x80808080u;
     uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
     dst[0] = w;
     dst[zq] = w;
+    if (stage)
+      stage[i] = v;
   }
   for (int i = tid + 4 * nt; i < n_ext; i += nt)
-    e32[i] = src32[n_app + i] ^ 0x80808080u;
+    e32[i] = srcp[n_app + i] ^ 0x80808080u;
   __syncthreads();
   if (io.stamps() && tid == 0)
     io.stamps()[0] = (uint32_t)wall_clock64();
@@ -178,6 +199,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       n_iter = max_pass + 1;
       break;
     }
+    if (stage && p == 1)
+      __threadfence(); /* the core columns' device copy (written in the prologue, long since arrived) is read from here on:
+                          drop what L1 may hold of the slot's previous request (the workgroup barrier above orders it) */
     const int bad_prev = flags[p & 1]; /* unsatisfied lanes after pass p - 1 (after the channel's hard decisions for p = 1) */
     if (!io.use_crc() && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;

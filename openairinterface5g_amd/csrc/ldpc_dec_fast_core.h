@@ -238,7 +238,23 @@ LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, in
   const int t = 4 * j;
   uint32_t parw = 0;
   const int ncore_edges = ext ? D - 1 : D;
-  for (int k = 0; k < ncore_edges; k++)
+  /* the sweep is a chain table entry -> window per edge: four edges in flight */
+  int k = 0;
+  for (; k + 4 <= ncore_edges; k += 4) {
+    uint32_t info[4], lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      info[i] = L.etbl[e0 + k + i] + (uint32_t)t;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      lo[i] = ldpc_lds_ld32(L.base, info[i] & ~3u);
+      hi[i] = ldpc_lds_ld32(L.base, (info[i] & ~3u) + 4u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      parw ^= ldpc_alignbyte(hi[i], lo[i], info[i]);
+  }
+  for (; k < ncore_edges; k++)
     parw ^= ldpc_window(L.base, L.etbl[e0 + k] + (uint32_t)t);
   uint32_t np = (parw >> 7) & 0x01010101u;
   if (ext) {

@@ -35,6 +35,8 @@ template <bool JOBS> struct ldpc_batch_io {
   __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ bool eager_check() const { return false; }
+  __device__ __forceinline__ const uint32_t *src32_prologue() const { return src32(); }
+  __device__ __forceinline__ uint32_t *stage_core() const { return nullptr; }
 };
 
 /* JOBS = heterogeneous batch (one job record per workgroup, optional transport-block abort flags); the homogeneous

@@ -8,9 +8,19 @@
  * its slot's doorbell in page-locked host memory.  A call is then: memcpy the LLRs into the slot, ring the doorbell,
  * spin on the completion word -- no runtime call, no lock shared between callers.
  *
- *   host -> GPU   slot ctl line 0: doorbell = (sequence << 12) | number of 16-byte units of [header | payload]
- *                 slot input area: srv_req header (64 B) followed by the payload (LLRs / segment bytes)
- *   GPU -> host   slot output area (bits / coded bytes), then ctl line 1: n_iter, done = doorbell value served
+ * Where the request lives: with a large PCIe BAR (every Instinct part) the request line and the payload area are DEVICE
+ * memory that the host writes directly (write-combining posted writes, ~24 GB/s measured: profiles/r02/bar_write.txt):
+ * the workgroup then polls and reads local memory -- no read ever crosses the link, which matters because one CU can
+ * keep only ~64 reads in flight (26 KB of LLRs pulled from host memory by one workgroup took 8-10 us).  Without a large
+ * BAR both sit in page-locked host memory and the workgroup pulls.
+ *
+ *   host -> GPU   request line (64 bytes) = the request header in four 16-byte chunks, each led by a tag word holding
+ *                 the call's sequence number; the host writes chunk 3, 2, 1, then chunk 0, fields before tag, so that
+ *                 whichever way the link splits the GPU's 64-byte read, a chunk whose tag shows the new number is
+ *                 complete -- the poll that sees four equal new tags HAS the header (no second trip for it);
+ *                 slot input area: the payload (LLRs / segment bytes), read by the decoder straight from host memory
+ *   GPU -> host   slot output area (bits / coded bytes), n_iter and timing stamps in ctl line 1, then -- behind a
+ *                 system-scope fence of every thread and a barrier -- done = sequence number served
  *
  * Lifetime: the kernel exits by itself when no slot has seen a request for `idle_ticks` (so a process that stops
  * calling -- or calls hipDeviceSynchronize -- is never stuck behind it) or when the host raises *host_stop.  The
@@ -24,8 +34,7 @@
 #include <stdint.h>
 
 #define SRV_MAX_SLOTS 128
-#define SRV_REQ_BYTES 64u
-#define SRV_IN_STRIDE (28u * 1024u)                /* header + up to 68*384 LLRs, or 8 segments of 1056 B */
+#define SRV_IN_STRIDE (28u * 1024u)                /* up to 68*384 LLRs, or 8 segments of 1056 B */
 #define SRV_OUT_STRIDE (200u * 1024u)              /* 8 segments x 66*384 coded bytes; decoder: <= 68*384 */
 #define SRV_LDS_BYTES (160 * 1024)
 #define SRV_BC_OFF (SRV_LDS_BYTES - 256)           /* broadcast area at the end of the workgroup's LDS */
@@ -33,25 +42,28 @@
 
 enum { SRV_KIND_DEC_FAST = 1, SRV_KIND_DEC_GENERIC = 2, SRV_KIND_ENC = 3 };
 
-typedef struct srv_req {   /* 64 bytes, first in the slot's input area */
-  uint32_t kind;
+typedef struct srv_req {   /* ctl line 0, host-written: four chunks of {tag, three words} */
+  uint32_t tag0;           /* = sequence number of the call (never 0, never 0xffffffff); written LAST */
+  uint32_t kind_mode;      /* kind | out_mode << 8 | use_crc << 16 | crc_type << 24 */
   uint32_t max_pass;       /* decoder: numMaxIter + 1 */
-  uint32_t use_crc, crcE, crc_type, out_mode;
-  uint32_t Kb, n_seg;      /* encoder: information columns, segments in this call (<= 8) */
-  uint64_t code;           /* device address of the ldpc_code_desc_t */
+  uint32_t crcE;
+  uint32_t tag1;
+  uint32_t code_lo, code_hi; /* device address of the ldpc_code_desc_t */
+  uint32_t kb_nseg;        /* encoder: information columns | segments in this call (<= 8) << 16 */
+  uint32_t tag2;
   uint32_t seg_in_stride, seg_out_stride; /* encoder: bytes between segments in the payload / output area */
-  uint32_t pad[4];
+  uint32_t payload_bytes;
+  uint32_t tag3;
+  uint32_t pad[3];
 } srv_req;
 
-typedef struct srv_slot_ctl { /* 128 bytes: one cache line per direction */
-  uint32_t doorbell;       /* host-written */
-  uint32_t pad0[15];
-  uint32_t done;           /* GPU-written: the doorbell value whose results are complete */
+typedef struct srv_slot_ctl { /* 64 bytes, GPU-written, in page-locked host memory: */
+  uint32_t done;           /* the sequence number whose results are complete: written last, system-scope release */
   int32_t n_iter;
-  uint32_t t_seen, t_staged, t_decoded; /* wall_clock64 (100 MHz) stamps of the request just served: doorbell seen,
-                                           payload staged, block function returned (diagnostics, nrLDPC_hip_server_stats) */
-  uint32_t t_prologue, t_passes; /* fast decoder only: state in LDS (first barrier passed), last pass finished */
-  uint32_t pad1[9];
+  uint32_t t_stage_decode; /* diagnostics, 10 ns ticks: request seen -> decoder entered (low 16 bits), -> block function
+                              returned (high 16 bits) */
+  uint32_t t_pro_passes;   /* fast decoder only: entered -> state in LDS (low), -> last pass finished (high) */
+  uint32_t pad1[12];
 } srv_slot_ctl;
 
 typedef struct srv_gctl {  /* device memory, shared by the workgroups of a generation */
@@ -61,10 +73,12 @@ typedef struct srv_gctl {  /* device memory, shared by the workgroups of a gener
 } srv_gctl;
 
 typedef struct srv_args {
-  srv_slot_ctl *ctl;       /* host, [n_slots] */
-  const uint8_t *in_host;  /* host, n_slots x SRV_IN_STRIDE */
+  srv_slot_ctl *ctl;       /* host, [n_slots]: completion lines */
+  const srv_req *req;      /* [n_slots] request lines: device memory the host writes over the PCIe BAR (fine-grained, so that
+                              the GPU does not keep stale copies in L2), or page-locked host memory without a large BAR */
+  const uint8_t *in_host;  /* n_slots x SRV_IN_STRIDE payload areas, same kind of memory as req */
   uint8_t *out_host;       /* host, n_slots x SRV_OUT_STRIDE */
-  uint8_t *staging;        /* device, n_slots x SRV_IN_STRIDE */
+  uint8_t *staging;        /* device, n_slots x SRV_IN_STRIDE: the core columns' LLRs, which the fast decoder re-reads every pass */
   srv_gctl *gctl;          /* device */
   uint32_t *state;         /* host: 2*gen+1 running, 2*gen+2 stopped */
   const uint32_t *host_stop; /* host: == gen asks generation gen to stop */

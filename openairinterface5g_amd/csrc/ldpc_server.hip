@@ -1,12 +1,13 @@
 /*
  * ldpc_server.hip -- resident server kernel behind the per-segment plugin entry points (protocol: ldpc_server.h).
  *
- * One workgroup of 1024 threads per caller slot, owning a whole CU (160 KiB of LDS).  Thread 0 polls the slot's
- * doorbell in page-locked host memory; a request is fetched by all threads straight from host memory ([header |
- * payload], 16 bytes per thread and load, everything in flight at once), staged in device memory (the decoder
- * re-reads the core columns' LLRs every pass), run through the same per-block device functions as the batch kernels
- * (ldpc_dec_fast_block.h / ldpc_dec_generic_block.h / ldpc_enc_packed_core.h) and the results are written straight
- * into the slot's host output area, followed by the completion word.
+ * One workgroup of 1024 threads per caller slot, owning a whole CU (160 KiB of LDS).  Wave 0 polls the slot's request
+ * line in page-locked host memory (64 bytes: the whole request header arrives with the poll that notices it); the
+ * payload is read straight from the slot's host memory by the decoder's own prologue (its latency hides behind the
+ * table and message initialisation; the fast decoder drops a device copy of the core columns, which it re-reads every
+ * pass), the block runs through the same per-block device functions as the batch kernels (ldpc_dec_fast_block.h /
+ * ldpc_dec_generic_block.h / ldpc_enc_packed_core.h) and the results are written straight into the slot's host
+ * output area, followed by the completion word.
  *
  * Replaces, for the reference's call pattern (one LDPCdecoder call per code segment from each thread-pool worker,
  * nr_ulsch_decoding.c:435-468; one LDPCencoder call per 8 segments, nr_dlsch_coding.c:386-403), the HIP runtime round
@@ -28,7 +29,6 @@
 #define SRV_THREADS 1024
 #endif
 #define SRV_ENC_GROUP 128 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
-#define SRV_FETCH ((SRV_IN_STRIDE / 16 + SRV_THREADS - 1) / SRV_THREADS)
 #ifndef SRV_WITH_ENCODER
 #define SRV_WITH_ENCODER 0
 #endif
@@ -58,20 +58,23 @@ template <typename T> __device__ __forceinline__ T *srv_sgpr(T *p)
 
 struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_dec_fast_block.h) */
   const srv_req *rq;
-  const uint8_t *payload;
+  const uint8_t *host_llr;  /* the slot's input area in host memory: read once, by the prologue */
+  const uint8_t *staged;    /* device copy of the core columns, written by the prologue, re-read every pass */
   uint8_t *hout;
   srv_args_ptr_t a;
   uint32_t *st;
-  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(payload); }
+  int tid_;
+  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(staged); }
+  __device__ __forceinline__ const uint32_t *src32_prologue() const { return reinterpret_cast<const uint32_t *>(host_llr); }
+  __device__ __forceinline__ uint32_t *stage_core() const { return reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(staged)); }
   __device__ __forceinline__ int8_t *out() const { return reinterpret_cast<int8_t *>(hout); }
   __device__ __forceinline__ int max_pass() const { return LDPC_UNIFORM((int)rq->max_pass); }
-  __device__ __forceinline__ int use_crc() const { return LDPC_UNIFORM((int)rq->use_crc); }
+  __device__ __forceinline__ int use_crc() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 16) & 0xffu)); }
   __device__ __forceinline__ int crcE() const { return LDPC_UNIFORM((int)rq->crcE); }
-  __device__ __forceinline__ const uint32_t *crc_pow() const { return a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u]; }
-  __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)rq->out_mode); }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return a->crc_pow_tbl[LDPC_UNIFORM(rq->kind_mode >> 24) & 3u]; }
+  __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu)); }
   __device__ __forceinline__ int *tb_abort() const { return nullptr; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
-  int tid_;
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }
 };
@@ -95,16 +98,22 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
   }
   for (;;) {
     a = SRV_ARGS();
-    if (threadIdx.x == 0) {
-      srv_slot_ctl *slot = a->ctl + blockIdx.x;
+    if (threadIdx.x < 64) {
+      /* wave 0 polls: lanes 0..15 read the 16 words of the slot's request line in ONE load; the request is there when
+       * the four chunk tags agree on a number that is not the one served last (ldpc_server.h) */
+      const uint32_t *line = reinterpret_cast<const uint32_t *>(a->req + blockIdx.x);
       const uint32_t last = bc[1], gen = a->gen;
-      const int w = blockIdx.x;
-      uint32_t d;
+      const int w = blockIdx.x, lane = threadIdx.x;
+      uint32_t d, word = 0;
       for (;;) {
-        /* both host words are requested before either is looked at: one PCIe round trip per poll */
-        d = srv_ld_sys(&slot->doorbell);
-        const uint32_t hs = w == 0 ? srv_ld_sys(a->host_stop) : 0u;
-        if (d != last)
+        if (lane < 16)
+          word = srv_ld_sys(line + lane);
+        /* (workgroup 0 also looks at the host's stop word: both host reads are in flight together) */
+        const uint32_t hs = (w == 0 && lane == 0) ? srv_ld_sys(a->host_stop) : 0u;
+        const uint32_t t0 = __builtin_amdgcn_readlane(word, 0), t1 = __builtin_amdgcn_readlane(word, 4),
+                       t2 = __builtin_amdgcn_readlane(word, 8), t3 = __builtin_amdgcn_readlane(word, 12);
+        d = t0;
+        if (t0 != last && t0 == t1 && t0 == t2 && t0 == t3)
           break;
         if (__hip_atomic_load(&a->gctl->stopping_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
           d = 0xffffffffu;
@@ -113,85 +122,61 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
         if (w == 0) { /* workgroup 0 decides for everybody: host request, or nobody has called for idle_ticks */
           const long long idle = (long long)wall_clock64() -
                                  __hip_atomic_load(&a->gctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (hs == gen || idle > (long long)a->idle_ticks) {
+          if ((uint32_t)__builtin_amdgcn_readfirstlane(hs) == gen || idle > (long long)a->idle_ticks) {
             __hip_atomic_store(&a->gctl->stopping_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d = 0xffffffffu;
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
       }
-      bc[0] = d;
-      bc[2] = (uint32_t)wall_clock64();
+      if (lane < 16)
+        bc[4 + lane] = word;
+      if (lane == 0) {
+        bc[0] = d;
+        bc[2] = (uint32_t)wall_clock64();
+      }
     }
     __syncthreads();
     const uint32_t d = bc[0];
     if (d == 0xffffffffu)
       break;
-    /* the host wrote [header | payload] before the doorbell: order our loads behind the doorbell load */
+    /* the host wrote the payload before the request line: order our loads behind the poll */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    a = SRV_ARGS();
-    {
-      const uint32_t n16 = d & 0xfffu;
-      const uint4 *hin = reinterpret_cast<const uint4 *>(a->in_host + (size_t)blockIdx.x * SRV_IN_STRIDE);
-      uint4 *stg = reinterpret_cast<uint4 *>(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
-      /* SRV_FETCH loads per thread, all in flight together: SRV_FETCH * SRV_THREADS * 16 bytes >= SRV_IN_STRIDE */
-      static_assert((size_t)SRV_FETCH * SRV_THREADS * 16 >= SRV_IN_STRIDE, "a request must fit the fetch");
-      uint4 v[SRV_FETCH];
-#pragma unroll
-      for (int k = 0; k < SRV_FETCH; k++) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * SRV_THREADS;
-        v[k] = make_uint4(0, 0, 0, 0);
-        if (i < n16)
-          v[k] = hin[i];
-      }
-#pragma unroll
-      for (int k = 0; k < SRV_FETCH; k++) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * SRV_THREADS;
-        if (i < n16)
-          stg[i] = v[k];
-      }
-      const uint4 v0 = v[0];
-      if (threadIdx.x < 4)
-        reinterpret_cast<uint4 *>(bc + 4)[threadIdx.x] = v0;
-    }
-    __threadfence(); /* the staged payload is re-read by other waves of this workgroup through L1 / L2 */
-    __syncthreads();
     a = SRV_ARGS();
     if (threadIdx.x == 0)
       bc[3] = (uint32_t)wall_clock64();
     const srv_req *rq = reinterpret_cast<const srv_req *>(bc + 4);
-    const uint32_t kind = LDPC_UNIFORM(rq->kind);
+    const uint32_t kind = LDPC_UNIFORM(rq->kind_mode) & 0xffu;
     /* (readfirstlane returns int: widen as unsigned, or a low dword >= 2^31 smears ones over the high dword) */
-    ldpc_code_ptr_t code = (ldpc_code_ptr_t)(((uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)(rq->code >> 32)) << 32) |
-                                             (uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)rq->code));
-    const uint8_t *payload = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE + SRV_REQ_BYTES);
+    ldpc_code_ptr_t code = (ldpc_code_ptr_t)(((uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_hi) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_lo));
+    const uint8_t *host_in = srv_sgpr(a->in_host + (size_t)blockIdx.x * SRV_IN_STRIDE);
     uint8_t *hout = srv_sgpr(a->out_host + (size_t)blockIdx.x * SRV_OUT_STRIDE);
     int n_iter = 0;
     if (kind == SRV_KIND_DEC_FAST) {
       int tid_l = (int)threadIdx.x;
-      asm volatile("" : "+v"(tid_l)); /* per iteration: nothing derived from it is hoisted out of the server loop */
-      const srv_fast_io io{rq, payload, hout, a, bc + 24, tid_l};
+      const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
+      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l};
       n_iter = ldpc_dec_fast_block(fsm, code, io);
     } else if (kind == SRV_KIND_DEC_GENERIC) {
       ldpc_gblock_io io;
-      io.llr = reinterpret_cast<const int8_t *>(payload);
+      io.llr = reinterpret_cast<const int8_t *>(host_in); /* read once, straight from the slot's host memory */
       io.out = reinterpret_cast<int8_t *>(hout);
       io.max_pass = LDPC_UNIFORM((int)rq->max_pass);
-      io.use_crc = LDPC_UNIFORM((int)rq->use_crc);
+      io.use_crc = LDPC_UNIFORM((int)((rq->kind_mode >> 16) & 0xffu));
       io.crcE = LDPC_UNIFORM((int)rq->crcE);
-      io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->crc_type) & 3u];
-      io.out_mode = LDPC_UNIFORM((int)rq->out_mode);
+      io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->kind_mode >> 24) & 3u];
+      io.out_mode = LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu));
       io.tb_abort = nullptr;
       n_iter = ldpc_dec_generic_block(reinterpret_cast<int8_t *>(fsm), code, io);
     } else if (SRV_WITH_ENCODER && kind == SRV_KIND_ENC) {
       /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases */
       const int tid = threadIdx.x, grp = tid / SRV_ENC_GROUP, gt = tid - grp * SRV_ENC_GROUP;
-      const int n_seg = LDPC_UNIFORM((int)rq->n_seg), Kb = LDPC_UNIFORM((int)rq->Kb);
+      const int n_seg = LDPC_UNIFORM((int)(rq->kb_nseg >> 16)), Kb = LDPC_UNIFORM((int)(rq->kb_nseg & 0xffffu));
       const int words = ldpc_encp_lds_words(code->ncols, code->kb_full, code->Z, code->nrows, code->nedges);
       ldpc_encp_lds L;
       ldpc_encp_carve(reinterpret_cast<uint32_t *>(fsm) + (size_t)grp * ((words + 3) & ~3), code, L);
-      const uint8_t *in = payload + (size_t)grp * LDPC_UNIFORM(rq->seg_in_stride);
+      const uint8_t *in = host_in + (size_t)grp * LDPC_UNIFORM(rq->seg_in_stride);
       uint8_t *out = hout + (size_t)grp * LDPC_UNIFORM(rq->seg_out_stride);
       for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++) {
         if (grp < n_seg)
@@ -199,19 +184,28 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
         __syncthreads();
       }
     }
-    /* results -> host, then the completion word: every thread's stores are out before thread 0 rings */
+    /* results -> host, then the completion word.  n_iter and the timing stamps travel with the results; every thread's
+     * stores are fenced to system scope before the barrier, and only then thread 0 rings -- with a system-scope RELEASE
+     * store (a plain store may be reordered against the result bytes on its way to host memory: measured, a handful
+     * of calls in 10^4 returned with stale output bytes) */
     const uint32_t t_decoded = (uint32_t)wall_clock64();
-    __threadfence_system();
+    if (threadIdx.x == 0) {
+      srv_slot_ctl *slot = a->ctl + blockIdx.x;
+      const uint32_t clip = 0xffffu;
+      const uint32_t dt_stage = bc[3] - bc[2], dt_dec = t_decoded - bc[3];
+      const uint32_t dt_pro = kind == SRV_KIND_DEC_FAST ? bc[24] - bc[3] : 0u, dt_pas = kind == SRV_KIND_DEC_FAST ? bc[25] - bc[24] : 0u;
+      srv_st_sys(reinterpret_cast<uint32_t *>(&slot->n_iter), (uint32_t)n_iter);
+      srv_st_sys(&slot->t_stage_decode, (dt_stage < clip ? dt_stage : clip) | ((dt_dec < clip ? dt_dec : clip) << 16));
+      srv_st_sys(&slot->t_pro_passes, (dt_pro < clip ? dt_pro : clip) | ((dt_pas < clip ? dt_pas : clip) << 16));
+    }
+    /* every wave pushes its own result stores out to system scope (L2 write-back of what it wrote + wait) before the
+     * barrier; a release by the publishing thread alone is NOT enough -- tried: the other waves' bytes, acknowledged by L2
+     * only, were overtaken by the completion word about once in 10^3 calls.  Release only: nothing is acquired here. */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     a = SRV_ARGS();
     if (threadIdx.x == 0) {
       srv_slot_ctl *slot = a->ctl + blockIdx.x;
-      srv_st_sys(reinterpret_cast<uint32_t *>(&slot->n_iter), (uint32_t)n_iter);
-      srv_st_sys(&slot->t_seen, bc[2]);
-      srv_st_sys(&slot->t_staged, bc[3]);
-      srv_st_sys(&slot->t_decoded, t_decoded);
-      srv_st_sys(&slot->t_prologue, bc[24]);
-      srv_st_sys(&slot->t_passes, bc[25]);
       __hip_atomic_store(&slot->done, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
       bc[1] = d;

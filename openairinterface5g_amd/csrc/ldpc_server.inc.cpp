@@ -8,6 +8,8 @@
  * shared with other callers and makes no HIP runtime call while the server is up.
  *
  * Environment: NRLDPC_HIP_SERVER=0 falls back to one launch per call (stream + pinned staging per thread);
+ * NRLDPC_HIP_SRV_BAR=0 keeps requests in host memory (pulled by the GPU) even where the host could push them into device
+ * memory;
  * NRLDPC_HIP_SRV_SLOTS=<n> caller slots = workgroups = CUs the server occupies while it is up (default 64, more
  * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
  * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls).
@@ -41,7 +43,9 @@ struct Server {
   int n_slots = 0;
   srv_args args;            /* template of the kernel arguments (gen filled in per launch) */
   srv_slot_ctl *ctl = nullptr;
+  srv_req *req = nullptr;   /* request lines and payload areas: device memory written over the BAR, or host memory */
   uint8_t *in_h = nullptr, *out_h = nullptr;
+  bool over_bar = false;
   uint32_t *state = nullptr, *host_stop = nullptr;
   hipStream_t stream = nullptr;
   std::atomic<uint32_t> gen{0};
@@ -71,7 +75,29 @@ int srv_init_locked()
   const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
   uint8_t *small = nullptr;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.ctl), (size_t)n * sizeof(srv_slot_ctl), flags));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.in_h), (size_t)n * SRV_IN_STRIDE, flags));
+  /* request lines + payload areas: in device memory when the host can write there (large BAR), see ldpc_server.h */
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, g.dev[0].id) != hipSuccess)
+    large_bar = 0;
+  const char *eb = getenv("NRLDPC_HIP_SRV_BAR");
+  srv.over_bar = large_bar == 1 && !(eb && atoi(eb) == 0);
+  if (srv.over_bar) {
+    uint8_t *blk = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&blk), (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE), hipDeviceMallocFinegrained) == hipSuccess) {
+      HIP_TRY(hipMemset(blk, 0, (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE)));
+      HIP_TRY(hipDeviceSynchronize());
+      srv.req = reinterpret_cast<srv_req *>(blk);
+      srv.in_h = blk + (size_t)n * sizeof(srv_req);
+    } else {
+      (void)hipGetLastError();
+      srv.over_bar = false;
+    }
+  }
+  if (!srv.over_bar) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.req), (size_t)n * sizeof(srv_req), flags));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.in_h), (size_t)n * SRV_IN_STRIDE, flags));
+    memset(srv.req, 0, (size_t)n * sizeof(srv_req));
+  }
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.out_h), (size_t)n * SRV_OUT_STRIDE, flags));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&small), 256, flags));
   memset(srv.ctl, 0, (size_t)n * sizeof(srv_slot_ctl));
@@ -83,8 +109,15 @@ int srv_init_locked()
   void *dp = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dp, srv.ctl, 0));
   a.ctl = static_cast<srv_slot_ctl *>(dp);
-  HIP_TRY(hipHostGetDevicePointer(&dp, srv.in_h, 0));
-  a.in_host = static_cast<const uint8_t *>(dp);
+  if (srv.over_bar) {
+    a.req = srv.req;
+    a.in_host = srv.in_h;
+  } else {
+    HIP_TRY(hipHostGetDevicePointer(&dp, srv.req, 0));
+    a.req = static_cast<const srv_req *>(dp);
+    HIP_TRY(hipHostGetDevicePointer(&dp, srv.in_h, 0));
+    a.in_host = static_cast<const uint8_t *>(dp);
+  }
   HIP_TRY(hipHostGetDevicePointer(&dp, srv.out_h, 0));
   a.out_host = static_cast<uint8_t *>(dp);
   HIP_TRY(hipHostGetDevicePointer(&dp, srv.state, 0));
@@ -102,7 +135,8 @@ int srv_init_locked()
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIP_TRY(hipStreamCreateWithPriority(&srv.stream, hipStreamNonBlocking, hi));
   if (getenv("NRLDPC_HIP_SRV_DEBUG"))
-    fprintf(stderr, "[libldpc_hip] server: %d slots, ctl %p in %p out %p state %p | staging %p (%zu B) gctl %p crc_pow %p %p %p %p\n", n,
+    fprintf(stderr, "[libldpc_hip] server: %d slots, requests %s, ctl %p in %p out %p state %p | staging %p (%zu B) gctl %p crc_pow %p %p %p %p\n", n,
+            srv.over_bar ? "pushed into device memory over the BAR" : "pulled from host memory",
             (void *)a.ctl, (const void *)a.in_host, (void *)a.out_host, (void *)a.state, (void *)a.staging, (size_t)n * SRV_IN_STRIDE,
             (void *)a.gctl, (const void *)a.crc_pow_tbl[0], (const void *)a.crc_pow_tbl[1], (const void *)a.crc_pow_tbl[2],
             (const void *)a.crc_pow_tbl[3]);
@@ -174,8 +208,9 @@ inline double srv_now()
 
 struct SrvCall {
   int slot;
-  uint8_t *in, *out;
+  uint8_t *in, *out; /* in: write-only for the host when it is device memory (reads over the BAR crawl) */
   srv_slot_ctl *ctl;
+  srv_req *req;
 };
 
 SrvCall srv_acquire()
@@ -191,22 +226,34 @@ SrvCall srv_acquire()
     if (spins > 64)
       sched_yield();
   }
-  return SrvCall{s, srv.in_h + (size_t)s * SRV_IN_STRIDE, srv.out_h + (size_t)s * SRV_OUT_STRIDE, srv.ctl + s};
+  return SrvCall{s, srv.in_h + (size_t)s * SRV_IN_STRIDE, srv.out_h + (size_t)s * SRV_OUT_STRIDE, srv.ctl + s, srv.req + s};
 }
 void srv_release(const SrvCall &c) { srv.slots[c.slot].busy.store(0, std::memory_order_release); }
 
-/* ring the doorbell for [header | payload_bytes] and wait for the completion word; returns n_iter via *n_iter */
-int srv_submit(const SrvCall &c, size_t payload_bytes, int32_t *n_iter)
+/* publish the request header `rq` (tags still unset) in the slot's ctl line and wait for the completion word; returns
+ * n_iter via *n_iter.  The payload must already be in the slot's input area. */
+int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
 {
   SrvSlotHost &h = srv.slots[c.slot];
-  h.seq = (h.seq + 1) & 0xfffffu;
+  h.seq = h.seq + 1 >= 0xfffffff0u ? 1u : h.seq + 1;
   h.calls++;
-  const uint32_t n16 = (uint32_t)((SRV_REQ_BYTES + payload_bytes + 15) / 16);
-  const uint32_t db = (h.seq << 12) | n16;
+  const uint32_t seq = h.seq;
   const double t_ring = srv_now();
-  __atomic_store_n(&c.ctl->doorbell, db, __ATOMIC_SEQ_CST); /* header and payload are ordered before it */
+  /* Fields first, then the four chunk tags (ldpc_server.h).  Host memory: x86 keeps the stores in order.  Device memory
+   * over the BAR is write-combining: the fence drains the payload and the fields before any tag goes out; the tags
+   * themselves may arrive in any order -- the poller waits for all four. */
+  volatile srv_req *q = c.req;
+  q->seg_in_stride = rq.seg_in_stride; q->seg_out_stride = rq.seg_out_stride; q->payload_bytes = rq.payload_bytes;
+  q->code_lo = rq.code_lo; q->code_hi = rq.code_hi; q->kb_nseg = rq.kb_nseg;
+  q->kind_mode = rq.kind_mode; q->max_pass = rq.max_pass; q->crcE = rq.crcE;
+  __builtin_ia32_sfence();
+  __atomic_store_n(&c.req->tag3, seq, __ATOMIC_RELEASE);
+  __atomic_store_n(&c.req->tag2, seq, __ATOMIC_RELEASE);
+  __atomic_store_n(&c.req->tag1, seq, __ATOMIC_RELEASE);
+  __atomic_store_n(&c.req->tag0, seq, __ATOMIC_RELEASE); /* (plain stores only: a locked instruction on BAR memory is a bus lock) */
+  __builtin_ia32_sfence(); /* push the line out now */
   for (uint32_t spins = 0;; spins++) {
-    if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == db)
+    if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == seq)
       break;
     if ((spins & 7) == 0 && srv_ensure_running() != 0)
       return -1;
@@ -218,10 +265,11 @@ int srv_submit(const SrvCall &c, size_t payload_bytes, int32_t *n_iter)
   h.host_wait_s += srv_now() - t_ring;
   if (n_iter)
     *n_iter = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
-  h.ticks_stage += (uint32_t)(c.ctl->t_staged - c.ctl->t_seen);
-  h.ticks_decode += (uint32_t)(c.ctl->t_decoded - c.ctl->t_staged);
-  h.ticks_prologue += (uint32_t)(c.ctl->t_prologue - c.ctl->t_staged);
-  h.ticks_passes += (uint32_t)(c.ctl->t_passes - c.ctl->t_prologue);
+  const uint32_t sd = c.ctl->t_stage_decode, pp = c.ctl->t_pro_passes;
+  h.ticks_stage += sd & 0xffffu;
+  h.ticks_decode += sd >> 16;
+  h.ticks_prologue += pp & 0xffffu;
+  h.ticks_passes += pp >> 16;
   return 0;
 }
 
@@ -240,22 +288,22 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   if (fill_dec_args(*p, ce, a) != 0)
     return -1;
   const int out_mode = a.out_mode, ob = out_bytes_of(hl, out_mode);
-  if (SRV_REQ_BYTES + (size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob > SRV_OUT_STRIDE)
+  if ((size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob > SRV_OUT_STRIDE)
     return 1;
   const double t_call = srv_now();
   const SrvCall c = srv_acquire();
-  srv_req *rq = reinterpret_cast<srv_req *>(c.in);
-  memset(rq, 0, sizeof(*rq));
-  rq->kind = kind;
-  rq->max_pass = (uint32_t)p->numMaxIter + 1u;
-  rq->use_crc = (uint32_t)a.use_crc;
-  rq->crcE = (uint32_t)a.E;
-  rq->crc_type = a.use_crc ? (uint32_t)p->crc_type : 0u;
-  rq->out_mode = (uint32_t)out_mode;
-  rq->code = reinterpret_cast<uint64_t>(ce->dev_lat);
-  memcpy(c.in + SRV_REQ_BYTES, llr, (size_t)hl.num_llr);
+  srv_req rq;
+  memset(&rq, 0, sizeof(rq));
+  rq.kind_mode = kind | ((uint32_t)out_mode << 8) | ((uint32_t)(a.use_crc != 0) << 16) | ((a.use_crc ? (uint32_t)p->crc_type : 0u) << 24);
+  rq.max_pass = (uint32_t)p->numMaxIter + 1u;
+  rq.crcE = (uint32_t)a.E;
+  const uint64_t code = reinterpret_cast<uint64_t>(ce->dev_lat);
+  rq.code_lo = (uint32_t)code;
+  rq.code_hi = (uint32_t)(code >> 32);
+  rq.payload_bytes = (uint32_t)hl.num_llr;
+  memcpy(c.in, llr, (size_t)hl.num_llr);
   int32_t n = 0;
-  const int rc = srv_submit(c, (size_t)hl.num_llr, &n);
+  const int rc = srv_submit(c, rq, &n);
   if (rc == 0) {
     *n_iter = n;
     if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
@@ -274,24 +322,26 @@ int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, u
   const int K = hc.kb_full * hc.Z, in_bytes = (K + 7) / 8, N = (hc.ncols - 2) * hc.Z;
   const size_t in_stride = align_up((size_t)in_bytes + 8, 16), out_stride = align_up((size_t)N, 16);
   const size_t lds = (size_t)4 * ((ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z, hc.nrows, hc.nedges) + 3) & ~3) * 8;
-  if (!ldpc_server_has_encoder() || n > 8 || SRV_REQ_BYTES + in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
+  if (!ldpc_server_has_encoder() || n > 8 || in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
     return 1;
   const SrvCall c = srv_acquire();
-  srv_req *rq = reinterpret_cast<srv_req *>(c.in);
-  memset(rq, 0, sizeof(*rq));
-  rq->kind = SRV_KIND_ENC;
-  rq->Kb = (uint32_t)Kb;
-  rq->n_seg = n;
-  rq->code = reinterpret_cast<uint64_t>(ce->dev);
-  rq->seg_in_stride = (uint32_t)in_stride;
-  rq->seg_out_stride = (uint32_t)out_stride;
+  srv_req rq;
+  memset(&rq, 0, sizeof(rq));
+  rq.kind_mode = SRV_KIND_ENC;
+  rq.kb_nseg = (uint32_t)Kb | (n << 16);
+  const uint64_t code = reinterpret_cast<uint64_t>(ce->dev);
+  rq.code_lo = (uint32_t)code;
+  rq.code_hi = (uint32_t)(code >> 32);
+  rq.seg_in_stride = (uint32_t)in_stride;
+  rq.seg_out_stride = (uint32_t)out_stride;
+  rq.payload_bytes = (uint32_t)(in_stride * n);
   for (unsigned j = 0; j < n; j++)
-    memcpy(c.in + SRV_REQ_BYTES + j * in_stride, input[first + j], (size_t)in_bytes);
+    memcpy(c.in + j * in_stride, input[first + j], (size_t)in_bytes);
   meter_stop(tinput); /* started by the caller */
   meter_start(tprep);
   meter_stop(tprep);
   meter_start(tparity);
-  const int rc = srv_submit(c, in_stride * n, nullptr);
+  const int rc = srv_submit(c, rq, nullptr);
   meter_stop(tparity);
   meter_start(toutput);
   if (rc == 0)

@@ -1,17 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r02; mkdir -p $O
 L=$GRAFT_REPO_ROOT/openairinterface5g_amd/lib/libldpc_hip.so
-run() { echo "=== $1 T=$2 N=$3 case=$4"; env $1 timeout 60 ./tests/abi_threads.bin $L $2 $3 $4 2>&1 | tail -${5:-3} | cut -c1-420; }
-{
-  for i in 1 2 3; do run "NRLDPC_HIP_SRV_SLOTS=4" 1 3000 1; done
-  run NRLDPC_HIP_SRV_DEBUG=1 1 3000 1 2
-  run NRLDPC_HIP_SRV_DEBUG=1 1 3000 0 2
-  run NRLDPC_HIP_SRV_DEBUG=1 1 3000 4 2
-  run NRLDPC_HIP_SRV_DEBUG=1 1 3000 6 2
-  for i in 1 2 3; do run X=1 32 600 ""; done
-  for i in 1 2; do run X=1 64 300 ""; done
-  run X=1 16 600 ""
-  run X=1 4 600 ""
-} > $O/dbg.txt 2>&1
-grep -c "Memory access fault" $O/dbg.txt
-cat $O/dbg.txt
+run() { echo "T=$1 case=${3:-mix}: $(timeout 120 ./tests/abi_threads.bin $L $1 $2 $3 2>&1 | tail -2 | cut -c1-230)"; }
+for i in 1 2 3 4 5 6; do run 8 6000; done
+for i in 1 2 3 4; do run 1 10000; done
+run 32 3000
+run 64 1500
+timeout 900 python -m pytest tests/test_gpu_decoder.py -m gpu -x -q -k "per_segment or concurrent or ldpctest" 2>&1 | tail -3
