@@ -275,7 +275,9 @@ def main():
         binding = {"name": "VALU issue (messages never leave LDS; HBM is idle 99 % of the time)"}
         if pmc.get("valu_wave_insts_per_launch"):
             n_simd = 256 * 4
-            avg_ns = pmc.get("valu_avg_ns_per_wave_inst_per_simd", 1.45)   # tools/ubench/valu_rate.hip, opcode mix of the kernel
+            # mean issue time per VALU instruction: derived by tools/valu_issue_model.py (disassembly opcode histogram x
+            # micro-benchmarked per-opcode rates), recorded with the counters by tools/make_traffic_json.py
+            avg_ns = pmc.get("valu_avg_ns_per_wave_inst_per_simd") or 1.43
             t_issue = pmc["valu_wave_insts_per_launch"] / n_simd * avg_ns * 1e-9
             binding.update({"valu_wave_insts_per_launch": pmc["valu_wave_insts_per_launch"],
                             "issue_time_at_measured_opcode_rates_ms": t_issue * 1e3, "frac": t_issue / kern_avg_s})
