@@ -482,3 +482,30 @@ def test_host_batches_sharded_over_logical_devices(hip, tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert not a["rx0_ack"].all() and a["rx1_ack"].sum() > a["rx0_ack"].sum()   # round 0 loses blocks, combining recovers them
+
+
+def test_abort_stops_the_siblings_of_a_failed_segment(hip):
+    """Transport-block-wide abort on the device (decoder.c:190-193, nr_ulsch_decoding.c:235-245: the first segment that
+    fails raises the flag, its siblings stop at their next pass).  60 lost transport blocks (26 segments each, pure noise,
+    numMaxIter = 20) next to 4 clean ones: verdicts, pass counts, payloads and soft buffers are the same with and without
+    the flag -- a lost TB reports numMaxIter + 1, NACK and a zeroed payload either way -- but with it the segments that
+    start after a sibling has failed leave at once, so the call is much shorter."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "abort_script.py"
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, NRLDPC_HIP_TB_ABORT=flag)
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+    on, off = res["1"], res["0"]
+    for r in (on, off):
+        assert r["ack"] == [0] * 60 + [1] * 4 and r["itm"][:60] == [21] * 60 and max(r["itm"][60:]) <= 3
+        assert r["clean_payload_ok"] and r["lost_payload_zero"]
+    assert on["harq"] == off["harq"]                # the soft buffers are written before the decoder runs
+    print(f"abort on {on['ms']:.3f} ms, off {off['ms']:.3f} ms")
+    assert on["ms"] < 0.75 * off["ms"], (on["ms"], off["ms"])
