@@ -440,6 +440,9 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
   a.E = 0;
   a.crc_pow = nullptr;
   a.jobs = nullptr;
+  a.tb_abort = nullptr;
+  a.pull = nullptr;
+  a.pull_stride = 0;
   for (int i = 0; i < 4; i++)
     a.crc_pow_tbl[i] = G().crc_pow[i];
   if (a.use_crc) {
@@ -616,6 +619,83 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
     chunk = (uint32_t)chunk_env;
   int lane = 0;
   c.chunks.clear();
+  /* Fast-kernel codes: the decoder's workgroups pull their rows over the link themselves (ldpc_dec_fast_pull_kernel) --
+   * from the caller's page-locked buffer in place, or from this thread's page-locked staging area, which the calling
+   * thread fills chunk by chunk while the previous chunks are being pulled and decoded -- and write bits and pass counts
+   * straight into page-locked memory.  No copy engine on the path.  NRLDPC_HIP_HOST_PULL=0: copy-engine path. */
+  static const int pull_env = [] { const char *e = getenv("NRLDPC_HIP_HOST_PULL"); return e ? atoi(e) : 1; }();
+  bool pull = pull_env != 0 && hc.f_ok && b->kernel != 1 && n_part >= 16;
+  const int8_t *pull_src = nullptr;
+  uint8_t *out_dev = nullptr;
+  if (pull) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, c.h_out, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      pull = false;
+    }
+    out_dev = static_cast<uint8_t *>(dp);
+    const void *hsrc = direct ? static_cast<const void *>(b->llr + (size_t)i0 * b->llr_stride) : static_cast<const void *>(c.h_in);
+    if (pull && (((reinterpret_cast<uintptr_t>(hsrc) | in_stride) & 3) != 0 ||
+                 hipHostGetDevicePointer(&dp, const_cast<void *>(hsrc), 0) != hipSuccess)) {
+      (void)hipGetLastError();
+      pull = false;
+    }
+    pull_src = static_cast<const int8_t *>(dp);
+  }
+  if (pull) {
+    if (chunk_env <= 0) /* page-locked source: whole rounds, two per launch; pageable: half rounds (the CPU copy sets the pace) */
+      chunk = (uint32_t)(G().n_cus * std::max(1, hc.f_wg_per_cu)) * (direct ? 2u : 1u) / (direct ? 1u : 2u);
+    const size_t stage_stride = align_up(hc.num_llr, 16);
+    for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {
+      const uint32_t n = std::min(chunk, n_part - k0);
+      hipStream_t s = lane ? c.stream2 : c.stream;
+      if (!direct) {
+        const int8_t *src = b->llr + (size_t)(i0 + k0) * b->llr_stride;
+        for (uint32_t i = 0; i < n; i++)
+          memcpy(c.h_in + (k0 + i) * in_stride, src + (size_t)i * b->llr_stride, hc.num_llr);
+      }
+      a.pull = pull_src + (size_t)k0 * in_stride; a.pull_stride = (uint32_t)in_stride;
+      a.llr = reinterpret_cast<const int8_t *>(c.d_in + k0 * stage_stride); a.llr_stride = (uint32_t)stage_stride;
+      static const int pull_out = [] { const char *e = getenv("NRLDPC_HIP_PULL_OUT"); return e ? atoi(e) : 1; }();
+      a.out = reinterpret_cast<int8_t *>((pull_out ? out_dev : c.d_out) + k0 * out_stride); a.out_stride = (uint32_t)out_stride;
+      a.n_iter = reinterpret_cast<int32_t *>((pull_out ? out_dev : c.d_out) + iter_off) + k0;
+      const bool lat = ce->use_latency(n_part, G().n_cus, b->kernel == 3 ? 1 : (b->kernel == 4 ? 2 : 0));
+      a.code = lat ? ce->dev_lat : ce->dev;
+      static const int pull_dbg = [] { const char *e = getenv("NRLDPC_HIP_PULL_DEBUG"); return e ? atoi(e) : 0; }();
+      static unsigned long long *dbg_d = nullptr;
+      if (pull_dbg) {
+        if (!dbg_d)
+          HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg_d), 5 * 8 * 65536));
+        a.tb_abort = reinterpret_cast<int *>(dbg_d + 3 * k0);
+      }
+      HIP_TRY(ldpc_launch_dec_fast_pull(a, lat ? ce->host_lat : ce->host, n, s));
+      if (pull_dbg && k0 + n >= n_part) {
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(5 * 65536);
+        HIP_TRY(hipMemcpy(h.data(), dbg_d, 8 * 5 * 65536, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (uint32_t i = 0; i < n_part; i++)
+          t0 = std::min(t0, h[3 * i]);
+        fprintf(stderr, "[pull] block start_us pull_us prologue_us passes_us output_us (100 MHz clock)\n");
+        for (uint32_t i = 0; i < n_part; i += (n_part > 32 ? n_part / 32 : 1)) {
+          const uint32_t s0 = (uint32_t)h[3 * 65536 + 2 * i], s1 = (uint32_t)h[3 * 65536 + 2 * i + 1];
+          fprintf(stderr, "[pull] %u %.1f %.1f %.1f %.1f %.1f\n", i, (h[3 * i] - t0) / 100.0, (h[3 * i + 1] - h[3 * i]) / 100.0,
+                  (uint32_t)(s0 - (uint32_t)h[3 * i + 1]) / 100.0, (uint32_t)(s1 - s0) / 100.0, (uint32_t)((uint32_t)h[3 * i + 2] - s1) / 100.0);
+        }
+      }
+      if (!pull_out) {
+        HIP_TRY(hipMemcpyAsync(c.h_out + k0 * out_stride, c.d_out + k0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * k0, c.d_out + iter_off + sizeof(int32_t) * k0,
+                               sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+      }
+      hipEvent_t ev;
+      if (c.event(c.chunks.size(), &ev) != 0)
+        return -1;
+      HIP_TRY(hipEventRecord(ev, s));
+      c.chunks.push_back(ThreadCtx::Chunk{k0, n});
+    }
+    return 0;
+  }
   for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {
     const uint32_t n = std::min(chunk, n_part - k0);
     hipStream_t s = lane ? c.stream2 : c.stream;

@@ -58,10 +58,82 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
     a.n_iter[job ? (uint32_t)job->iter_idx : blockIdx.x] = n_iter;
 }
 
+/* Host-buffer batches: the block's LLRs sit in page-locked host memory.  The workgroup pulls its row over the link into
+ * its row of the device staging buffer (16-byte loads, all of a 1024-thread workgroup's 26 KB in flight at once) and then
+ * runs the ordinary block body on that copy, which stays L2-resident for the per-pass re-reads.  With a launch's
+ * workgroups at different points of their life (pulling / decoding) the link and the CUs are busy at the same time, with
+ * no copy-engine -> kernel dependency anywhere (measured: a chunked hipMemcpyAsync pipeline loses ~40 us per such edge;
+ * profiles/r02/README.md). */
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const int nb = code->num_llr, tid = (int)threadIdx.x, nt = (int)blockDim.x; /* Zc % 4 == 0: a multiple of 4 bytes */
+  unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.tb_abort); /* diagnostics (NRLDPC_HIP_PULL_DEBUG): 3 clocks per block */
+  if (dbg && threadIdx.x == 0)
+    dbg[3 * blockIdx.x] = wall_clock64();
+  const uint8_t *src = reinterpret_cast<const uint8_t *>(a.pull) + (size_t)blockIdx.x * a.pull_stride;
+  uint8_t *dst = reinterpret_cast<uint8_t *>(const_cast<int8_t *>(a.llr)) + (size_t)blockIdx.x * a.llr_stride;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    const int n16 = nb >> 4;
+    for (int i = tid; i < n16; i += 4 * nt) { /* four loads in flight per thread; out-of-range ones re-read the last unit */
+      const int last = n16 - 1;
+      const int i1 = i + nt, i2 = i + 2 * nt, i3 = i + 3 * nt;
+      const uint4 v0 = s16[i], v1 = s16[i1 < last ? i1 : last], v2 = s16[i2 < last ? i2 : last], v3 = s16[i3 < last ? i3 : last];
+      d16[i] = v0;
+      if (i1 < n16) d16[i1] = v1;
+      if (i2 < n16) d16[i2] = v2;
+      if (i3 < n16) d16[i3] = v3;
+    }
+    const int rest = (nb & 15) >> 2;
+    if (tid < rest)
+      reinterpret_cast<uint32_t *>(dst)[4 * n16 + tid] = reinterpret_cast<const uint32_t *>(src)[4 * n16 + tid];
+  } else {
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+    const int n4 = nb >> 2;
+    for (int i = tid; i < n4; i += 4 * nt) {
+      const int last = n4 - 1;
+      const int i1 = i + nt, i2 = i + 2 * nt, i3 = i + 3 * nt;
+      const uint32_t v0 = s4[i], v1 = s4[i1 < last ? i1 : last], v2 = s4[i2 < last ? i2 : last], v3 = s4[i3 < last ? i3 : last];
+      d4[i] = v0;
+      if (i1 < n4) d4[i1] = v1;
+      if (i2 < n4) d4[i2] = v2;
+      if (i3 < n4) d4[i3] = v3;
+    }
+  }
+  /* The row is read back by other waves of this workgroup only: workgroup scope is enough (the CU's vector cache is
+   * write-through and shared by the workgroup's waves).  An agent-scope fence here writes back and invalidates the
+   * XCD's whole L2 -- per workgroup: measured 89 us of L2 misses in the prologue that follows. */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (dbg && threadIdx.x == 0)
+    dbg[3 * blockIdx.x + 1] = wall_clock64();
+  uint32_t *st = reinterpret_cast<uint32_t *>(fsm + code->f_lds_misc + 40); /* behind the block body's flags */
+  struct pull_io : ldpc_batch_io<false> {
+    uint32_t *st_;
+    __device__ __forceinline__ uint32_t *stamps() const { return st_; }
+  };
+  const pull_io io{{a, (ldpc_job_ptr_t) nullptr}, dbg ? st : nullptr};
+  const int n_iter = ldpc_dec_fast_block(fsm, code, io);
+  if (threadIdx.x == 0) {
+    a.n_iter[blockIdx.x] = n_iter;
+    if (dbg) {
+      dbg[3 * blockIdx.x + 2] = wall_clock64();
+      dbg[3 * 65536 + 2 * blockIdx.x] = st[0];
+      dbg[3 * 65536 + 2 * blockIdx.x + 1] = st[1];
+    }
+  }
+}
+
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[2] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>)};
-  for (int i = 0; i < 2; i++) {
+  const void *k[3] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel)};
+  for (int i = 0; i < 3; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -76,6 +148,16 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
   hipLaunchKernelGGL((ldpc_dec_fast_kernel<false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  if (a.jobs || !a.pull)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ldpc_dec_fast_pull_kernel, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 

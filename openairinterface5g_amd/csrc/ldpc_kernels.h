@@ -43,6 +43,10 @@ struct ldpc_dec_args {
   const ldpc_dec_job *jobs; /* NULL: homogeneous batch addressed by strides */
   const uint32_t *crc_pow_tbl[4]; /* per crc_type, used with jobs */
   int *tb_abort;            /* with jobs: per transport block "a segment failed" flags (zero on entry), or NULL */
+  /* host-buffer batches (ldpc_launch_dec_fast_pull): the workgroup first fetches its row from `pull` -- page-locked host
+   * memory, device-mapped address -- into its row of `llr` (device memory, written here), then decodes from there */
+  const int8_t *pull;
+  uint32_t pull_stride;
 };
 
 struct ldpc_enc_args {
@@ -68,6 +72,9 @@ hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_b
 hipError_t ldpc_fast_kernel_init(void);
 hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                 hipStream_t stream);
+/* the same with a.pull set: every workgroup pulls its LLR row over the link itself (no copy engine, no staging copy) */
+hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
+                                     hipStream_t stream);
 /* encoder: one workgroup per code block; workgroup size and dynamic LDS of the selected encoder kernel for a code */
 int ldpc_enc_is_packed(void); /* 1: bit-packed kernel selected (default), 0: NRLDPC_HIP_ENC_KERNEL=bytes */
 void ldpc_enc_launch_shape(const ldpc_code_desc_t &host_code, int *n_threads, int *lds_bytes);
