@@ -306,6 +306,7 @@ struct ThreadCtx {
   /* chunks of the host-buffer decode in flight: [first block, blocks) and the event behind the chunk's last copy */
   struct Chunk { uint32_t k0, n; };
   std::vector<Chunk> chunks;
+  bool out_direct = false, iter_direct = false; /* the kernels of the call in flight write the caller's arrays themselves */
   std::vector<hipEvent_t> events;
   int event(size_t i, hipEvent_t *e)
   {
@@ -626,14 +627,17 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
   static const int pull_env = [] { const char *e = getenv("NRLDPC_HIP_HOST_PULL"); return e ? atoi(e) : 1; }();
   bool pull = pull_env != 0 && hc.f_ok && b->kernel != 1 && n_part >= 16;
   const int8_t *pull_src = nullptr;
-  uint8_t *out_dev = nullptr;
+  uint8_t *stage_out = nullptr;
+  c.out_direct = c.iter_direct = false;
+  int8_t *out_dev = nullptr;
+  int32_t *iter_dev = nullptr;
   if (pull) {
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, c.h_out, 0) != hipSuccess) {
       (void)hipGetLastError();
       pull = false;
     }
-    out_dev = static_cast<uint8_t *>(dp);
+    stage_out = static_cast<uint8_t *>(dp);
     const void *hsrc = direct ? static_cast<const void *>(b->llr + (size_t)i0 * b->llr_stride) : static_cast<const void *>(c.h_in);
     if (pull && (((reinterpret_cast<uintptr_t>(hsrc) | in_stride) & 3) != 0 ||
                  hipHostGetDevicePointer(&dp, const_cast<void *>(hsrc), 0) != hipSuccess)) {
@@ -643,8 +647,26 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
     pull_src = static_cast<const int8_t *>(dp);
   }
   if (pull) {
-    if (chunk_env <= 0) /* page-locked source: whole rounds, two per launch; pageable: half rounds (the CPU copy sets the pace) */
-      chunk = (uint32_t)(G().n_cus * std::max(1, hc.f_wg_per_cu)) * (direct ? 2u : 1u) / (direct ? 1u : 2u);
+    /* results: straight into the caller's arrays when those are page-locked too (nothing left to hand over but the
+     * event), otherwise into this thread's page-locked staging rows, copied out chunk by chunk in dec_host_finish */
+    void *dp = nullptr;
+    int8_t *out0 = b->out + (size_t)i0 * b->out_stride;
+    if (((reinterpret_cast<uintptr_t>(out0) | b->out_stride) & 3) == 0 && host_ptr_is_pinned(out0) &&
+        hipHostGetDevicePointer(&dp, out0, 0) == hipSuccess) {
+      c.out_direct = true;
+      out_dev = static_cast<int8_t *>(dp);
+    }
+    if (host_ptr_is_pinned(b->n_iter + i0) && hipHostGetDevicePointer(&dp, b->n_iter + i0, 0) == hipSuccess) {
+      c.iter_direct = true;
+      iter_dev = static_cast<int32_t *>(dp);
+    }
+    (void)hipGetLastError();
+    if (chunk_env <= 0) {
+      /* page-locked source: two workgroup rounds per launch when results are handed over by this thread (the copy-out of
+       * one chunk overlaps the next chunk's kernel), one launch otherwise; pageable: one round per launch, the CPU copy sets the pace */
+      const uint32_t round = (uint32_t)(G().n_cus * std::max(1, hc.f_wg_per_cu));
+      chunk = direct ? (c.out_direct ? n_part : 2 * round) : round;
+    }
     const size_t stage_stride = align_up(hc.num_llr, 16);
     for (uint32_t k0 = 0; k0 < n_part; k0 += chunk, lane ^= 1) {
       const uint32_t n = std::min(chunk, n_part - k0);
@@ -656,38 +678,15 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
       }
       a.pull = pull_src + (size_t)k0 * in_stride; a.pull_stride = (uint32_t)in_stride;
       a.llr = reinterpret_cast<const int8_t *>(c.d_in + k0 * stage_stride); a.llr_stride = (uint32_t)stage_stride;
-      static const int pull_out = [] { const char *e = getenv("NRLDPC_HIP_PULL_OUT"); return e ? atoi(e) : 1; }();
-      a.out = reinterpret_cast<int8_t *>((pull_out ? out_dev : c.d_out) + k0 * out_stride); a.out_stride = (uint32_t)out_stride;
-      a.n_iter = reinterpret_cast<int32_t *>((pull_out ? out_dev : c.d_out) + iter_off) + k0;
+      if (c.out_direct) {
+        a.out = out_dev + (size_t)k0 * b->out_stride; a.out_stride = b->out_stride;
+      } else {
+        a.out = reinterpret_cast<int8_t *>(stage_out + k0 * out_stride); a.out_stride = (uint32_t)out_stride;
+      }
+      a.n_iter = c.iter_direct ? iter_dev + k0 : reinterpret_cast<int32_t *>(stage_out + iter_off) + k0;
       const bool lat = ce->use_latency(n_part, G().n_cus, b->kernel == 3 ? 1 : (b->kernel == 4 ? 2 : 0));
       a.code = lat ? ce->dev_lat : ce->dev;
-      static const int pull_dbg = [] { const char *e = getenv("NRLDPC_HIP_PULL_DEBUG"); return e ? atoi(e) : 0; }();
-      static unsigned long long *dbg_d = nullptr;
-      if (pull_dbg) {
-        if (!dbg_d)
-          HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg_d), 5 * 8 * 65536));
-        a.tb_abort = reinterpret_cast<int *>(dbg_d + 3 * k0);
-      }
       HIP_TRY(ldpc_launch_dec_fast_pull(a, lat ? ce->host_lat : ce->host, n, s));
-      if (pull_dbg && k0 + n >= n_part) {
-        HIP_TRY(hipDeviceSynchronize());
-        std::vector<unsigned long long> h(5 * 65536);
-        HIP_TRY(hipMemcpy(h.data(), dbg_d, 8 * 5 * 65536, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (uint32_t i = 0; i < n_part; i++)
-          t0 = std::min(t0, h[3 * i]);
-        fprintf(stderr, "[pull] block start_us pull_us prologue_us passes_us output_us (100 MHz clock)\n");
-        for (uint32_t i = 0; i < n_part; i += (n_part > 32 ? n_part / 32 : 1)) {
-          const uint32_t s0 = (uint32_t)h[3 * 65536 + 2 * i], s1 = (uint32_t)h[3 * 65536 + 2 * i + 1];
-          fprintf(stderr, "[pull] %u %.1f %.1f %.1f %.1f %.1f\n", i, (h[3 * i] - t0) / 100.0, (h[3 * i + 1] - h[3 * i]) / 100.0,
-                  (uint32_t)(s0 - (uint32_t)h[3 * i + 1]) / 100.0, (uint32_t)(s1 - s0) / 100.0, (uint32_t)((uint32_t)h[3 * i + 2] - s1) / 100.0);
-        }
-      }
-      if (!pull_out) {
-        HIP_TRY(hipMemcpyAsync(c.h_out + k0 * out_stride, c.d_out + k0 * out_stride, out_stride * n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(c.h_out + iter_off + sizeof(int32_t) * k0, c.d_out + iter_off + sizeof(int32_t) * k0,
-                               sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-      }
       hipEvent_t ev;
       if (c.event(c.chunks.size(), &ev) != 0)
         return -1;
@@ -743,14 +742,17 @@ int dec_host_finish(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_par
   /* chunk by chunk: a chunk's results are handed over while the later chunks are still on the link / in the decoder */
   for (size_t q = 0; q < c.chunks.size(); q++) {
     HIP_TRY(hipEventSynchronize(c.events[q]));
+    if (c.out_direct && c.iter_direct)
+      continue;
     for (uint32_t i = c.chunks[q].k0; i < c.chunks[q].k0 + c.chunks[q].n; i++) {
-      const int32_t n = h_iter[i];
+      const int32_t n = c.iter_direct ? b->n_iter[i0 + i] : h_iter[i];
       b->n_iter[i0 + i] = n;
-      if (!use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+      if (!c.out_direct && (!use_crc || n >= 3)) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
         memcpy(b->out + (size_t)(i0 + i) * b->out_stride, c.h_out + i * out_stride, ob);
     }
   }
   c.chunks.clear();
+  c.out_direct = c.iter_direct = false;
   return 0;
 }
 

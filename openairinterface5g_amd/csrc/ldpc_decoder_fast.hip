@@ -69,9 +69,6 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
   const int nb = code->num_llr, tid = (int)threadIdx.x, nt = (int)blockDim.x; /* Zc % 4 == 0: a multiple of 4 bytes */
-  unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.tb_abort); /* diagnostics (NRLDPC_HIP_PULL_DEBUG): 3 clocks per block */
-  if (dbg && threadIdx.x == 0)
-    dbg[3 * blockIdx.x] = wall_clock64();
   const uint8_t *src = reinterpret_cast<const uint8_t *>(a.pull) + (size_t)blockIdx.x * a.pull_stride;
   uint8_t *dst = reinterpret_cast<uint8_t *>(const_cast<int8_t *>(a.llr)) + (size_t)blockIdx.x * a.llr_stride;
   if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
@@ -106,27 +103,15 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
   }
   /* The row is read back by other waves of this workgroup only: workgroup scope is enough (the CU's vector cache is
    * write-through and shared by the workgroup's waves).  An agent-scope fence here writes back and invalidates the
-   * XCD's whole L2 -- per workgroup: measured 89 us of L2 misses in the prologue that follows. */
+   * XCD's whole L2 -- per workgroup: measured 89 us of L2 misses in the prologue that follows
+   * (profiles/r02/host_pull_timeline_*.txt). */
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (dbg && threadIdx.x == 0)
-    dbg[3 * blockIdx.x + 1] = wall_clock64();
-  uint32_t *st = reinterpret_cast<uint32_t *>(fsm + code->f_lds_misc + 40); /* behind the block body's flags */
-  struct pull_io : ldpc_batch_io<false> {
-    uint32_t *st_;
-    __device__ __forceinline__ uint32_t *stamps() const { return st_; }
-  };
-  const pull_io io{{a, (ldpc_job_ptr_t) nullptr}, dbg ? st : nullptr};
+  const ldpc_batch_io<false> io{a, (ldpc_job_ptr_t) nullptr};
   const int n_iter = ldpc_dec_fast_block(fsm, code, io);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0)
     a.n_iter[blockIdx.x] = n_iter;
-    if (dbg) {
-      dbg[3 * blockIdx.x + 2] = wall_clock64();
-      dbg[3 * 65536 + 2 * blockIdx.x] = st[0];
-      dbg[3 * 65536 + 2 * blockIdx.x + 1] = st[1];
-    }
-  }
 }
 
 hipError_t ldpc_fast_kernel_init(void)

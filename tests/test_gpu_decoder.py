@@ -225,6 +225,44 @@ def test_full_size_batch_properties_device(hip):
     assert int(out0[torch.from_numpy(ok0).cuda()][:, :K // 8].max()) == 0
 
 
+@pytest.mark.parametrize("cfg", [(1, 384, 13), (1, 96, 23), (2, 208, 15), (2, 64, 13), (1, 32, 89), (2, 16, 23)])
+def test_host_buffer_paths(hip, cfg):
+    """LDPCdecoder_batch with mem = HOST: the decoder's workgroups pull their LLR rows over the link themselves -- from the
+    caller's page-locked array in place (row pitches that are and are not multiples of 16 bytes) or from the library's
+    staging area (pageable caller) -- and write bits / pass counts into the caller's arrays when those are page-locked,
+    into staging rows otherwise; every combination equals the oracle, in parity-check and in CRC mode (where p_out of a
+    block that stopped before pass 3 must stay untouched, decoder.c:849-861)."""
+    import torch
+    BG, Z, R = cfg
+    rng = np.random.default_rng(1000 * BG + Z + R)
+    n, K = 40, kbits(BG, Z)
+    row = hip.ldpc.num_llr(BG, Z, R)
+    ob = hip.ldpc.out_bytes(BG, Z, R, 0)
+    infos = []
+    for i in range(n):
+        info = random_info(rng, BG, Z)
+        crc = O.crc("crc24b", info, K - 24) >> 8
+        info[K // 8 - 3:K // 8] = [(crc >> 16) & 255, (crc >> 8) & 255, crc & 255]
+        infos.append(info)
+    llrs = [make_llr(rng, BG, Z, R, float(rng.choice([-3.0, 0.5, 2.0, 6.0])), infos[i]) for i in range(n - 1)] + [np.zeros(row, np.int8)]
+    for use_crc in (False, True):
+        refs = [O.decode(BG, Z, R, llrs[i], 6, 0, use_crc, K if use_crc else 0, 1, out_init=0x5a) for i in range(n)]
+        for pitch in (row, row + 4, (row + 15) // 16 * 16 + 16):
+            for llr_pinned in (True, False):
+                for out_pinned in (True, False):
+                    src = torch.zeros((n, pitch), dtype=torch.int8, pin_memory=llr_pinned).numpy()
+                    src[:, :row] = np.stack(llrs)
+                    if pitch > row:
+                        src[:, row:] = 99                       # never read
+                    dst = torch.full((n, (ob + 3) // 4 * 4 + 8), 0x5a, dtype=torch.uint8, pin_memory=out_pinned).numpy()
+                    it, out = hip.decode_batch_host(BG, Z, R, src, numMaxIter=6, check_crc=use_crc, E=K if use_crc else 0,
+                                                    crc_type=1, out=dst)
+                    for i in range(n):
+                        assert refs[i][0] == it[i], (cfg, use_crc, pitch, llr_pinned, out_pinned, i, refs[i][0], int(it[i]))
+                        assert np.array_equal(refs[i][1], out[i]), (cfg, use_crc, pitch, llr_pinned, out_pinned, i)
+                    assert (dst[:, (ob + 3) // 4 * 4:] == 0x5a).all()
+
+
 def test_config3_mixed_bg2_batch_every_block(hip):
     """BASELINE configs[2] at full size: 256 blocks each of BG2 Zc=64 R=1/5, Zc=64 R=1/3, Zc=208 R=1/5, Zc=208 R=1/3
     (short URLLC-style blocks), in the waterfall so that pass counts spread from 2 to 9: every block's bits and pass

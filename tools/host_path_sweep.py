@@ -20,11 +20,14 @@ llr[:, 2 * Z:] = torch.clamp(torch.floor(y / (sigma / 16.0)), -128, 127).to(torc
 pin = torch.empty(llr.shape, dtype=torch.int8, pin_memory=True); pin.copy_(llr); pinn = pin.numpy()
 page = llr.cpu().numpy().copy()
 out = np.zeros((n, 3264), np.uint8)
-for name, src in (("pinned", pinn), ("pageable", page)):
+out_pin = torch.zeros((n, 3264), dtype=torch.uint8, pin_memory=True).numpy()
+ref_it, ref_out = pkg.decode_batch_host(BG, Z, R, page, numMaxIter=8)
+for name, src, dst in (("pinned LLRs, pinned out", pinn, out_pin), ("pinned", pinn, out), ("pageable", page, out)):
     for _ in range(3):
-        pkg.decode_batch_host(BG, Z, R, src, numMaxIter=8, out=out)
+        it, o = pkg.decode_batch_host(BG, Z, R, src, numMaxIter=8, out=dst)
+    assert np.array_equal(it, ref_it) and np.array_equal(o, ref_out), name
     ts = []
     for _ in range(15):
-        t0 = time.perf_counter(); pkg.decode_batch_host(BG, Z, R, src, numMaxIter=8, out=out); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); pkg.decode_batch_host(BG, Z, R, src, numMaxIter=8, out=dst); ts.append(time.perf_counter() - t0)
     ts.sort()
     print(f"chunk={os.environ.get('NRLDPC_HIP_HOST_CHUNK','default')} {name}: median {ts[7]*1e3:.3f} ms min {ts[0]*1e3:.3f} ms -> {n*66*Z/ts[7]/1e9:.1f} Gb/s coded")
