@@ -31,6 +31,14 @@
  *   int *tb_abort()           optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559)
  *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics)
  *   int tid()                 threadIdx.x
+ *   uint32_t ld_llr(p)        one dword of src32_prologue()'s row: a plain load, or one that bypasses the caches when the
+ *                             row was written by the host while this kernel was running (resident server)
+ *   uint32_t out_tag()        0: the output row is written as it is.  Otherwise (resident server): the row goes out in
+ *                             16-byte units {three output dwords, tag}, one store each, so that the host can tell unit by
+ *                             unit that it has arrived and no fence or completion ordering is needed; put16(p, a, b, c,
+ *                             tag) is that store (it must leave the caches by itself)
+ *   bool tables_resident()    the code's tables are still in this workgroup's LDS from the previous block (resident
+ *                             server, same code as last time): the prologue does not copy them again
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
  *                             check-node phase when the block has converged); same results, same pass counts */
@@ -87,28 +95,32 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int ia = tid + k * nt;
-      va[k] = ia < n_app ? srcp[ia] : 0u;
-      ve[k] = ia < n_ext ? srcp[n_app + ia] : 0u;
+      va[k] = ia < n_app ? io.ld_llr(srcp + ia) : 0u;
+      ve[k] = ia < n_ext ? io.ld_llr(srcp + n_app + ia) : 0u;
     }
   }
-  for (int i = tid; i < nedges; i += nt)
-    etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
-  for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
-    ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
-  for (int i = tid; i < code->nrows; i += nt)
-    rowtbl[i] = code->f_rowtbl[i];
-  for (int i = tid; i < ncore; i += nt)
-    coltbl[i] = code->f_coltbl[i];
+  const bool have_tables = io.tables_resident();
+  if (!have_tables) {
+    for (int i = tid; i < nedges; i += nt)
+      etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
+    for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
+      ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
+    for (int i = tid; i < code->nrows; i += nt)
+      rowtbl[i] = code->f_rowtbl[i];
+    for (int i = tid; i < ncore; i += nt)
+      coltbl[i] = code->f_coltbl[i];
+  }
   if (stage) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int ia = tid + k * nt;
-      va[k] = ia < n_app ? srcp[ia] : 0u;
-      ve[k] = ia < n_ext ? srcp[n_app + ia] : 0u;
+      va[k] = ia < n_app ? io.ld_llr(srcp + ia) : 0u;
+      ve[k] = ia < n_ext ? io.ld_llr(srcp + n_app + ia) : 0u;
     }
   }
-  for (int i = tid; i < (Z + 4) >> 2; i += nt)
-    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
+  if (!have_tables)
+    for (int i = tid; i < (Z + 4) >> 2; i += nt)
+      reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   if (tid < 8)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen,
                        [4], [5] task queues of the two phases */
@@ -137,7 +149,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   }
   for (int i = tid + 4 * nt; i < n_app; i += nt) { /* small workgroups: the rest */
     const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
-    const uint32_t v = srcp[i], w = v ^ 0x80808080u;
+    const uint32_t v = io.ld_llr(srcp + i), w = v ^ 0x80808080u;
     uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride) + j;
     dst[0] = w;
     dst[zq] = w;
@@ -145,7 +157,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       stage[i] = v;
   }
   for (int i = tid + 4 * nt; i < n_ext; i += nt)
-    e32[i] = srcp[n_app + i] ^ 0x80808080u;
+    e32[i] = io.ld_llr(srcp + n_app + i) ^ 0x80808080u;
   __syncthreads();
   if (io.stamps() && tid == 0)
     io.stamps()[0] = (uint32_t)wall_clock64();
@@ -173,7 +185,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         const int gi = item - gstart;
         const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
         const uint32_t rowrec = rowtbl[srow0 + rig];
-        const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
+        const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
         const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         syn |= m & mask;
@@ -199,9 +211,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       n_iter = max_pass + 1;
       break;
     }
-    if (stage && p == 1)
-      __threadfence(); /* the core columns' device copy (written in the prologue, long since arrived) is read from here on:
-                          drop what L1 may hold of the slot's previous request (the workgroup barrier above orders it) */
+    /* (the core columns' device copy, written in the prologue by this workgroup's own waves, is read from here on: the
+     * barriers since then order it at workgroup scope, which is all a CU's write-through vector cache needs; an agent-
+     * scope fence here would write back and invalidate the XCD's L2) */
     const int bad_prev = flags[p & 1]; /* unsatisfied lanes after pass p - 1 (after the channel's hard decisions for p = 1) */
     if (!io.use_crc() && p >= 3 && flags[p & 1] == 0) {
       n_iter = p - 1;
@@ -234,33 +246,27 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
        * p + 1 <= max_pass as there), as a sweep of its own over the same task list -- when the previous pass was already
        * close (few unsatisfied lanes): a block that is far from converging does not pay for sweeps that cannot succeed,
        * and a missed chance only means the stop is noticed one check-node phase later, with the same pass count */
+      /* items are walked by index, not by task: row record (degree, first edge) per lane from the LDS table, no queue and
+       * no task records from the descriptor -- the sweep is a few loads per edge, and the fetch chain in front of every
+       * task was most of its time (6 us -> 2 us for BG1 Zc = 384) */
       uint32_t esyn = 0;
-      for (;;) {
-        const int task = ldpc_draw(&flags[4], lane);
-        if (task >= n_cn_tasks)
-          break;
-        const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
-        const int item = code->f_cn_task[task][2] + lane;
-        const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
-        if (item < gend) {
-          const int gi = item - gstart;
-          const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
-          const uint32_t rowrec = rowtbl[srow0 + rig];
-          const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j;
-          const uint32_t m = ldpc_fast_pc(L, deg, ext, e0, j, rstride);
-          const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-          esyn |= m & mask;
-        }
+      const int n_items = code->nrows * zq;
+      for (int item = tid; item < n_items; item += nt) {
+        const int sr = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sr * zq;
+        const uint32_t rowrec = rowtbl[sr];
+        const int e0 = (int)(rowrec & 0x1ffu), deg = (int)((rowrec >> 9) & 0x1fu), ext = (int)((rowrec >> 14) & 1u);
+        const int valid = (int)(rowrec >> 16) - 4 * j;
+        const uint32_t m = ldpc_fast_pc(L, deg, ext, e0, j, rstride);
+        const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+        esyn |= m & mask;
       }
       if (__any(esyn != 0) && lane == 0)
         flags[6] = 1;
       __syncthreads();
       const int bad = flags[6];
       __syncthreads();
-      if (tid == 0) {
+      if (tid == 0)
         flags[6] = 0;
-        flags[4] = 0;
-      }
       if (!bad) {
         n_iter = p;
         break;
@@ -303,23 +309,46 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
 
   /* ---- hard decision ------------------------------------------------------------------------------------- */
   if ((!io.use_crc() || n_iter >= 3) && n_iter <= max_pass) {
-    if (io.out_mode() == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(io.out());
-      const int nwords = (num_llr + 31) >> 5;
-      for (int w = tid; w < nwords; w += nt) {
-        uint32_t word = 0;
+    /* output dword w: packed bits 32w .. 32w+31 MSB first (bnProc.h:1353-1380), resp. bits 4w .. 4w+3 one per byte */
+    auto bits_word = [&](int w) -> uint32_t {
+      uint32_t word = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
-          if (b < ncz) {
-            const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
-            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
-            const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
-            word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
-          }
+      for (int q = 0; q < 8; q++) {
+        const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
+        if (b < ncz) {
+          const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+          const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+          const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+          word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
         }
-        o[w] = word;
       }
+      return word;
+    };
+    auto bytes_word = [&](int w) -> uint32_t {
+      const int b = 4 * w;
+      if (b >= ncz)
+        return 0u;
+      const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+      const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+      return (nb >> 7) & 0x01010101u;
+    };
+    const uint32_t tag = io.out_tag();
+    const int nwords = io.out_mode() == 0 ? (num_llr + 31) >> 5 : num_llr >> 2;
+    if (tag) {
+      uint4 *o16 = reinterpret_cast<uint4 *>(io.out());
+      for (int c = tid; 3 * c < nwords; c += nt) {
+        uint32_t w3[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int w = 3 * c + q;
+          w3[q] = w < nwords ? (io.out_mode() == 0 ? bits_word(w) : bytes_word(w)) : 0u;
+        }
+        io.put16(o16 + c, w3[0], w3[1], w3[2], tag);
+      }
+    } else if (io.out_mode() == 0) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(io.out());
+      for (int w = tid; w < nwords; w += nt)
+        o[w] = bits_word(w);
     } else {
       int8_t *o = io.out();
       for (int i = tid; i < num_llr; i += nt)

@@ -59,7 +59,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   }
   qsort(rows, d->nrows, sizeof(rows[0]), by_key_desc);
   for (int i = 0; i < d->nrows; i++)
-    d->f_rowtbl[i] = (uint32_t)d->row_ptr[rows[i].id] | ((uint32_t)d->pc_lo[rows[i].id] << 16);
+    d->f_rowtbl[i] = (uint32_t)d->row_ptr[rows[i].id] | ((uint32_t)rows[i].key << 9) | ((uint32_t)(rows[i].id >= 4) << 14) |
+                     ((uint32_t)d->pc_lo[rows[i].id] << 16);
   /* CN tasks: one degree group after the other, 64 items per task */
   int nt = 0, item = 0, cost[LDPC_F_MAX_CN_TASKS];
   for (int i = 0; i < d->nrows;) {

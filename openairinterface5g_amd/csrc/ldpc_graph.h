@@ -92,7 +92,7 @@ typedef struct ldpc_code_desc {
   /* BN task: {first item, end item (all columns), loop bound = degree of the first item's column} */
   int32_t f_bn_task[LDPC_F_MAX_BN_TASKS][3];
   /* tables the kernel copies into LDS (read per lane): */
-  uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge | pc_lo << 16 */
+  uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge (9 bits) | degree << 9 | has extension column << 14 | pc_lo << 16 */
   uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;
                                             extension column: f_lds_ext + (col-ncore)*Z, or col*Z = byte offset in the
                                             block's LLR input when f_ext_global */

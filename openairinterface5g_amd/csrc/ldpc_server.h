@@ -19,8 +19,10 @@
  *                 whichever way the link splits the GPU's 64-byte read, a chunk whose tag shows the new number is
  *                 complete -- the poll that sees four equal new tags HAS the header (no second trip for it);
  *                 slot input area: the payload (LLRs / segment bytes), read by the decoder straight from host memory
- *   GPU -> host   slot output area (bits / coded bytes), n_iter and timing stamps in ctl line 1, then -- behind a
- *                 system-scope fence of every thread and a barrier -- done = sequence number served
+ *   GPU -> host   fast decoder: the slot's output area in 16-byte units {three output dwords, sequence number} and the
+ *                 completion line {sequence number, n_iter, two timing words} as one 16-byte store: every unit proves
+ *                 its own arrival, nothing is fenced or ordered.  Other kinds: plain output bytes, n_iter and stamps,
+ *                 then -- behind a system-scope fence of every thread and a barrier -- done = sequence number served
  *
  * Lifetime: the kernel exits by itself when no slot has seen a request for `idle_ticks` (so a process that stops
  * calling -- or calls hipDeviceSynchronize -- is never stuck behind it) or when the host raises *host_stop.  The
@@ -35,7 +37,7 @@
 
 #define SRV_MAX_SLOTS 128
 #define SRV_IN_STRIDE (28u * 1024u)                /* up to 68*384 LLRs, or 8 segments of 1056 B */
-#define SRV_OUT_STRIDE (200u * 1024u)              /* 8 segments x 66*384 coded bytes; decoder: <= 68*384 */
+#define SRV_OUT_STRIDE (200u * 1024u)              /* 8 segments x 66*384 coded bytes; decoder: <= 68*384 bytes x 4/3 (tagged units) */
 #define SRV_LDS_BYTES (160 * 1024)
 #define SRV_BC_OFF (SRV_LDS_BYTES - 256)           /* broadcast area at the end of the workgroup's LDS */
 #define SRV_CODE_LDS_MAX SRV_BC_OFF                /* a code is servable when its kernel's LDS fits below */

@@ -42,6 +42,19 @@ __device__ __forceinline__ void srv_st_sys(uint32_t *p, uint32_t v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+/* one 16-byte store that is written through to system memory by itself (sc0 sc1: not left in L2 until somebody's release
+ * -- plain stores to page-locked host memory stay there until the kernel ends: measured, every call took the idle
+ * timeout) */
+typedef uint32_t srv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void srv_st16_sys(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+  const srv_u32x4 v = {a, b, c, d};
+  /* (the s_nop: a VALU write of the store's data registers needs a wait state after a store of more than 64 bits; the
+   * compiler's hazard recogniser does not look inside inline assembly -- without it the units went out with corrupted
+   * third / fourth dwords) */
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 /* The server loop keeps next to nothing live across a decode: the kernel arguments are re-read from the kernarg segment
  * (scalar loads) where they are needed, the loop state sits in LDS.  Inlined next to a loop with its own live values
  * the fast decoder -- 127 of the 128 VGPRs a 1024-thread workgroup may use -- would spill; out of line it would need a
@@ -64,6 +77,8 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   srv_args_ptr_t a;
   uint32_t *st;
   int tid_;
+  bool resident_;
+  uint32_t tag_;
   __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(staged); }
   __device__ __forceinline__ const uint32_t *src32_prologue() const { return reinterpret_cast<const uint32_t *>(host_llr); }
   __device__ __forceinline__ uint32_t *stage_core() const { return reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(staged)); }
@@ -77,6 +92,11 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }
+  __device__ __forceinline__ bool tables_resident() const { return resident_; }
+  __device__ __forceinline__ uint32_t out_tag() const { return tag_; }
+  __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { srv_st16_sys(p, x, y, z, t); }
+  /* the payload was written by the host (over the BAR, or into page-locked memory) while this kernel runs: system scope */
+  __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return srv_ld_sys(p); }
 };
 
 __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
@@ -90,6 +110,7 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
   srv_args_ptr_t a = SRV_ARGS();
   if (threadIdx.x == 0) {
     srv_slot_ctl *slot = a->ctl + blockIdx.x;
+    bc[20] = bc[21] = 0; /* no code's tables in LDS yet */
     bc[1] = srv_ld_sys(&slot->done); /* a request the previous generation left unserved shows as doorbell != done */
     if (blockIdx.x == 0) {
       atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
@@ -141,8 +162,10 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
     const uint32_t d = bc[0];
     if (d == 0xffffffffu)
       break;
-    /* the host wrote the payload before the request line: order our loads behind the poll */
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    /* the host wrote the payload before the request line; the poll's load has returned, so the payload loads issued from
+     * here on see it -- provided they do not hit in a cache: the fast decoder reads the payload with system-scope loads
+     * (srv_fast_io::ld_llr), the generic one behind an acquire fence (below).  A system-scope acquire here would drop
+     * the XCD's L2 for every request. */
     a = SRV_ARGS();
     if (threadIdx.x == 0)
       bc[3] = (uint32_t)wall_clock64();
@@ -156,9 +179,18 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
     if (kind == SRV_KIND_DEC_FAST) {
       int tid_l = (int)threadIdx.x;
       const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
-      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l};
+      /* bc[20], bc[21]: the code whose tables this workgroup's LDS holds (0: none) */
+      const bool resident = bc[20] == LDPC_UNIFORM(rq->code_lo) && bc[21] == LDPC_UNIFORM(rq->code_hi);
+      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d};
       n_iter = ldpc_dec_fast_block(fsm, code, io);
+      if (threadIdx.x == 0) {
+        bc[20] = rq->code_lo;
+        bc[21] = rq->code_hi;
+      }
     } else if (kind == SRV_KIND_DEC_GENERIC) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (threadIdx.x == 0)
+        bc[20] = bc[21] = 0; /* this block overwrites the LDS the fast decoder keeps its tables in */
       ldpc_gblock_io io;
       io.llr = reinterpret_cast<const int8_t *>(host_in); /* read once, straight from the slot's host memory */
       io.out = reinterpret_cast<int8_t *>(hout);
@@ -184,29 +216,44 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
         __syncthreads();
       }
     }
-    /* results -> host, then the completion word.  n_iter and the timing stamps travel with the results; every thread's
-     * stores are fenced to system scope before the barrier, and only then thread 0 rings -- with a system-scope RELEASE
-     * store (a plain store may be reordered against the result bytes on its way to host memory: measured, a handful
-     * of calls in 10^4 returned with stale output bytes) */
+    /* Results -> host.  n_iter and the timing stamps travel in the completion line.
+     * Fast decoder: every 16-byte unit of the output area carries the call's sequence number (ldpc_dec_fast_block.h,
+     * out_tag) and so does the completion line, one 16-byte store: the host accepts a unit when it shows the number, in
+     * whatever order the stores arrive -- no fence, no barrier, nothing to wait for here.
+     * Other kinds: plain output bytes; every thread's stores are fenced to system scope before the barrier and only then
+     * thread 0 rings, with a system-scope RELEASE store (a plain store was reordered against the result bytes on its way
+     * to host memory; a release by the publishing thread alone was overtaken too: about one call in 10^3 came back with
+     * stale output bytes). */
     const uint32_t t_decoded = (uint32_t)wall_clock64();
+    uint32_t sd = 0, pp = 0;
     if (threadIdx.x == 0) {
-      srv_slot_ctl *slot = a->ctl + blockIdx.x;
       const uint32_t clip = 0xffffu;
       const uint32_t dt_stage = bc[3] - bc[2], dt_dec = t_decoded - bc[3];
       const uint32_t dt_pro = kind == SRV_KIND_DEC_FAST ? bc[24] - bc[3] : 0u, dt_pas = kind == SRV_KIND_DEC_FAST ? bc[25] - bc[24] : 0u;
-      srv_st_sys(reinterpret_cast<uint32_t *>(&slot->n_iter), (uint32_t)n_iter);
-      srv_st_sys(&slot->t_stage_decode, (dt_stage < clip ? dt_stage : clip) | ((dt_dec < clip ? dt_dec : clip) << 16));
-      srv_st_sys(&slot->t_pro_passes, (dt_pro < clip ? dt_pro : clip) | ((dt_pas < clip ? dt_pas : clip) << 16));
+      sd = (dt_stage < clip ? dt_stage : clip) | ((dt_dec < clip ? dt_dec : clip) << 16);
+      pp = (dt_pro < clip ? dt_pro : clip) | ((dt_pas < clip ? dt_pas : clip) << 16);
     }
-    /* every wave pushes its own result stores out to system scope (L2 write-back of what it wrote + wait) before the
-     * barrier; a release by the publishing thread alone is NOT enough -- tried: the other waves' bytes, acknowledged by L2
-     * only, were overtaken by the completion word about once in 10^3 calls.  Release only: nothing is acquired here. */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    __syncthreads();
-    a = SRV_ARGS();
+    if (kind == SRV_KIND_DEC_FAST) {
+      if (threadIdx.x == 0) {
+        srv_slot_ctl *slot = a->ctl + blockIdx.x;
+        srv_st16_sys(slot, d, (uint32_t)n_iter, sd, pp);
+      }
+    } else {
+      if (threadIdx.x == 0) {
+        srv_slot_ctl *slot = a->ctl + blockIdx.x;
+        srv_st_sys(reinterpret_cast<uint32_t *>(&slot->n_iter), (uint32_t)n_iter);
+        srv_st_sys(&slot->t_stage_decode, sd);
+        srv_st_sys(&slot->t_pro_passes, pp);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __syncthreads();
+      a = SRV_ARGS();
+      if (threadIdx.x == 0) {
+        srv_slot_ctl *slot = a->ctl + blockIdx.x;
+        __hip_atomic_store(&slot->done, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (threadIdx.x == 0) {
-      srv_slot_ctl *slot = a->ctl + blockIdx.x;
-      __hip_atomic_store(&slot->done, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
       bc[1] = d;
     }

@@ -14,6 +14,7 @@
  * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
  * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls).
  */
+#include <emmintrin.h>
 #include <atomic>
 #include <sched.h>
 #include <time.h>
@@ -288,7 +289,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   if (fill_dec_args(*p, ce, a) != 0)
     return -1;
   const int out_mode = a.out_mode, ob = out_bytes_of(hl, out_mode);
-  if ((size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob > SRV_OUT_STRIDE)
+  if ((size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob * 4 / 3 + 32 > SRV_OUT_STRIDE)
     return 1;
   const double t_call = srv_now();
   const SrvCall c = srv_acquire();
@@ -306,8 +307,32 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   const int rc = srv_submit(c, rq, &n);
   if (rc == 0) {
     *n_iter = n;
-    if (!a.use_crc || n >= 3) /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
-      memcpy(out, c.out, (size_t)ob);
+    if (!a.use_crc || n >= 3) { /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+      if (kind == SRV_KIND_DEC_FAST) {
+        /* 16-byte units {three output dwords, sequence number} (ldpc_server.h): a unit is there when it shows this call's
+         * number; one aligned 16-byte load per look, so a unit is never seen half written */
+        const uint32_t seq = srv.slots[c.slot].seq;
+        const int n_units = (ob / 4 + 2) / 3;
+        for (int u = 0; u < n_units; u++) {
+          const __m128i *src = reinterpret_cast<const __m128i *>(c.out) + u;
+          __m128i v = _mm_load_si128(src);
+          for (uint32_t spins = 0; (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi32(v, 0xff)) != seq; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xfff) == 0xfff && srv_ensure_running() != 0)
+              break;
+            v = _mm_load_si128(src);
+          }
+          const int left = ob - 12 * u;
+          if (left >= 12) {
+            memcpy(out + 12 * u, &v, 12);
+          } else if (left > 0) {
+            memcpy(out + 12 * u, &v, (size_t)left);
+          }
+        }
+      } else {
+        memcpy(out, c.out, (size_t)ob);
+      }
+    }
   }
   srv.slots[c.slot].host_total_s += srv_now() - t_call;
   srv_release(c);

@@ -231,7 +231,7 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
           const int gi = item - gstart;
           const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
           const uint32_t rowrec = rowtbl[srow0 + rig];
-          const int e0 = (int)(rowrec & 0xffffu), valid = (int)(rowrec >> 16) - 4 * j;
+          const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
           const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
           const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
           syn |= m & mask;
