@@ -147,7 +147,8 @@ typedef struct nrLDPC_hip_dec_batch {
   void *stream;               /* hipStream_t for DEVICE mem; NULL = HIP's default (null) stream */
   int32_t kernel;             /* 0 = best available for (BG,Z,R); 1 = generic kernel (any code); 2 = fast kernel or error;
                                * 3 / 4 = fast kernel with the throughput / latency workgroup shape forced (0 and 2 pick the
-                               * shape from n_blocks: latency shape up to one workgroup round of the GPU) */
+                               * shape from n_blocks: latency shape up to one workgroup round of the GPU; for Zc <= 64 a launch
+                               * that fills the GPU packs several blocks into a workgroup); 5 = that multi-block variant forced */
 } nrLDPC_hip_dec_batch_t;
 /* 0 on success, negative on bad parameters / HIP error.  DEVICE mem: asynchronous w.r.t. the host. */
 int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b);

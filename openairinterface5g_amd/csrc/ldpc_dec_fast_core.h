@@ -145,10 +145,12 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
 /* MODE 0: D1 and the magnitudes of every edge stay in registers between the two sweeps; 1: D1 only (magnitudes
  * recomputed); 2: nothing (the second sweep re-reads LDS and recomputes D1) -- for the degree-19 rows, whose 38+
  * live registers would otherwise spill at 16 waves per workgroup. */
+/* boff_r / boff_a (several blocks per workgroup, ldpc_dec_fast_mblock.h): byte offset of the item's block inside a
+ * message / extension-LLR row resp. inside an APP row; 0 in the one-block kernels, where they fold away. */
 template <int D, bool EXT, int MODE>
-LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
+LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0, int boff_a = 0)
 {
-  const int t = 4 * j;
+  const int t = 4 * j + boff_r, ta = 4 * j + boff_a; /* t: position in message and extension rows; ta: in APP rows */
   constexpr bool KEEP = MODE == 0;
   uint32_t d_lo[MODE <= 1 ? D : 1], d_hi[MODE <= 1 ? D : 1], g_lo[KEEP ? D : 1], g_hi[KEEP ? D : 1];
   ldpc_v2u m1l = ldpc_splatu(0xffff), m2l = m1l, m1h = m1l, m2h = m1l;
@@ -163,7 +165,7 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
     if (EXT && k == D - 1)
       ldpc_fast_cn_edge<true>(L, info, t, rw, true, dl, dh, parw, extl, exth);
     else
-      ldpc_fast_cn_edge<false>(L, info, t, rw, true, dl, dh, parw, extl, exth);
+      ldpc_fast_cn_edge<false>(L, info, ta, rw, true, dl, dh, parw, extl, exth);
     if (MODE <= 1) {
       d_lo[k] = dl;
       d_hi[k] = dh;
@@ -207,7 +209,7 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
       if (EXT && k == D - 1)
         ldpc_fast_cn_edge<true>(L, info, t, rw, false, dl, dh, parw, extl, exth);
       else
-        ldpc_fast_cn_edge<false>(L, info, t, rw, false, dl, dh, parw, extl, exth);
+        ldpc_fast_cn_edge<false>(L, info, ta, rw, false, dl, dh, parw, extl, exth);
     }
     const ldpc_v2u ml = KEEP ? ldpc_as_v2u(g_lo[k]) : ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     const ldpc_v2u mh = KEEP ? ldpc_as_v2u(g_hi[k]) : ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
@@ -276,24 +278,25 @@ LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, in
 #define LDPC_F_MODE_D19 2
 #endif
 /* dispatch on the task's (wave-uniform) degree */
-LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L, int e0, int j, int Z, int rstride)
+LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0,
+                                       int boff_a = 0)
 {
   if (!ext) {
     switch (deg) {
-      case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19>(L, e0, j, Z, rstride);
-      case 10: return ldpc_fast_cn<10, false, 0>(L, e0, j, Z, rstride);
-      default: return ldpc_fast_cn<8, false, 0>(L, e0, j, Z, rstride);
+      case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19>(L, e0, j, Z, rstride, boff_r, boff_a);
+      case 10: return ldpc_fast_cn<10, false, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+      default: return ldpc_fast_cn<8, false, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
     }
   }
   switch (deg) {
-    case 3: return ldpc_fast_cn<3, true, 0>(L, e0, j, Z, rstride);
-    case 4: return ldpc_fast_cn<4, true, 0>(L, e0, j, Z, rstride);
-    case 5: return ldpc_fast_cn<5, true, 0>(L, e0, j, Z, rstride);
-    case 6: return ldpc_fast_cn<6, true, 0>(L, e0, j, Z, rstride);
-    case 7: return ldpc_fast_cn<7, true, 0>(L, e0, j, Z, rstride);
-    case 8: return ldpc_fast_cn<8, true, 0>(L, e0, j, Z, rstride);
-    case 9: return ldpc_fast_cn<9, true, 0>(L, e0, j, Z, rstride);
-    default: return ldpc_fast_cn<10, true, 0>(L, e0, j, Z, rstride);
+    case 3: return ldpc_fast_cn<3, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 4: return ldpc_fast_cn<4, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 5: return ldpc_fast_cn<5, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 6: return ldpc_fast_cn<6, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 7: return ldpc_fast_cn<7, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 8: return ldpc_fast_cn<8, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 9: return ldpc_fast_cn<9, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    default: return ldpc_fast_cn<10, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
   }
 }
 
@@ -301,7 +304,7 @@ LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L,
  * colrec = f_coltbl entry of the column; maxdeg = wave-uniform loop bound >= the column's degree;
  * llr_word = the four channel LLRs (true int8 bytes). */
 LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, int j, int Z, int astride,
-                          uint32_t llr_word)
+                          uint32_t llr_word, int boff_r = 0, int boff_a = 0)
 {
   const int u = 4 * j;
   const int c = (int)(colrec & 0xffu), deg = (int)((colrec >> 8) & 0xffu), start = (int)(colrec >> 16);
@@ -319,7 +322,7 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
       const uint2 ce = tbl[k + i];
       const uint32_t q = (uint32_t)u + ce.x;            /* u + Z - shift in [1, 2Z) */
       const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z; /* mod Z: q - Z wraps to a huge value when q < Z */
-      w[i] = ldpc_window_al(L.base, ce.y + p, q);
+      w[i] = ldpc_window_al(L.base, ce.y + p + (uint32_t)boff_r, q);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -331,7 +334,7 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
     const uint2 ce = tbl[k];
     const uint32_t q = (uint32_t)u + ce.x;
     const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z;
-    const uint32_t v = ldpc_window_al(L.base, ce.y + p, q);
+    const uint32_t v = ldpc_window_al(L.base, ce.y + p + (uint32_t)boff_r, q);
     acc_e += v & 0x00ff00ffu;
     acc_o += (v >> 8) & 0x00ff00ffu;
   }
@@ -343,9 +346,9 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
   const ldpc_v2i vo = ldpc_pmin(ldpc_pmax(ldpc_as_v2i(acc_o) - bias, lo), hi) + b128;
   /* bytes: lane0 = ve.lo, lane1 = vo.lo, lane2 = ve.hi, lane3 = vo.hi */
   const uint32_t w = ldpc_perm(ldpc_as_u32(vo), ldpc_as_u32(ve), 0x06020400u);
-  uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + u);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a);
   dst[0] = w;
-  *reinterpret_cast<uint32_t *>(L.app + c * astride + u + Z) = w;
+  *reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a + Z) = w;
 }
 
 /* hard decision of code bit `b` (< ncore*Z) from the biased APP store */

@@ -1,0 +1,231 @@
+/*
+ * ldpc_dec_fast_mblock.h -- SEVERAL code blocks of one small code through the "fast" flooding min-sum decoder in one
+ * workgroup (device code; homogeneous batches only).
+ *
+ * Why: a lifted row of a small code has only Zc/4 four-lane items, and a check-node task is 64 items of ONE degree group
+ * (ldpc_graph.c) -- BG1 Zc = 32: 8 items per row, most degree groups hold one to three rows, so a one-block workgroup runs
+ * its tasks half empty (Zc = 16: a quarter, Zc = 8: an eighth; profiles/r01/occupancy_sweep.txt: 0.9 / 1.5 / 2.9 ps per
+ * edge-lane-pass against 0.5 for the large codes).  With f_mb blocks side by side inside every LDS row (ldpc_graph.h) an
+ * item is (row, block, group) and a row of all blocks fills a task.  The per-item arithmetic is the one-block kernel's
+ * (ldpc_dec_fast_core.h, with the block's offsets inside a row); what this file adds is per-block state: syndrome flags,
+ * CRC registers, pass counts, and an "active" flag -- a block that has stopped (parity or CRC, nrLDPC_decoder.c:842-861)
+ * is skipped from then on, so its APP words stay what they were when it stopped, as in the one-block kernel.
+ *
+ * Contract per block = ldpc_dec_fast_block.h's (nrLDPC_decoder_core, reference nrLDPC_decoder.c:206-880).
+ */
+#ifndef LDPC_DEC_FAST_MBLOCK_H
+#define LDPC_DEC_FAST_MBLOCK_H
+#include <hip/hip_runtime.h>
+#include "ldpc_kernels.h"
+#include "ldpc_dec_fast_block.h"
+
+#define LDPC_MB_MAX 16
+/* the workgroup's flag words (ints at f_lds_misc, 512 bytes): [0], [1] task queues of the two phases, [2] blocks still
+ * active, then five arrays of LDPC_MB_MAX: syndrome flags of odd / even passes, CRC registers, active, pass counts */
+#define LDPC_MB_SYN(par) (16 + LDPC_MB_MAX * (par))
+#define LDPC_MB_CRC (16 + 2 * LDPC_MB_MAX)
+#define LDPC_MB_ACT (16 + 3 * LDPC_MB_MAX)
+#define LDPC_MB_NIT (16 + 4 * LDPC_MB_MAX)
+
+/* blocks first .. first + n_valid - 1 of the launch (n_valid <= f_mb); results to a.out / a.n_iter */
+__device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_dec_args &a, uint32_t first, int n_valid)
+{
+  const int Z = code->Z, zq = code->f_zq, zqb = code->f_zqb, rstride = code->f_rstride, astride = code->f_astride;
+  const int pr = Z + 4, pa = 2 * Z; /* a block's bytes inside a message / extension row, inside an APP row */
+  const uint32_t zq_magic = code->f_zq_magic, zqb_magic = code->f_zqb_magic;
+  const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u;
+  ldpc_fast_lds L;
+  L.base = fsm;
+  L.r = fsm + code->f_lds_r;
+  L.app = fsm + code->f_lds_app;
+  L.ext = fsm + code->f_lds_ext;
+  uint32_t *etbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_etbl);
+  uint32_t *ctbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_ctbl);
+  uint32_t *rowtbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_rowtbl);
+  uint32_t *coltbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_coltbl);
+  L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
+  L.gllr = nullptr;
+  L.ext_global = 0;
+  int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x, lane = tid & 63;
+  const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
+  const int n_app = ncore * zq, n_ext = (code->ncols - ncore) * zq;
+  const uint32_t stride4 = a.llr_stride >> 2;
+  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (size_t)first * a.llr_stride);
+  const int max_pass = a.num_max_iter + 1;
+
+  /* ---- tables and state into LDS ------------------------------------------------------------------------ */
+  const uint32_t lds0 = ldpc_lds_addr(fsm);
+  for (int i = tid; i < nedges; i += nt)
+    etbl[i] = code->f_etbl[i] + lds0;
+  for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
+    ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
+  for (int i = tid; i < code->nrows; i += nt)
+    rowtbl[i] = code->f_rowtbl[i];
+  for (int i = tid; i < ncore; i += nt)
+    coltbl[i] = code->f_coltbl[i];
+  for (int i = tid; i < (code->f_mb * pr) >> 2; i += nt)
+    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
+  if (tid < 16)
+    flags[tid] = 0;
+  if (tid < LDPC_MB_MAX) {
+    flags[LDPC_MB_SYN(0) + tid] = 0;
+    flags[LDPC_MB_SYN(1) + tid] = 0;
+    flags[LDPC_MB_CRC + tid] = 0;
+    flags[LDPC_MB_ACT + tid] = tid < n_valid;
+    flags[LDPC_MB_NIT + tid] = max_pass;
+  }
+  {
+    const int nr4 = (nedges * rstride) >> 2;
+    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
+    for (int i = tid; i < nr4; i += nt)
+      r32[i] = 0x80808080u;
+  }
+  /* APP := channel LLR (both copies) and the extension columns' LLRs, block by block */
+  for (int b = 0; b < n_valid; b++) {
+    const uint32_t *sb = src32 + (size_t)b * stride4;
+    for (int i = tid; i < n_app; i += nt) {
+      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+      const uint32_t w = sb[i] ^ 0x80808080u;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + b * pa) + j;
+      dst[0] = w;
+      dst[zq] = w;
+    }
+    for (int i = tid; i < n_ext; i += nt) {
+      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+      reinterpret_cast<uint32_t *>(L.ext + c * rstride + b * pr)[j] = sb[n_app + i] ^ 0x80808080u;
+    }
+  }
+  __syncthreads();
+
+  /* ---- passes ------------------------------------------------------------------------------------------ */
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
+  const int use_crc = a.use_crc;
+  for (int p = 1; p <= max_pass; ++p) {
+    for (;;) {
+      const int task = ldpc_draw(&flags[0], lane);
+      if (task >= n_cn_tasks)
+        break;
+      const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+      const int item = code->f_cn_task[task][2] + lane;
+      const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
+      if (item < gend) {
+        const int gi = item - gstart;
+        const int rig = (int)ldpc_umulhi((uint32_t)gi, zqb_magic), jb = gi - rig * zqb;
+        const int b = (int)ldpc_umulhi((uint32_t)jb, zq_magic), j = jb - b * zq;
+        if (flags[LDPC_MB_ACT + b]) {
+          const uint32_t rowrec = rowtbl[srow0 + rig];
+          const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
+          const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride, b * pr, b * pa);
+          const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+          if (m & mask)
+            flags[LDPC_MB_SYN(p & 1) + b] = 1; /* (same value from every lane that writes) */
+        }
+      }
+    }
+    if (tid == 0)
+      flags[1] = 0; /* nobody draws bit-node tasks now */
+    __syncthreads();
+    /* nrLDPC_decoder.c:842-848: a block whose previous pass satisfied every (looked-at) check stops, from pass 3 on */
+    if (tid < n_valid && flags[LDPC_MB_ACT + tid] && !use_crc && p >= 3 && flags[LDPC_MB_SYN(p & 1) + tid] == 0) {
+      flags[LDPC_MB_NIT + tid] = p - 1;
+      flags[LDPC_MB_ACT + tid] = 0;
+      atomicAdd(&flags[2], 1);
+    }
+    __syncthreads();
+    if (flags[2] >= n_valid)
+      break;
+    for (;;) {
+      const int ticket = ldpc_draw(&flags[1], lane);
+      if (ticket * bn_group >= n_bn_tasks)
+        break;
+      for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
+        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+        const int maxdeg = code->f_bn_task[task][2];
+        if (item < end) {
+          const int sc = (int)ldpc_umulhi((uint32_t)item, zqb_magic), jb = item - sc * zqb;
+          const int b = (int)ldpc_umulhi((uint32_t)jb, zq_magic), j = jb - b * zq;
+          if (flags[LDPC_MB_ACT + b]) {
+            const uint32_t colrec = coltbl[sc];
+            const uint32_t lw = src32[(size_t)b * stride4 + (uint32_t)((int)(colrec & 0xffu) * zq + j)];
+            ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw, b * pr, b * pa);
+          }
+        }
+      }
+    }
+    if (tid == 0)
+      flags[0] = 0; /* nobody draws check-node tasks now */
+    if (tid < LDPC_MB_MAX) {
+      flags[LDPC_MB_SYN((p + 1) & 1) + tid] = 0;
+      flags[LDPC_MB_CRC + tid] = 0;
+    }
+    __syncthreads();
+    if (use_crc && p >= 3) { /* decoder.c:849-861, per block; see ldpc_dec_generic_block.h for the CRC argument */
+      const int crcE = a.E;
+      const uint32_t *crc_pow = a.crc_pow;
+      for (int b = 0; b < n_valid; b++) {
+        if (!flags[LDPC_MB_ACT + b])
+          continue;
+        uint32_t x = 0;
+        for (int i = 4 * tid; i < crcE; i += 4 * nt) {
+          const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
+          const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + b * pa + u);
+          const uint4 pw = *reinterpret_cast<const uint4 *>(crc_pow + (crcE - 4 - i));
+          x ^= (pw.w & (0u - ((nb >> 7) & 1u))) ^ (pw.z & (0u - ((nb >> 15) & 1u))) ^ (pw.y & (0u - ((nb >> 23) & 1u))) ^
+               (pw.x & (0u - (nb >> 31)));
+        }
+        for (int off = 32; off; off >>= 1)
+          x ^= __shfl_xor(x, off);
+        if (lane == 0 && x)
+          atomicXor(reinterpret_cast<unsigned int *>(&flags[LDPC_MB_CRC + b]), x);
+      }
+      __syncthreads();
+      if (tid < n_valid && flags[LDPC_MB_ACT + tid] && flags[LDPC_MB_CRC + tid] == 0) {
+        flags[LDPC_MB_NIT + tid] = p;
+        flags[LDPC_MB_ACT + tid] = 0;
+        atomicAdd(&flags[2], 1);
+      }
+      __syncthreads();
+      if (flags[2] >= n_valid)
+        break;
+    }
+  }
+
+  /* ---- hard decisions ------------------------------------------------------------------------------------ */
+  for (int b = 0; b < n_valid; b++) {
+    const int n_iter = flags[LDPC_MB_NIT + b];
+    if (use_crc && n_iter < 3)
+      continue; /* decoder.c:849-861: p_out stays untouched */
+    int8_t *orow = a.out + (size_t)(first + b) * a.out_stride;
+    if (a.out_mode == 0) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(orow);
+      const int nwords = (num_llr + 31) >> 5;
+      for (int w = tid; w < nwords; w += nt) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int bit = 32 * w + 4 * q;
+          if (bit < ncz) {
+            const int c = (int)ldpc_umulhi((uint32_t)bit, z_magic), u = bit - c * Z;
+            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + b * pa + u);
+            const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+            word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
+          }
+        }
+        o[w] = word;
+      }
+    } else {
+      for (int i = tid; i < num_llr; i += nt) {
+        int8_t v = 0;
+        if (i < ncz) {
+          const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
+          v = (int8_t)(L.app[c * astride + b * pa + u] < 128);
+        }
+        orow[i] = v;
+      }
+    }
+  }
+  if (tid < n_valid)
+    a.n_iter[first + tid] = flags[LDPC_MB_NIT + tid];
+}
+#endif

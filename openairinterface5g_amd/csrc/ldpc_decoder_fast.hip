@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_block.h"
+#include "ldpc_dec_fast_mblock.h"
 
 /* a block of a batch launch: addressed by strides (homogeneous batch) or by its job record; everything is read from
  * the kernel arguments / the job record where it is needed (scalar loads), see ldpc_dec_fast_block.h */
@@ -118,11 +119,21 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
     a.n_iter[blockIdx.x] = n_iter;
 }
 
+/* small lifting sizes: f_mb blocks per workgroup (ldpc_dec_fast_mblock.h) */
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_kernel(const ldpc_dec_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const uint32_t first = blockIdx.x * (uint32_t)code->f_mb;
+  const uint32_t left = a.n_blocks - first;
+  ldpc_dec_fast_mblock(fsm, code, a, first, left < (uint32_t)code->f_mb ? (int)left : code->f_mb);
+}
+
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[3] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel)};
-  for (int i = 0; i < 3; i++) {
+  const void *k[4] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel)};
+  for (int i = 0; i < 4; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -137,6 +148,18 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
   hipLaunchKernelGGL((ldpc_dec_fast_kernel<false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a0, const ldpc_code_desc_t &hc, uint32_t n_blocks, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  if (a0.jobs || hc.f_mb < 2 || !hc.f_ok)
+    return hipErrorInvalidValue;
+  ldpc_dec_args a = a0;
+  a.n_blocks = n_blocks;
+  hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel, dim3((n_blocks + hc.f_mb - 1) / hc.f_mb), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 

@@ -39,17 +39,21 @@ static int by_key_desc(const void *pa, const void *pb)
 static int align16(int x) { return (x + 15) & ~15; }
 
 /* schedules and tables of the "fast" decoder kernel (see ldpc_graph.h) */
-static void build_fast_section(ldpc_code_desc_t *d, int shape)
+static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
 {
   const int Z = d->Z;
   d->f_ok = 0;
   if ((Z & 3) || Z < 8)
     return;
-  const int zq = Z / 4;
-  d->f_zq = zq;
-  d->f_zq_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq - 1) / (uint64_t)zq);
-  d->f_rstride = Z + 4;
-  d->f_astride = 2 * Z;
+  const int zq1 = Z / 4;
+  const int zq = zq1 * mb; /* items per lifted row / column: all blocks of the workgroup (mb = 1: the one block) */
+  d->f_mb = mb;
+  d->f_zq = zq1;
+  d->f_zq_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq1 - 1) / (uint64_t)zq1);
+  d->f_zqb = zq;
+  d->f_zqb_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq - 1) / (uint64_t)zq);
+  d->f_rstride = mb * (Z + 4);
+  d->f_astride = mb * 2 * Z;
 
   /* rows sorted by degree (descending, stable) */
   sort_item_t rows[LDPC_MAX_ROWS];
@@ -136,14 +140,15 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   /* the magic division must be exact for every item index that occurs */
   const int max_item = d->nrows * zq > nitems ? d->nrows * zq : nitems;
   for (int i = 0; i < max_item + 64; i++)
-    if ((int)(((uint64_t)i * d->f_zq_magic) >> 32) != i / zq)
+    if ((int)(((uint64_t)i * d->f_zqb_magic) >> 32) != i / zq || (int)(((uint64_t)i * d->f_zq_magic) >> 32) != i / zq1)
       return;
 
   /* LDS layout.  The channel LLRs of the degree-1 columns are read once per pass by one check-node edge each; when
    * leaving them in global memory (L2) lets one more workgroup fit on a CU, they are not staged (f_ext_global). */
-  const int ext_bytes = align16((d->ncols - d->ncore) * Z);
+  const int ext_bytes = mb > 1 ? align16((d->ncols - d->ncore) * d->f_rstride) : align16((d->ncols - d->ncore) * Z);
+  const int misc_bytes = mb > 1 ? 512 : 64;
   const int fixed = align16(d->nedges * d->f_rstride) + align16(d->ncore * d->f_astride) + align16(d->nedges * 4) +
-                    align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(Z + 4) + 64;
+                    align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(mb * (Z + 4)) + misc_bytes;
   /* Workgroup shape.  A CU holds 16 waves of this kernel (<= 128 VGPRs), so the waves per workgroup w and the
    * workgroups per CU k are chosen together: maximise the resident waves k*w subject to k workgroups fitting in the
    * 160 KiB of LDS (with or without the staged extension LLRs) and w <= check-node tasks; w a multiple of 4 so that the
@@ -163,7 +168,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
     for (int w = LDPC_F_MAX_WAVES; w >= 1; w = (w > 4 ? w - 4 : w - 1)) {
       if (w > nt)
         continue;
-      for (int eg = 0; eg <= 1; eg++) {
+      for (int eg = 0; eg <= (mb > 1 ? 0 : 1); eg++) {
         int k = lds_cu / (fixed + (eg ? 0 : ext_bytes));
         if (k > 16 / w) k = 16 / w;
         if (k > 8) k = 8;
@@ -179,7 +184,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
     if (env && atoi(env) >= 1 && atoi(env) <= LDPC_F_MAX_WAVES)
       waves = atoi(env) < nt ? atoi(env) : nt;
     const char *eg = getenv("NRLDPC_HIP_EXT_GLOBAL");
-    if (eg && (eg[0] == '0' || eg[0] == '1'))
+    if (eg && (eg[0] == '0' || eg[0] == '1') && mb == 1)
       d->f_ext_global = eg[0] == '1';
   }
   {
@@ -216,8 +221,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   d->f_lds_rowtbl = d->f_lds_ctbl + align16(d->f_n_ctbl * 8);
   d->f_lds_coltbl = d->f_lds_rowtbl + align16(d->nrows * 4);
   d->f_lds_zero = d->f_lds_coltbl + align16(d->ncore * 4);
-  d->f_lds_misc = d->f_lds_zero + align16(Z + 4);
-  d->f_lds_total = d->f_lds_misc + 64;
+  d->f_lds_misc = d->f_lds_zero + align16(mb * (Z + 4));
+  d->f_lds_total = d->f_lds_misc + misc_bytes;
   if (d->f_lds_total > 160 * 1024)
     return;
   for (int i = 0; i < d->f_n_ctbl; i++) /* minus the window's byte phase (ldpc_fast_bn); may wrap below 0, mod 2^32 */
@@ -227,7 +232,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape)
   for (int e = 0; e < d->nedges; e++) {
     const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
     d->f_etbl[e] = c < d->ncore ? (uint32_t)(d->f_lds_app + c * d->f_astride + s)
-                                : (d->f_ext_global ? (uint32_t)(c * Z) : (uint32_t)(d->f_lds_ext + (c - d->ncore) * Z));
+                                : (d->f_ext_global ? (uint32_t)(c * Z)
+                                                   : (uint32_t)(d->f_lds_ext + (c - d->ncore) * (mb > 1 ? d->f_rstride : Z)));
   }
   d->f_ok = 1;
 }
@@ -435,6 +441,28 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;
   d->n_threads = waves * 64;
-  build_fast_section(d, shape);
+  build_fast_section(d, shape, 1);
+  return 0;
+}
+
+int ldpc_multi_blocks_for(int Z)
+{
+  if ((Z & 3) || Z < 8 || Z > 64)
+    return 1;
+  int mb = 64 / (Z / 4); /* one lifted row of all blocks ~ one 64-item task */
+  if (mb > 16)
+    mb = 16;
+  return mb < 2 ? 1 : mb;
+}
+
+int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d)
+{
+  if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_THROUGHPUT, d) != 0)
+    return -1;
+  if (mb < 2 || mb > 16) {
+    d->f_ok = 0;
+    return 0;
+  }
+  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb);
   return 0;
 }

@@ -106,6 +106,14 @@ typedef struct ldpc_code_desc {
   int32_t f_bn_group;   /* bit-node tasks per queue ticket (>= 1) */
   int32_t f_ext_global; /* 1: the degree-1 columns' LLRs are read from the input buffer, not staged in LDS */
   int32_t f_lds_zero; /* Z + 4 zero bytes */
+  /* Several code blocks per workgroup (small lifting sizes: a lifted row has only Z/4 items, so one block's degree groups
+   * leave most of a 64-item task empty).  f_mb > 1: the workgroup's LDS holds f_mb blocks side by side INSIDE every row --
+   * message / extension-LLR row of an edge = f_mb x (Z + 4) bytes, APP row of a column = f_mb x 2Z bytes -- and an item
+   * is (row | column, block, 4-lane group): f_zqb = f_mb * Z/4 items per row.  f_rstride / f_astride / f_etbl / f_ctbl
+   * and the task lists are built for that layout; the per-item bodies get the block's offsets inside a row (ldpc_dec_fast_core.h,
+   * boff_r / boff_a).  Kernel: ldpc_dec_fast_mblock.h. */
+  int32_t f_mb, f_zqb;
+  uint32_t f_zqb_magic;
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus
@@ -119,6 +127,10 @@ int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d); /* = throug
 #define LDPC_SHAPE_THROUGHPUT 0
 #define LDPC_SHAPE_LATENCY 1
 int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t *d);
+/* throughput shape with `mb` blocks per workgroup (f_ok = 0 when the code does not qualify or does not fit) */
+int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d);
+/* blocks per workgroup that fill a 64-item task row by row for this lifting size; 1: not worth it */
+int ldpc_multi_blocks_for(int Z);
 /* set index iLS of lifting size Z (38.212 Table 5.3.2-1), -1 if Z is not a lifting size */
 int ldpc_lifting_set_index(int Z);
 #ifdef __cplusplus

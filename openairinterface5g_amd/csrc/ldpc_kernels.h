@@ -47,6 +47,7 @@ struct ldpc_dec_args {
    * memory, device-mapped address -- into its row of `llr` (device memory, written here), then decodes from there */
   const int8_t *pull;
   uint32_t pull_stride;
+  uint32_t n_blocks; /* multi-block launches: blocks in the launch (the last workgroup may hold fewer than f_mb) */
 };
 
 struct ldpc_enc_args {
@@ -75,6 +76,9 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
 /* the same with a.pull set: every workgroup pulls its LLR row over the link itself (no copy engine, no staging copy) */
 hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                      hipStream_t stream);
+/* small lifting sizes, homogeneous batch: host_code.f_mb blocks per workgroup (ldpc_dec_fast_mblock.h) */
+hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
+                                      hipStream_t stream);
 /* encoder: one workgroup per code block; workgroup size and dynamic LDS of the selected encoder kernel for a code */
 int ldpc_enc_is_packed(void); /* 1: bit-packed kernel selected (default), 0: NRLDPC_HIP_ENC_KERNEL=bytes */
 void ldpc_enc_launch_shape(const ldpc_code_desc_t &host_code, int *n_threads, int *lds_bytes);

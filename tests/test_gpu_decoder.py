@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 def kernels_for(Z):
     """1 = generic kernel (any code); 3 / 4 = fast kernel (Zc % 4 == 0, Zc >= 8) in its throughput / latency workgroup
-    shape (0 and 2 would pick the shape from the batch size); all must match the oracle."""
+    shape (0 and 2 would pick the shape from the batch size); 5 = its multi-block variant; all must match the oracle."""
+    if Z % 4 == 0 and 8 <= Z <= 64:
+        return (1, 3, 4, 5)          # 5: several blocks per workgroup (small lifting sizes)
     return (1, 3, 4) if (Z % 4 == 0 and Z >= 8) else (1,)
 
 
@@ -261,6 +263,49 @@ def test_host_buffer_paths(hip, cfg):
                         assert refs[i][0] == it[i], (cfg, use_crc, pitch, llr_pinned, out_pinned, i, refs[i][0], int(it[i]))
                         assert np.array_equal(refs[i][1], out[i]), (cfg, use_crc, pitch, llr_pinned, out_pinned, i)
                     assert (dst[:, (ob + 3) // 4 * 4:] == 0x5a).all()
+
+
+@pytest.mark.parametrize("cfg", [(1, 32, 13), (1, 8, 89), (2, 16, 15), (2, 48, 13), (1, 64, 23), (2, 24, 23)])
+def test_small_lifting_sizes_several_blocks_per_workgroup(hip, cfg):
+    """Zc <= 64: a batch that fills the GPU is decoded with several code blocks per workgroup (ldpc_dec_fast_mblock.h).
+    Blocks of one workgroup stop at different passes (mixed SNRs, some never), the last workgroup is partly filled, in
+    parity-check and in CRC mode: all blocks equal the oracle (vectorisable restatement, itself pinned to the scalar one),
+    and the automatic choice (kernel 0) gives the same as the forced one (kernel 5)."""
+    import torch
+    BG, Z, R = cfg
+    rng = np.random.default_rng(31 * Z + R + BG)
+    K = kbits(BG, Z)
+    info = hip.ldpc.code_info(BG, Z, R)
+    n = 256 * 8 * 16 + 37 if Z <= 16 else 256 * 2 * (64 // (Z // 4)) + 37
+    row = hip.ldpc.num_llr(BG, Z, R)
+    base = []
+    for i in range(24):
+        inf = random_info(rng, BG, Z)
+        crc = O.crc("crc24b", inf, K - 24) >> 8
+        inf[K // 8 - 3:K // 8] = [(crc >> 16) & 255, (crc >> 8) & 255, crc & 255]
+        base.append(make_llr(rng, BG, Z, R, float(rng.choice([-4.0, -1.0, 0.5, 2.0, 5.0])), inf))
+    base.append(make_llr(rng, BG, Z, R, "rand"))
+    base.append(np.zeros(row, np.int8))
+    idx = rng.integers(0, len(base), n)
+    llr_h = np.stack(base)[idx]
+    llr = torch.from_numpy(llr_h).cuda()
+    ob = hip.ldpc.out_bytes(BG, Z, R)
+    for use_crc in (False, True):
+        refs = [O.decode(BG, Z, R, b, 8, 0, use_crc, K if use_crc else 0, 1, out_init=0x77) for b in base]
+        res = {}
+        for kern in (5, 0):
+            out = torch.full((n, ob), 0x77, dtype=torch.uint8, device="cuda")
+            it = torch.zeros(n, dtype=torch.int32, device="cuda")
+            hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8, check_crc=use_crc, E=K if use_crc else 0, crc_type=1, kernel=kern)
+            torch.cuda.synchronize()
+            res[kern] = (it.cpu().numpy(), out.cpu().numpy())
+        for kern in (5, 0):
+            it_h, out_h = res[kern]
+            for i in range(n):
+                n_ref, out_ref = refs[idx[i]]
+                assert n_ref == it_h[i], (cfg, use_crc, kern, i, n_ref, int(it_h[i]))
+                assert np.array_equal(out_ref, out_h[i]), (cfg, use_crc, kern, i)
+    assert info is not None
 
 
 def test_config3_mixed_bg2_batch_every_block(hip):

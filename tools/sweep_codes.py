@@ -3,6 +3,7 @@
 
   python tools/sweep_codes.py [n_blocks] > gpurun_out/sweep_codes.txt
 """
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,6 +17,7 @@ import openairinterface5g_amd as pkg  # noqa: E402
 m = pkg.ldpc
 pkg.LDPCinit()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+KERNEL = int(os.environ.get("SWEEP_KERNEL", "0"))   # nrLDPC_hip_dec_batch_t.kernel: 0 best, 3 one block per workgroup, 5 several
 only = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]  # optional: BG,Z,R triples
 codes = [(1, 384, 13), (1, 384, 23), (1, 384, 89), (1, 352, 13), (1, 320, 13), (1, 256, 13), (1, 192, 13), (1, 128, 13), (1, 96, 13),
          (1, 64, 13), (1, 32, 13), (1, 16, 13), (1, 8, 13), (1, 30, 13), (1, 7, 13),
@@ -29,12 +31,12 @@ for BG, Z, R in (only or codes):
     out = torch.zeros((n, m.out_bytes(BG, Z, R)), dtype=torch.uint8, device="cuda")
     it = torch.zeros(n, dtype=torch.int32, device="cuda")
     for _ in range(3):
-        pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+        pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8, kernel=KERNEL)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 10
     for _ in range(reps):
-        pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+        pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8, kernel=KERNEL)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     assert int(it.min()) == 9, (BG, Z, R, int(it.min()))
