@@ -49,12 +49,13 @@ struct CodeEntry {
   ldpc_code_desc_t *dev = nullptr;
   ldpc_code_desc_t host_lat;        /* latency shape, for launches of at most one workgroup round */
   ldpc_code_desc_t *dev_lat = nullptr;
-  ldpc_code_desc_t host_multi;      /* small lifting sizes: several blocks per workgroup (f_ok = 0: not for this code) */
+  ldpc_code_desc_t host_multi;      /* small lifting sizes: several blocks per workgroup -- side by side (Zc % 4 == 0) or four
+                                       interleaved byte-wise (any Zc, f_sub = 4); f_ok = 0: not for this code */
   ldpc_code_desc_t *dev_multi = nullptr;
   /* homogeneous launches that fill the GPU with multi-block workgroups at least once */
   bool use_multi(uint32_t n_blocks, int n_cus) const
   {
-    return dev_multi && n_blocks >= (uint32_t)(n_cus * host_multi.f_wg_per_cu * host_multi.f_mb);
+    return dev_multi && n_blocks >= (uint32_t)(n_cus * host_multi.f_wg_per_cu * host_multi.f_mb * host_multi.f_sub);
   }
   /* the variant for a decoder launch of n_blocks workgroups; force: 0 = by size, 1 = throughput, 2 = latency */
   bool use_latency(uint32_t n_blocks, int n_cus, int force = 0) const
@@ -258,11 +259,20 @@ const CodeEntry *get_code(int BG, int Z, int R)
     set_error("invalid (BG, Z, R)");
     return nullptr;
   }
-  static const int multi_env = [] { const char *v = getenv("NRLDPC_HIP_MULTI"); return v ? atoi(v) : -1; }(); /* 0: off, n: force n blocks */
-  const int mb = multi_env >= 0 ? multi_env : ldpc_multi_blocks_for(Z);
+  static const int multi_env = [] { const char *v = getenv("NRLDPC_HIP_MULTI"); return v ? atoi(v) : -1; }(); /* 0: off, n: force n per workgroup */
   ce->host_multi.f_ok = 0;
-  if (mb > 1 && ce->host.f_ok && ldpc_build_code_desc_multi(BG, Z, R, mb, &ce->host_multi) != 0)
-    ce->host_multi.f_ok = 0;
+  if (multi_env != 0) {
+    if (ce->host.f_ok) {
+      const int mb = multi_env > 0 ? multi_env : ldpc_multi_blocks_for(Z);
+      if (mb > 1 && ldpc_build_code_desc_multi(BG, Z, R, mb, &ce->host_multi) != 0)
+        ce->host_multi.f_ok = 0;
+    } else if (Z <= 30) { /* the lifting sizes that are not multiples of 4 (and 2 .. 7): four blocks interleaved */
+      int mb = multi_env > 0 ? multi_env : 64 / Z;
+      mb = mb < 1 ? 1 : (mb > 16 ? 16 : mb);
+      if (ldpc_build_code_desc_interleaved(BG, Z, R, mb, &ce->host_multi) != 0)
+        ce->host_multi.f_ok = 0;
+    }
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(d.id);
@@ -435,17 +445,18 @@ int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_
     batch_blocks = n_blocks; /* the launch is one chunk of a larger batch: the whole batch decides the shape */
   const ldpc_code_desc_t &hc = ce->host;
   const bool fast_ok = hc.f_ok && ((reinterpret_cast<uintptr_t>(a.llr) | a.llr_stride) & 3) == 0;
+  /* kernel 5: several blocks per workgroup forced (tests); 0 / 2: when the launch fills the GPU with such workgroups */
+  const bool multi_ok = !a.jobs && ce->dev_multi && (ce->host_multi.f_sub == 4 || fast_ok);
+  if (multi_ok && (kernel == 5 || ((kernel == 0 || kernel == 2) && ce->use_multi(batch_blocks, G().n_cus)))) {
+    a.code = ce->dev_multi;
+    HIP_TRY(ldpc_launch_dec_fast_multi(a, ce->host_multi, n_blocks, s));
+    return 0;
+  }
+  if (kernel == 5)
+    return set_error("no multi-block variant for this code");
   if (kernel >= 2 && !fast_ok)
     return set_error("fast kernel not applicable (needs Zc % 4 == 0, Zc >= 8, 4-byte aligned LLR rows)");
   if (kernel != 1 && fast_ok) {
-    /* kernel 5: several blocks per workgroup forced (tests); 0 / 2: when the launch fills the GPU with such workgroups */
-    if (!a.jobs && ce->dev_multi && (kernel == 5 || ((kernel == 0 || kernel == 2) && ce->use_multi(batch_blocks, G().n_cus)))) {
-      a.code = ce->dev_multi;
-      HIP_TRY(ldpc_launch_dec_fast_multi(a, ce->host_multi, n_blocks, s));
-      return 0;
-    }
-    if (kernel == 5)
-      return set_error("no multi-block variant for this code");
     const bool lat = ce->use_latency(batch_blocks, G().n_cus, kernel == 3 ? 1 : (kernel == 4 ? 2 : 0));
     a.code = lat ? ce->dev_lat : ce->dev;
     HIP_TRY(ldpc_launch_dec_fast(a, lat ? ce->host_lat : ce->host, n_blocks, s));

@@ -11,6 +11,11 @@
  * CRC registers, pass counts, and an "active" flag -- a block that has stopped (parity or CRC, nrLDPC_decoder.c:842-861)
  * is skipped from then on, so its APP words stay what they were when it stopped, as in the one-block kernel.
  *
+ * SUB = 4 (lifting sizes that are not multiples of 4): four blocks are interleaved byte-wise into one block of the virtual
+ * code of ldpc_graph.h (f_sub) -- every window an aligned dword, whatever Zc is -- and f_mb counts such groups.  The four
+ * blocks of a group share their items, so a stopped block cannot be skipped; instead a block's output is written at the
+ * moment it stops (its APP bytes are then still what the stop was decided on) and the group goes on for the others.
+ *
  * Contract per block = ldpc_dec_fast_block.h's (nrLDPC_decoder_core, reference nrLDPC_decoder.c:206-880).
  */
 #ifndef LDPC_DEC_FAST_MBLOCK_H
@@ -19,15 +24,74 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_block.h"
 
-#define LDPC_MB_MAX 16
-/* the workgroup's flag words (ints at f_lds_misc, 512 bytes): [0], [1] task queues of the two phases, [2] blocks still
- * active, then five arrays of LDPC_MB_MAX: syndrome flags of odd / even passes, CRC registers, active, pass counts */
+#define LDPC_MB_MAX 64 /* blocks per workgroup: 16 groups x SUB */
+/* the workgroup's flag words (ints at f_lds_misc): [0], [1] task queues of the two phases, [2] blocks that have stopped,
+ * then arrays of LDPC_MB_MAX: syndrome flags of odd / even passes, CRC registers, active, pass counts; SUB = 4 also: "to
+ * be written out now" */
 #define LDPC_MB_SYN(par) (16 + LDPC_MB_MAX * (par))
 #define LDPC_MB_CRC (16 + 2 * LDPC_MB_MAX)
 #define LDPC_MB_ACT (16 + 3 * LDPC_MB_MAX)
 #define LDPC_MB_NIT (16 + 4 * LDPC_MB_MAX)
+#define LDPC_MB_OUT (16 + 5 * LDPC_MB_MAX) /* needs 16 + 6 * 64 ints = 1600 bytes with SUB = 4 */
 
-/* blocks first .. first + n_valid - 1 of the launch (n_valid <= f_mb); results to a.out / a.n_iter */
+/* hard decisions of one block -> its output row (bnProc.h:1353-1380 packing).  SUB = 4: the block is byte `sub` of every
+ * dword of group `v`. */
+template <int SUB>
+__device__ __forceinline__ void ldpc_mb_write_out(const ldpc_fast_lds &L, ldpc_code_ptr_t code, const ldpc_dec_args &a, uint32_t blk_global,
+                                                  int v, int sub, int tid, int nt)
+{
+  const int Zv = code->Z, zr = Zv / SUB, astride = code->f_astride, pa = 2 * Zv;
+  const int num_llr = code->num_llr, ncz = code->ncore * zr;
+  const uint32_t zr_magic = 0xffffffffu / (uint32_t)zr + 1u;
+  int8_t *orow = a.out + (size_t)blk_global * a.out_stride;
+  if (SUB == 1 && a.out_mode == 0) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(orow);
+    const int nwords = (num_llr + 31) >> 5;
+    for (int w = tid; w < nwords; w += nt) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int bit = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
+        if (bit < ncz) {
+          const int c = (int)ldpc_umulhi((uint32_t)bit, zr_magic), u = bit - c * zr;
+          const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + v * pa + u);
+          const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+          word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
+        }
+      }
+      o[w] = word;
+    }
+    return;
+  }
+  if (a.out_mode == 0) { /* bit by bit (small codes: at most 68 x 30 bits) */
+    uint32_t *o = reinterpret_cast<uint32_t *>(orow);
+    const int nwords = (num_llr + 31) >> 5;
+    for (int w = tid; w < nwords; w += nt) {
+      uint32_t word = 0;
+      for (int q = 0; q < 32; q++) {
+        const int bit = 32 * w + q;
+        if (bit < ncz) {
+          const int c = (int)ldpc_umulhi((uint32_t)bit, zr_magic), u = bit - c * zr;
+          const uint32_t neg = L.app[c * astride + v * pa + SUB * u + sub] < 128;
+          word |= neg << ((q & ~7) + 7 - (q & 7)); /* byte q / 8 of the word, MSB first inside the byte */
+        }
+      }
+      o[w] = word;
+    }
+  } else {
+    for (int i = tid; i < num_llr; i += nt) {
+      int8_t val = 0;
+      if (i < ncz) {
+        const int c = (int)ldpc_umulhi((uint32_t)i, zr_magic), u = i - c * zr;
+        val = (int8_t)(L.app[c * astride + v * pa + SUB * u + sub] < 128);
+      }
+      orow[i] = val;
+    }
+  }
+}
+
+/* blocks first .. first + n_valid - 1 of the launch (n_valid <= f_mb * SUB); results to a.out / a.n_iter */
+template <int SUB>
 __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_dec_args &a, uint32_t first, int n_valid)
 {
   const int Z = code->Z, zq = code->f_zq, zqb = code->f_zqb, rstride = code->f_rstride, astride = code->f_astride;
@@ -50,8 +114,13 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
   const int tid = (int)threadIdx.x, nt = (int)blockDim.x, lane = tid & 63;
   const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
   const int n_app = ncore * zq, n_ext = (code->ncols - ncore) * zq;
+  const int zr = Z / SUB; /* the real code's lifting size */
+  const int n_groups = (n_valid + SUB - 1) / SUB; /* groups (SUB = 1: blocks) that hold at least one real block */
   const uint32_t stride4 = a.llr_stride >> 2;
   const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (size_t)first * a.llr_stride);
+  const int8_t *__restrict__ src8 = a.llr + (size_t)first * a.llr_stride;
+  uint32_t *llr_lds = reinterpret_cast<uint32_t *>(fsm + code->f_lds_llr); /* SUB = 4: [ncore][f_mb][Z / 4] interleaved channel LLRs */
+  (void)src32; (void)src8; (void)llr_lds; (void)ncz; (void)z_magic; (void)zr; (void)num_llr;
   const int max_pass = a.num_max_iter + 1;
 
   /* ---- tables and state into LDS ------------------------------------------------------------------------ */
@@ -74,6 +143,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
     flags[LDPC_MB_CRC + tid] = 0;
     flags[LDPC_MB_ACT + tid] = tid < n_valid;
     flags[LDPC_MB_NIT + tid] = max_pass;
+    flags[LDPC_MB_OUT + tid] = 0;
   }
   {
     const int nr4 = (nedges * rstride) >> 2;
@@ -82,18 +152,46 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
       r32[i] = 0x80808080u;
   }
   /* APP := channel LLR (both copies) and the extension columns' LLRs, block by block */
-  for (int b = 0; b < n_valid; b++) {
-    const uint32_t *sb = src32 + (size_t)b * stride4;
-    for (int i = tid; i < n_app; i += nt) {
-      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
-      const uint32_t w = sb[i] ^ 0x80808080u;
-      uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + b * pa) + j;
-      dst[0] = w;
-      dst[zq] = w;
+  if (SUB == 1) {
+    for (int b = 0; b < n_valid; b++) {
+      const uint32_t *sb = src32 + (size_t)b * stride4;
+      for (int i = tid; i < n_app; i += nt) {
+        const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+        const uint32_t w = sb[i] ^ 0x80808080u;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + b * pa) + j;
+        dst[0] = w;
+        dst[zq] = w;
+      }
+      for (int i = tid; i < n_ext; i += nt) {
+        const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+        reinterpret_cast<uint32_t *>(L.ext + c * rstride + b * pr)[j] = sb[n_app + i] ^ 0x80808080u;
+      }
     }
-    for (int i = tid; i < n_ext; i += nt) {
-      const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
-      reinterpret_cast<uint32_t *>(L.ext + c * rstride + b * pr)[j] = sb[n_app + i] ^ 0x80808080u;
+  } else {
+    /* dword (column c, real lane t) of group v = the four blocks' LLR bytes at c * zr + t (zero for a block beyond the
+     * batch); n_app / n_ext count exactly these dwords per group (zq = Z / 4 = zr) */
+    for (int v = 0; v < n_groups; v++) {
+      const int8_t *sb = src8 + (size_t)(SUB * v) * a.llr_stride;
+      const int nsub = n_valid - SUB * v; /* real blocks in this group (>= 1) */
+      for (int i = tid; i < n_app + n_ext; i += nt) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < SUB; q++)
+          if (q < nsub)
+            w |= (uint32_t)(uint8_t)sb[(size_t)q * a.llr_stride + i] << (8 * q);
+        const uint32_t wb = w ^ 0x80808080u;
+        if (i < n_app) {
+          const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
+          uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + v * pa) + j;
+          dst[0] = wb;
+          dst[zq] = wb;
+          llr_lds[(c * code->f_mb + v) * zq + j] = w;
+        } else {
+          const int k = i - n_app;
+          const int c = (int)ldpc_umulhi((uint32_t)k, zq_magic), j = k - c * zq;
+          reinterpret_cast<uint32_t *>(L.ext + c * rstride + v * pr)[j] = wb;
+        }
+      }
     }
   }
   __syncthreads();
@@ -101,6 +199,22 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
   /* ---- passes ------------------------------------------------------------------------------------------ */
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
   const int use_crc = a.use_crc;
+  /* is group / block g still worked on?  SUB = 1: the block's own flag; SUB = 4: any of its four */
+  auto group_active = [&](int g) -> bool {
+    if (SUB == 1)
+      return flags[LDPC_MB_ACT + g] != 0;
+    const int4 f = *reinterpret_cast<const int4 *>(&flags[LDPC_MB_ACT + SUB * g]);
+    return (f.x | f.y | f.z | f.w) != 0;
+  };
+  /* SUB = 4: rows of the blocks that have just stopped (flags[LDPC_MB_OUT]) -- called between two barriers while their
+   * APP bytes are what the stop was decided on */
+  auto flush_stopped = [&]() {
+    if (SUB == 1)
+      return;
+    for (int blk = 0; blk < n_valid; blk++)
+      if (flags[LDPC_MB_OUT + blk] && (!use_crc || flags[LDPC_MB_NIT + blk] >= 3))
+        ldpc_mb_write_out<SUB>(L, code, a, first + blk, blk / SUB, blk % SUB, tid, nt);
+  };
   for (int p = 1; p <= max_pass; ++p) {
     for (;;) {
       const int task = ldpc_draw(&flags[0], lane);
@@ -113,13 +227,21 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
         const int gi = item - gstart;
         const int rig = (int)ldpc_umulhi((uint32_t)gi, zqb_magic), jb = gi - rig * zqb;
         const int b = (int)ldpc_umulhi((uint32_t)jb, zq_magic), j = jb - b * zq;
-        if (flags[LDPC_MB_ACT + b]) {
+        if (b < n_groups && group_active(b)) {
           const uint32_t rowrec = rowtbl[srow0 + rig];
           const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
           const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride, b * pr, b * pa);
           const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-          if (m & mask)
-            flags[LDPC_MB_SYN(p & 1) + b] = 1; /* (same value from every lane that writes) */
+          const uint32_t bad = m & mask;
+          if (SUB == 1) {
+            if (bad)
+              flags[LDPC_MB_SYN(p & 1) + b] = 1; /* (same value from every lane that writes) */
+          } else { /* bit i = lane 4j + i of the virtual code = lane j of block i */
+#pragma unroll
+            for (int q = 0; q < SUB; q++)
+              if (bad & (1u << q))
+                flags[LDPC_MB_SYN(p & 1) + SUB * b + q] = 1;
+          }
         }
       }
     }
@@ -130,11 +252,18 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
     if (tid < n_valid && flags[LDPC_MB_ACT + tid] && !use_crc && p >= 3 && flags[LDPC_MB_SYN(p & 1) + tid] == 0) {
       flags[LDPC_MB_NIT + tid] = p - 1;
       flags[LDPC_MB_ACT + tid] = 0;
+      flags[LDPC_MB_OUT + tid] = 1;
       atomicAdd(&flags[2], 1);
     }
     __syncthreads();
+    flush_stopped();
     if (flags[2] >= n_valid)
       break;
+    if (SUB != 1) {
+      __syncthreads();
+      if (tid < LDPC_MB_MAX)
+        flags[LDPC_MB_OUT + tid] = 0;
+    }
     for (;;) {
       const int ticket = ldpc_draw(&flags[1], lane);
       if (ticket * bn_group >= n_bn_tasks)
@@ -145,9 +274,10 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
         if (item < end) {
           const int sc = (int)ldpc_umulhi((uint32_t)item, zqb_magic), jb = item - sc * zqb;
           const int b = (int)ldpc_umulhi((uint32_t)jb, zq_magic), j = jb - b * zq;
-          if (flags[LDPC_MB_ACT + b]) {
+          if (b < n_groups && group_active(b)) {
             const uint32_t colrec = coltbl[sc];
-            const uint32_t lw = src32[(size_t)b * stride4 + (uint32_t)((int)(colrec & 0xffu) * zq + j)];
+            const int c = (int)(colrec & 0xffu);
+            const uint32_t lw = SUB == 1 ? src32[(size_t)b * stride4 + (uint32_t)(c * zq + j)] : llr_lds[(c * code->f_mb + b) * zq + j];
             ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw, b * pr, b * pa);
           }
         }
@@ -163,67 +293,61 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
     if (use_crc && p >= 3) { /* decoder.c:849-861, per block; see ldpc_dec_generic_block.h for the CRC argument */
       const int crcE = a.E;
       const uint32_t *crc_pow = a.crc_pow;
-      for (int b = 0; b < n_valid; b++) {
-        if (!flags[LDPC_MB_ACT + b])
+      for (int blk = 0; blk < n_valid; blk++) {
+        if (!flags[LDPC_MB_ACT + blk])
           continue;
         uint32_t x = 0;
-        for (int i = 4 * tid; i < crcE; i += 4 * nt) {
-          const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
-          const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + b * pa + u);
-          const uint4 pw = *reinterpret_cast<const uint4 *>(crc_pow + (crcE - 4 - i));
-          x ^= (pw.w & (0u - ((nb >> 7) & 1u))) ^ (pw.z & (0u - ((nb >> 15) & 1u))) ^ (pw.y & (0u - ((nb >> 23) & 1u))) ^
-               (pw.x & (0u - (nb >> 31)));
+        if (SUB == 1) {
+          for (int i = 4 * tid; i < crcE; i += 4 * nt) {
+            const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
+            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + blk * pa + u);
+            const uint4 pw = *reinterpret_cast<const uint4 *>(crc_pow + (crcE - 4 - i));
+            x ^= (pw.w & (0u - ((nb >> 7) & 1u))) ^ (pw.z & (0u - ((nb >> 15) & 1u))) ^ (pw.y & (0u - ((nb >> 23) & 1u))) ^
+                 (pw.x & (0u - (nb >> 31)));
+          }
+        } else {
+          const uint32_t zr_magic = 0xffffffffu / (uint32_t)zr + 1u;
+          const int v = blk / SUB, sub = blk % SUB;
+          for (int i = tid; i < crcE; i += nt) {
+            const int c = (int)ldpc_umulhi((uint32_t)i, zr_magic), u = i - c * zr;
+            if (L.app[c * astride + v * pa + SUB * u + sub] < 128)
+              x ^= crc_pow[crcE - 1 - i];
+          }
         }
         for (int off = 32; off; off >>= 1)
           x ^= __shfl_xor(x, off);
         if (lane == 0 && x)
-          atomicXor(reinterpret_cast<unsigned int *>(&flags[LDPC_MB_CRC + b]), x);
+          atomicXor(reinterpret_cast<unsigned int *>(&flags[LDPC_MB_CRC + blk]), x);
       }
       __syncthreads();
       if (tid < n_valid && flags[LDPC_MB_ACT + tid] && flags[LDPC_MB_CRC + tid] == 0) {
         flags[LDPC_MB_NIT + tid] = p;
         flags[LDPC_MB_ACT + tid] = 0;
+        flags[LDPC_MB_OUT + tid] = 1;
         atomicAdd(&flags[2], 1);
       }
       __syncthreads();
+      flush_stopped();
       if (flags[2] >= n_valid)
         break;
+      if (SUB != 1) {
+        __syncthreads();
+        if (tid < LDPC_MB_MAX)
+          flags[LDPC_MB_OUT + tid] = 0;
+        __syncthreads();
+      }
     }
   }
 
-  /* ---- hard decisions ------------------------------------------------------------------------------------ */
-  for (int b = 0; b < n_valid; b++) {
-    const int n_iter = flags[LDPC_MB_NIT + b];
+  /* ---- hard decisions: SUB = 1 every block (a stopped block's APP words were left alone); SUB = 4 the blocks that never
+   * stopped ------------------------------------------------------------------------------------------------ */
+  for (int blk = 0; blk < n_valid; blk++) {
+    const int n_iter = flags[LDPC_MB_NIT + blk];
     if (use_crc && n_iter < 3)
       continue; /* decoder.c:849-861: p_out stays untouched */
-    int8_t *orow = a.out + (size_t)(first + b) * a.out_stride;
-    if (a.out_mode == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(orow);
-      const int nwords = (num_llr + 31) >> 5;
-      for (int w = tid; w < nwords; w += nt) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int bit = 32 * w + 4 * q;
-          if (bit < ncz) {
-            const int c = (int)ldpc_umulhi((uint32_t)bit, z_magic), u = bit - c * Z;
-            const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + b * pa + u);
-            const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
-            word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
-          }
-        }
-        o[w] = word;
-      }
-    } else {
-      for (int i = tid; i < num_llr; i += nt) {
-        int8_t v = 0;
-        if (i < ncz) {
-          const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
-          v = (int8_t)(L.app[c * astride + b * pa + u] < 128);
-        }
-        orow[i] = v;
-      }
-    }
+    if (SUB != 1 && !flags[LDPC_MB_ACT + blk])
+      continue; /* written when it stopped */
+    ldpc_mb_write_out<SUB>(L, code, a, first + blk, blk / SUB, blk % SUB, tid, nt);
   }
   if (tid < n_valid)
     a.n_iter[first + tid] = flags[LDPC_MB_NIT + tid];

@@ -119,21 +119,25 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
     a.n_iter[blockIdx.x] = n_iter;
 }
 
-/* small lifting sizes: f_mb blocks per workgroup (ldpc_dec_fast_mblock.h) */
+/* small lifting sizes: f_mb blocks (SUB = 4: f_mb groups of four byte-interleaved blocks) per workgroup
+ * (ldpc_dec_fast_mblock.h) */
+template <int SUB>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
-  const uint32_t first = blockIdx.x * (uint32_t)code->f_mb;
+  const uint32_t per_wg = (uint32_t)code->f_mb * SUB;
+  const uint32_t first = blockIdx.x * per_wg;
   const uint32_t left = a.n_blocks - first;
-  ldpc_dec_fast_mblock(fsm, code, a, first, left < (uint32_t)code->f_mb ? (int)left : code->f_mb);
+  ldpc_dec_fast_mblock<SUB>(fsm, code, a, first, left < per_wg ? (int)left : (int)per_wg);
 }
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[4] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel)};
-  for (int i = 0; i < 4; i++) {
+  const void *k[5] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>)};
+  for (int i = 0; i < 5; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -155,11 +159,16 @@ hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a0, const ldpc_code_d
 {
   if (n_blocks == 0)
     return hipSuccess;
-  if (a0.jobs || hc.f_mb < 2 || !hc.f_ok)
+  if (a0.jobs || !hc.f_ok || (hc.f_sub != 4 && hc.f_mb < 2))
     return hipErrorInvalidValue;
   ldpc_dec_args a = a0;
   a.n_blocks = n_blocks;
-  hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel, dim3((n_blocks + hc.f_mb - 1) / hc.f_mb), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  const uint32_t per_wg = (uint32_t)hc.f_mb * (uint32_t)hc.f_sub;
+  const dim3 grid((n_blocks + per_wg - 1) / per_wg), block(hc.f_n_threads);
+  if (hc.f_sub == 4)
+    hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<4>, grid, block, hc.f_lds_total, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<1>, grid, block, hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 

@@ -48,6 +48,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
   const int zq1 = Z / 4;
   const int zq = zq1 * mb; /* items per lifted row / column: all blocks of the workgroup (mb = 1: the one block) */
   d->f_mb = mb;
+  if (d->f_sub != 4)
+    d->f_sub = 1;
   d->f_zq = zq1;
   d->f_zq_magic = (uint32_t)((0x100000000ULL + (uint64_t)zq1 - 1) / (uint64_t)zq1);
   d->f_zqb = zq;
@@ -145,10 +147,11 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
 
   /* LDS layout.  The channel LLRs of the degree-1 columns are read once per pass by one check-node edge each; when
    * leaving them in global memory (L2) lets one more workgroup fit on a CU, they are not staged (f_ext_global). */
-  const int ext_bytes = mb > 1 ? align16((d->ncols - d->ncore) * d->f_rstride) : align16((d->ncols - d->ncore) * Z);
-  const int misc_bytes = mb > 1 ? 512 : 64;
+  const int ext_bytes = (mb > 1 || d->f_sub == 4) ? align16((d->ncols - d->ncore) * d->f_rstride) : align16((d->ncols - d->ncore) * Z);
+  const int misc_bytes = (d->f_sub == 4 || mb > 1) ? 1664 : 64; /* ldpc_dec_fast_mblock.h: per-block flag arrays */
+  const int llr_bytes = d->f_sub == 4 ? align16(d->ncore * d->f_astride / 2) : 0; /* [ncore][mb][Z] */
   const int fixed = align16(d->nedges * d->f_rstride) + align16(d->ncore * d->f_astride) + align16(d->nedges * 4) +
-                    align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(mb * (Z + 4)) + misc_bytes;
+                    align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(mb * (Z + 4)) + misc_bytes + llr_bytes;
   /* Workgroup shape.  A CU holds 16 waves of this kernel (<= 128 VGPRs), so the waves per workgroup w and the
    * workgroups per CU k are chosen together: maximise the resident waves k*w subject to k workgroups fitting in the
    * 160 KiB of LDS (with or without the staged extension LLRs) and w <= check-node tasks; w a multiple of 4 so that the
@@ -168,7 +171,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
     for (int w = LDPC_F_MAX_WAVES; w >= 1; w = (w > 4 ? w - 4 : w - 1)) {
       if (w > nt)
         continue;
-      for (int eg = 0; eg <= (mb > 1 ? 0 : 1); eg++) {
+      for (int eg = 0; eg <= ((mb > 1 || d->f_sub == 4) ? 0 : 1); eg++) {
         int k = lds_cu / (fixed + (eg ? 0 : ext_bytes));
         if (k > 16 / w) k = 16 / w;
         if (k > 8) k = 8;
@@ -184,7 +187,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
     if (env && atoi(env) >= 1 && atoi(env) <= LDPC_F_MAX_WAVES)
       waves = atoi(env) < nt ? atoi(env) : nt;
     const char *eg = getenv("NRLDPC_HIP_EXT_GLOBAL");
-    if (eg && (eg[0] == '0' || eg[0] == '1') && mb == 1)
+    if (eg && (eg[0] == '0' || eg[0] == '1') && mb == 1 && d->f_sub != 4)
       d->f_ext_global = eg[0] == '1';
   }
   {
@@ -221,7 +224,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
   d->f_lds_rowtbl = d->f_lds_ctbl + align16(d->f_n_ctbl * 8);
   d->f_lds_coltbl = d->f_lds_rowtbl + align16(d->nrows * 4);
   d->f_lds_zero = d->f_lds_coltbl + align16(d->ncore * 4);
-  d->f_lds_misc = d->f_lds_zero + align16(mb * (Z + 4));
+  d->f_lds_llr = d->f_lds_zero + align16(mb * (Z + 4));
+  d->f_lds_misc = d->f_lds_llr + llr_bytes;
   d->f_lds_total = d->f_lds_misc + misc_bytes;
   if (d->f_lds_total > 160 * 1024)
     return;
@@ -233,7 +237,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
     const int c = d->e_col[e], s = (int)(d->e_info[e] & 0xffffu);
     d->f_etbl[e] = c < d->ncore ? (uint32_t)(d->f_lds_app + c * d->f_astride + s)
                                 : (d->f_ext_global ? (uint32_t)(c * Z)
-                                                   : (uint32_t)(d->f_lds_ext + (c - d->ncore) * (mb > 1 ? d->f_rstride : Z)));
+                                                   : (uint32_t)(d->f_lds_ext + (c - d->ncore) * ((mb > 1 || d->f_sub == 4) ? d->f_rstride : Z)));
   }
   d->f_ok = 1;
 }
@@ -463,6 +467,26 @@ int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d
     d->f_ok = 0;
     return 0;
   }
+  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb);
+  return 0;
+}
+
+int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_desc_t *d)
+{
+  if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_THROUGHPUT, d) != 0)
+    return -1;
+  d->f_ok = 0;
+  if (mb < 1 || mb > 16 || 4 * Z > LDPC_MAX_Z)
+    return 0;
+  /* the virtual code: lane 4t + i = lane t of block i; a shift by s lanes of every block = a shift by 4s virtual lanes */
+  for (int e = 0; e < d->nedges; e++)
+    d->e_info[e] = (d->e_info[e] & 0xffff0000u) | (4u * (d->e_info[e] & 0xffffu));
+  for (int k = 0; k < d->col_ptr[d->ncore]; k++)
+    d->col_edge[k] = (d->col_edge[k] & 0xffff0000u) | (4u * (d->col_edge[k] & 0xffffu));
+  for (int r = 0; r < d->nrows; r++)
+    d->pc_lo[r] *= 4;
+  d->Z = 4 * Z; /* (num_llr, ncols, zw and the generic kernel's fields keep describing the real code) */
+  d->f_sub = 4;
   build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb);
   return 0;
 }

@@ -114,6 +114,12 @@ typedef struct ldpc_code_desc {
    * boff_r / boff_a).  Kernel: ldpc_dec_fast_mblock.h. */
   int32_t f_mb, f_zqb;
   uint32_t f_zqb_magic;
+  /* f_sub = 4: lifting sizes that are not multiples of 4.  FOUR code blocks are interleaved byte-wise -- byte i of the dword
+   * at (row, lane t) belongs to block i -- which is the same as ONE block of a code with lifting size 4 Zc whose shifts are
+   * 4 s: every window is an aligned dword, whatever Zc is.  The descriptor then describes that virtual code (Z = 4 Zc,
+   * shifts and pc_lo times 4; num_llr, ncols stay the real code's) and f_mb counts groups of four.  f_lds_llr: the core
+   * columns' channel LLRs in the interleaved layout (the bit-node phase reads them every pass).  f_sub = 1 otherwise. */
+  int32_t f_sub, f_lds_llr;
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus
@@ -129,6 +135,8 @@ int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d); /* = throug
 int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t *d);
 /* throughput shape with `mb` blocks per workgroup (f_ok = 0 when the code does not qualify or does not fit) */
 int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d);
+/* any Z: four blocks interleaved byte-wise (f_sub = 4), `mb` such groups per workgroup */
+int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_desc_t *d);
 /* blocks per workgroup that fill a 64-item task row by row for this lifting size; 1: not worth it */
 int ldpc_multi_blocks_for(int Z);
 /* set index iLS of lifting size Z (38.212 Table 5.3.2-1), -1 if Z is not a lifting size */

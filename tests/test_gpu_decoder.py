@@ -13,7 +13,9 @@ def kernels_for(Z):
     shape (0 and 2 would pick the shape from the batch size); 5 = its multi-block variant; all must match the oracle."""
     if Z % 4 == 0 and 8 <= Z <= 64:
         return (1, 3, 4, 5)          # 5: several blocks per workgroup (small lifting sizes)
-    return (1, 3, 4) if (Z % 4 == 0 and Z >= 8) else (1,)
+    if Z % 4 == 0 and Z >= 8:
+        return (1, 3, 4)
+    return (1, 5) if Z <= 30 else (1,)   # 5: four blocks interleaved byte-wise (any Zc)
 
 
 def _compare(hip, BG, Z, R, llrs, it, mode=0, use_crc=False, E=0, ct=1):
@@ -265,47 +267,47 @@ def test_host_buffer_paths(hip, cfg):
                     assert (dst[:, (ob + 3) // 4 * 4:] == 0x5a).all()
 
 
-@pytest.mark.parametrize("cfg", [(1, 32, 13), (1, 8, 89), (2, 16, 15), (2, 48, 13), (1, 64, 23), (2, 24, 23)])
+@pytest.mark.parametrize("cfg", [(1, 32, 13), (1, 8, 89), (2, 16, 15), (2, 48, 13), (1, 64, 23), (2, 24, 23),
+                                 (1, 30, 13), (2, 15, 15), (1, 7, 89), (2, 2, 23), (1, 26, 23), (2, 4, 13), (1, 13, 13)])
 def test_small_lifting_sizes_several_blocks_per_workgroup(hip, cfg):
-    """Zc <= 64: a batch that fills the GPU is decoded with several code blocks per workgroup (ldpc_dec_fast_mblock.h).
-    Blocks of one workgroup stop at different passes (mixed SNRs, some never), the last workgroup is partly filled, in
-    parity-check and in CRC mode: all blocks equal the oracle (vectorisable restatement, itself pinned to the scalar one),
-    and the automatic choice (kernel 0) gives the same as the forced one (kernel 5)."""
+    """Zc <= 64: a batch that fills the GPU is decoded with several code blocks per workgroup (ldpc_dec_fast_mblock.h):
+    side by side for Zc % 4 == 0, four interleaved byte-wise for the other lifting sizes.  Blocks of one workgroup stop at
+    different passes (mixed SNRs, some never), the last workgroup is partly filled, in parity-check and in CRC mode: all
+    blocks equal the oracle, and the automatic choice (kernel 0) gives the same as the forced one (kernel 5)."""
     import torch
     BG, Z, R = cfg
     rng = np.random.default_rng(31 * Z + R + BG)
     K = kbits(BG, Z)
-    info = hip.ldpc.code_info(BG, Z, R)
-    n = 256 * 8 * 16 + 37 if Z <= 16 else 256 * 2 * (64 // (Z // 4)) + 37
+    per_wg = 64 // (Z // 4) if (Z % 4 == 0 and Z >= 8) else 4 * min(16, max(1, 64 // Z))
+    n = 256 * (8 if Z <= 16 else 2) * min(per_wg, 64) + 37
     row = hip.ldpc.num_llr(BG, Z, R)
     base = []
     for i in range(24):
         inf = random_info(rng, BG, Z)
-        crc = O.crc("crc24b", inf, K - 24) >> 8
-        inf[K // 8 - 3:K // 8] = [(crc >> 16) & 255, (crc >> 8) & 255, crc & 255]
+        if K >= 48:
+            crc = O.crc("crc24b", inf, K - 24) >> 8
+            inf[K // 8 - 3:K // 8] = [(crc >> 16) & 255, (crc >> 8) & 255, crc & 255]
         base.append(make_llr(rng, BG, Z, R, float(rng.choice([-4.0, -1.0, 0.5, 2.0, 5.0])), inf))
     base.append(make_llr(rng, BG, Z, R, "rand"))
     base.append(np.zeros(row, np.int8))
     idx = rng.integers(0, len(base), n)
-    llr_h = np.stack(base)[idx]
-    llr = torch.from_numpy(llr_h).cuda()
+    llr = torch.from_numpy(np.stack(base)[idx]).cuda()
     ob = hip.ldpc.out_bytes(BG, Z, R)
-    for use_crc in (False, True):
+    modes = (False, True) if (K >= 48 and K % 8 == 0) else (False,)
+    for use_crc in modes:
         refs = [O.decode(BG, Z, R, b, 8, 0, use_crc, K if use_crc else 0, 1, out_init=0x77) for b in base]
-        res = {}
+        exp_it = np.array([r[0] for r in refs], np.int32)[idx]
+        exp_out = np.stack([r[1] for r in refs])[idx]
         for kern in (5, 0):
             out = torch.full((n, ob), 0x77, dtype=torch.uint8, device="cuda")
             it = torch.zeros(n, dtype=torch.int32, device="cuda")
             hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8, check_crc=use_crc, E=K if use_crc else 0, crc_type=1, kernel=kern)
             torch.cuda.synchronize()
-            res[kern] = (it.cpu().numpy(), out.cpu().numpy())
-        for kern in (5, 0):
-            it_h, out_h = res[kern]
-            for i in range(n):
-                n_ref, out_ref = refs[idx[i]]
-                assert n_ref == it_h[i], (cfg, use_crc, kern, i, n_ref, int(it_h[i]))
-                assert np.array_equal(out_ref, out_h[i]), (cfg, use_crc, kern, i)
-    assert info is not None
+            it_h, out_h = it.cpu().numpy(), out.cpu().numpy()
+            bad = np.nonzero(it_h != exp_it)[0]
+            assert bad.size == 0, (cfg, use_crc, kern, int(bad[0]), int(exp_it[bad[0]]), int(it_h[bad[0]]), bad.size)
+            bad = np.nonzero((out_h != exp_out).any(axis=1))[0]
+            assert bad.size == 0, (cfg, use_crc, kern, int(bad[0]), bad.size)
 
 
 def test_config3_mixed_bg2_batch_every_block(hip):
