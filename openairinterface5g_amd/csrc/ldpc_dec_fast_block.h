@@ -124,13 +124,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   if (tid < 8)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen,
                        [4], [5] task queues of the two phases */
-  {
-    const int nr4 = (nedges * rstride) >> 2;
-    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
-    for (int i = tid; i < nr4; i += nt)
-      r32[i] = 0x80808080u;
-  }
-  /* APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
+  /* (the message array is not initialised: the first check-node phase takes r = 0 without reading it and writes every
+   * message, wrap-around bytes included)
+   * APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
   uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -186,7 +182,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
         const uint32_t rowrec = rowtbl[srow0 + rig];
         const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
-        const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
+        /* pass 1: the messages are all 0 and are not read (nor initialised by the prologue) */
+        const uint32_t m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
+                                  : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         syn |= m & mask;
       }

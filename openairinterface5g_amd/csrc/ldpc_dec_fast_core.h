@@ -113,7 +113,9 @@ LDPC_HD uint32_t ldpc_window(const uint8_t *base, uint32_t off) { return ldpc_wi
  * 32-bit ALU ops that cannot carry between the halves by construction. */
 /* D1 pairs of one edge (see above) from the LDS words; `first` additionally folds the edge into the syndrome
  * accumulators (only wanted once per edge). */
-template <bool IS_EXT>
+/* P1 = first pass of a block: every message is still 0, `rw` is not looked at (the caller has not loaded it and the
+ * message array need not be initialised) */
+template <bool IS_EXT, bool P1 = false>
 LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uint32_t rw, bool first, uint32_t &dl, uint32_t &dh,
                                uint32_t &parw, uint32_t &extl, uint32_t &exth)
 {
@@ -124,8 +126,8 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
     al = ldpc_perm(0x80808080u, lw, 0x05010400u);
     ah = ldpc_perm(0x80808080u, lw, 0x05030402u);
     if (first) { /* hard decision of the degree-1 bit: sat8(llr + r) < 0 <=> llr' + r' < 256 (cnProc.h:940) */
-      extl = al + ldpc_perm(0u, rw, 0x0c010c00u);
-      exth = ah + ldpc_perm(0u, rw, 0x0c030c02u);
+      extl = al + (P1 ? 0x00800080u : ldpc_perm(0u, rw, 0x0c010c00u));
+      exth = ah + (P1 ? 0x00800080u : ldpc_perm(0u, rw, 0x0c030c02u));
     }
     rl = 0x00800080u; /* this edge's CN input is the channel LLR itself (mPass.h:306-388) */
     rh = 0x00800080u;
@@ -135,8 +137,8 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
       parw ^= aw;
     al = ldpc_perm(0x80808080u, aw, 0x05010400u); /* (0x8000 | byte 0), (0x8000 | byte 1) */
     ah = ldpc_perm(0x80808080u, aw, 0x05030402u);
-    rl = ldpc_perm(0u, rw, 0x0c010c00u);
-    rh = ldpc_perm(0u, rw, 0x0c030c02u);
+    rl = P1 ? 0x00800080u : ldpc_perm(0u, rw, 0x0c010c00u);
+    rh = P1 ? 0x00800080u : ldpc_perm(0u, rw, 0x0c030c02u);
   }
   dl = al - rl;
   dh = ah - rh;
@@ -147,7 +149,7 @@ LDPC_HD void ldpc_fast_cn_edge(const ldpc_fast_lds &L, uint32_t info, int t, uin
  * live registers would otherwise spill at 16 waves per workgroup. */
 /* boff_r / boff_a (several blocks per workgroup, ldpc_dec_fast_mblock.h): byte offset of the item's block inside a
  * message / extension-LLR row resp. inside an APP row; 0 in the one-block kernels, where they fold away. */
-template <int D, bool EXT, int MODE>
+template <int D, bool EXT, int MODE, bool P1 = false>
 LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0, int boff_a = 0)
 {
   const int t = 4 * j + boff_r, ta = 4 * j + boff_a; /* t: position in message and extension rows; ta: in APP rows */
@@ -160,12 +162,12 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
 #pragma unroll
   for (int k = 0; k < D; k++) {
     const uint32_t info = L.etbl[e0 + k];
-    const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
+    const uint32_t rw = P1 ? 0u : *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
     uint32_t dl, dh;
     if (EXT && k == D - 1)
-      ldpc_fast_cn_edge<true>(L, info, t, rw, true, dl, dh, parw, extl, exth);
+      ldpc_fast_cn_edge<true, P1>(L, info, t, rw, true, dl, dh, parw, extl, exth);
     else
-      ldpc_fast_cn_edge<false>(L, info, ta, rw, true, dl, dh, parw, extl, exth);
+      ldpc_fast_cn_edge<false, P1>(L, info, ta, rw, true, dl, dh, parw, extl, exth);
     if (MODE <= 1) {
       d_lo[k] = dl;
       d_hi[k] = dh;
@@ -205,11 +207,11 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
       dh = d_hi[k];
     } else {
       const uint32_t info = L.etbl[e0 + k];
-      const uint32_t rw = *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
+      const uint32_t rw = P1 ? 0u : *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
       if (EXT && k == D - 1)
-        ldpc_fast_cn_edge<true>(L, info, t, rw, false, dl, dh, parw, extl, exth);
+        ldpc_fast_cn_edge<true, P1>(L, info, t, rw, false, dl, dh, parw, extl, exth);
       else
-        ldpc_fast_cn_edge<false>(L, info, ta, rw, false, dl, dh, parw, extl, exth);
+        ldpc_fast_cn_edge<false, P1>(L, info, ta, rw, false, dl, dh, parw, extl, exth);
     }
     const ldpc_v2u ml = KEEP ? ldpc_as_v2u(g_lo[k]) : ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     const ldpc_v2u mh = KEEP ? ldpc_as_v2u(g_hi[k]) : ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
@@ -278,25 +280,26 @@ LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, in
 #define LDPC_F_MODE_D19 2
 #endif
 /* dispatch on the task's (wave-uniform) degree */
+template <bool P1 = false>
 LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0,
                                        int boff_a = 0)
 {
   if (!ext) {
     switch (deg) {
-      case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19>(L, e0, j, Z, rstride, boff_r, boff_a);
-      case 10: return ldpc_fast_cn<10, false, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-      default: return ldpc_fast_cn<8, false, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+      case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+      case 10: return ldpc_fast_cn<10, false, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+      default: return ldpc_fast_cn<8, false, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
     }
   }
   switch (deg) {
-    case 3: return ldpc_fast_cn<3, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 4: return ldpc_fast_cn<4, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 5: return ldpc_fast_cn<5, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 6: return ldpc_fast_cn<6, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 7: return ldpc_fast_cn<7, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 8: return ldpc_fast_cn<8, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 9: return ldpc_fast_cn<9, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
-    default: return ldpc_fast_cn<10, true, 0>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 3: return ldpc_fast_cn<3, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 4: return ldpc_fast_cn<4, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 5: return ldpc_fast_cn<5, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 6: return ldpc_fast_cn<6, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 7: return ldpc_fast_cn<7, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 8: return ldpc_fast_cn<8, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 9: return ldpc_fast_cn<9, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    default: return ldpc_fast_cn<10, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
   }
 }
 

@@ -35,7 +35,9 @@ template <bool JOBS> struct ldpc_batch_io {
   }
   __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-  __device__ __forceinline__ bool eager_check() const { return false; }
+  /* homogeneous launches: the parity check of a pass right after it when the block is close to converging (a block that
+   * stops saves the next pass' check-node phase; one that does not converge never gets close and pays nothing) */
+  __device__ __forceinline__ bool eager_check() const { return !JOBS; }
   __device__ __forceinline__ bool tables_resident() const { return false; }
   __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
   __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { *p = make_uint4(x, y, z, t); }

@@ -212,9 +212,8 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
     const int next4 = code->f_ext_global ? 0 : (code->ncols - ncore) * zq;
     uint32_t *e32 = reinterpret_cast<uint32_t *>(L.ext);
     for (int i = 0; i < next4; i++) e32[i] = src32[ncore * zq + i] ^ 0x80808080u;
-    const int nr4 = (nedges * rstride) >> 2;
-    uint32_t *r32 = reinterpret_cast<uint32_t *>(L.r);
-    for (int i = 0; i < nr4; i++) r32[i] = 0x80808080u;
+    /* (the message array keeps the 0x5a poison: the first pass must not read it -- as in the kernel) */
+    (void)rstride;
   }
   const int max_pass = numMaxIter + 1;
   int n_iter = max_pass;
@@ -232,7 +231,8 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
           const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
           const uint32_t rowrec = rowtbl[srow0 + rig];
           const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
-          const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride);
+          const uint32_t m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
+                                    : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
           const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
           syn |= m & mask;
         }
