@@ -32,13 +32,22 @@ for k, v in sorted(acc.items()):
 PY
 done | tee $O/chain_pmc.txt
 echo "== abi"
-run() { echo "$1 T=$2 case=${4:-mix}: $(env $1 timeout 120 ./tests/abi_threads.bin $L $2 ${3:-400} $4 2>&1 | tail -1 | cut -c1-330)"; }
+run() { echo "$1 T=$2 case=${4:-mix}: $(env $1 timeout 60 ./tests/abi_threads.bin $L $2 ${3:-400} $4 2>&1 | tail -1 | cut -c1-330)"; }
 { run X=1 1 3000 1; run X=1 1 2000 0; run NRLDPC_HIP_SRV_BAR=0 1 3000 1; run NRLDPC_HIP_SERVER=0 1 1000 1
   for T in 1 4 16 32 64; do run X=1 $T 1000; done
   for T in 1 16 32; do run NRLDPC_HIP_SERVER=0 $T 300; done; } | tee $O/abi_threads.txt
 timeout 300 python tests/ldpctest_hip.py -l 8448 -s 10 -n 200 > $O/ldpctest_hip_8448.txt 2>&1; tail -3 $O/ldpctest_hip_8448.txt
 echo "== host path + ubench"
 timeout 120 python tools/host_path_sweep.py 2>&1 | grep chunk | tee $O/host_path.txt
+NRLDPC_HIP_HOST_PULL=0 timeout 120 python tools/host_path_sweep.py 2>&1 | grep chunk | sed "s/^/copy engine: /" | tee -a $O/host_path.txt
 timeout 120 tools/ubench/h2d_link.bin > $O/h2d_link.txt 2>&1; timeout 120 tools/ubench/hbm_rw.bin > $O/hbm_rw.txt 2>&1; timeout 120 tools/ubench/bar_write.bin > $O/bar_write.txt 2>&1
+echo "== small lifting sizes"
+C4="1,64,13 1,32,13 1,16,13 1,8,13 1,48,13 1,24,13 2,64,15 2,32,15 2,16,15 2,8,15"
+CX="1,30,13 1,26,13 1,22,13 1,15,13 1,7,13 1,2,13 2,30,15 2,15,15 2,7,15 2,3,15"
+{ echo "# Zc % 4 == 0, one block per workgroup (kernel 3), 32768 blocks"; SWEEP_KERNEL=3 timeout 300 python tools/sweep_codes.py 32768 $C4 2>&1 | grep -v amdgpu.ids
+  echo "# Zc % 4 == 0, several blocks per workgroup (kernel 0 = automatic)"; SWEEP_KERNEL=0 timeout 300 python tools/sweep_codes.py 32768 $C4 2>&1 | grep -v amdgpu.ids
+  echo "# other Zc, generic kernel (kernel 1)"; SWEEP_KERNEL=1 timeout 300 python tools/sweep_codes.py 32768 $CX 2>&1 | grep -v amdgpu.ids
+  echo "# other Zc, four blocks interleaved byte-wise, several groups per workgroup (kernel 0 = automatic)"; SWEEP_KERNEL=0 timeout 300 python tools/sweep_codes.py 32768 $CX 2>&1 | grep -v amdgpu.ids
+} > $O/small_lifting_sizes.txt; tail -12 $O/small_lifting_sizes.txt
 echo "== bench_extra"; timeout 900 python tools/bench_extra.py > $O/bench_extra.json 2> $O/bench_extra.err; echo rc=$?
 rm -rf $O/prof_bench/*/*trace.csv $O/prof_chain/*/*trace.csv   # keep the merge small
