@@ -303,19 +303,18 @@ LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L,
   }
 }
 
-/* One bit-node item: core column c, bits u..u+3 (u = 4j): APP = clamp_s8(llr + sum r) (bnProc.h:136-160).
- * colrec = f_coltbl entry of the column; maxdeg = wave-uniform loop bound >= the column's degree;
- * llr_word = the four channel LLRs (true int8 bytes). */
-LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, int j, int Z, int astride,
-                          uint32_t llr_word, int boff_r = 0, int boff_a = 0)
+/* One bit-node item: core column c, bits u..u+3 (u = 4j): APP = clamp_s8(llr + sum r) (bnProc.h:136-160), in two steps.
+ * ldpc_fast_bn_gather: acc_e / acc_o += the biased message bytes of the column's edges, as packed 16-bit sums of lanes
+ * (0,2) and (1,3).  colrec = f_coltbl entry of the column; maxdeg = wave-uniform loop bound >= the column's degree.
+ * The gather is a chain table entry -> address -> window per edge; four edges are kept in flight.  Table entry =
+ * {x = Z - shift, y = LDS address of the message row - (x & 3)}: u and Z are multiples of 4, so the window's byte
+ * phase is x & 3 for every item and y + p is the aligned dword that holds its first byte.  Columns with fewer than
+ * maxdeg edges are padded with entries that point at a row of zero bytes (contribution 0): no predication. */
+LDPC_HD void ldpc_fast_bn_gather(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, int j, int Z, int boff_r, uint32_t &acc_e,
+                                 uint32_t &acc_o)
 {
   const int u = 4 * j;
-  const int c = (int)(colrec & 0xffu), deg = (int)((colrec >> 8) & 0xffu), start = (int)(colrec >> 16);
-  uint32_t acc_e = 0, acc_o = 0; /* packed 16-bit sums of the biased bytes: lanes (0,2) and (1,3) */
-  /* The gather is a chain table entry -> address -> window per edge; four edges are kept in flight.  Table entry =
-   * {x = Z - shift, y = LDS address of the message row - (x & 3)}: u and Z are multiples of 4, so the window's byte
-   * phase is x & 3 for every item and y + p is the aligned dword that holds its first byte.  Columns with fewer than
-   * maxdeg edges are padded with entries that point at a row of zero bytes (contribution 0): no predication. */
+  const int start = (int)(colrec >> 16);
   const uint2 *tbl = reinterpret_cast<const uint2 *>(L.ctbl) + start;
   int k = 0;
   for (; k + 4 <= maxdeg; k += 4) {
@@ -341,6 +340,13 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
     acc_e += v & 0x00ff00ffu;
     acc_o += (v >> 8) & 0x00ff00ffu;
   }
+}
+/* ldpc_fast_bn_finish: the sums of ALL `deg` edges of column c (each byte biased by 128) + the channel LLRs (true int8
+ * bytes) -> clamped APP, stored twice */
+LDPC_HD void ldpc_fast_bn_finish(const ldpc_fast_lds &L, int c, int deg, int j, int Z, int astride, uint32_t llr_word, uint32_t acc_e,
+                                 uint32_t acc_o, int boff_a)
+{
+  const int u = 4 * j;
   const uint32_t lw = llr_word ^ 0x80808080u;
   acc_e += lw & 0x00ff00ffu;
   acc_o += (lw >> 8) & 0x00ff00ffu;
@@ -352,6 +358,13 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
   uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a);
   dst[0] = w;
   *reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a + Z) = w;
+}
+LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, int j, int Z, int astride,
+                          uint32_t llr_word, int boff_r = 0, int boff_a = 0)
+{
+  uint32_t acc_e = 0, acc_o = 0;
+  ldpc_fast_bn_gather(L, colrec, maxdeg, j, Z, boff_r, acc_e, acc_o);
+  ldpc_fast_bn_finish(L, (int)(colrec & 0xffu), (int)((colrec >> 8) & 0xffu), j, Z, astride, llr_word, acc_e, acc_o, boff_a);
 }
 
 /* hard decision of code bit `b` (< ncore*Z) from the biased APP store */

@@ -190,6 +190,20 @@ def LDPCdecoder(p_decParams, p_llr, p_out=None, ab=None, harq_pid=0, ulsch_id=0,
     return n, p_out
 
 
+def raw_decoder_call(p_decParams):
+    """(call, keep): `call(llr_address, out_address) -> numIter` is the bare C entry point LDPCdecoder with everything but
+    the two buffer addresses bound beforehand -- for callers that time the call itself, as ldpctest does with
+    start_meas / stop_meas around `LDPCdecoder(...)` (ldpctest.c:329-334), without this module's per-call marshalling."""
+    L = load_library()
+    proto = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    fn = proto(("LDPCdecoder", L))   # its own prototype object: L.LDPCdecoder keeps the typed one
+    pref = C.cast(C.pointer(p_decParams), C.c_void_p)
+
+    def call(llr_address, out_address):
+        return fn(pref, 0, 0, 0, llr_address, out_address, None, None)
+    return call, (p_decParams, pref)
+
+
 def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=None, block_length=None):
     """Up to 8 segments through the reference entry point (ldpc_encoder_optim8segmulti.c:46).
     inputs: list of uint8[K/8]; returns list of uint8[(66|50)*Zc] (one bit per byte) for ALL n_segments
