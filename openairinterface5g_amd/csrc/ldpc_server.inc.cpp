@@ -12,7 +12,8 @@
  * memory;
  * NRLDPC_HIP_SRV_SLOTS=<n> caller slots = workgroups = CUs the server occupies while it is up (default 64, more
  * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
- * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls).
+ * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls);
+ * NRLDPC_HIP_SRV_SPLIT=2|4 CUs per slot: large codes are decoded by that many workgroups together (ldpc_dec_fast_part.h).
  */
 #include <emmintrin.h>
 #include <atomic>
@@ -35,6 +36,7 @@ struct alignas(64) SrvSlotHost {
   uint64_t calls = 0; /* written by the slot's holder only */
   uint64_t ticks_stage = 0, ticks_decode = 0; /* GPU-side: doorbell seen -> payload staged -> block function returned */
   uint64_t ticks_prologue = 0, ticks_passes = 0; /* fast decoder: staged -> state in LDS -> last pass done */
+  uint64_t ticks_phase[5] = {0, 0, 0, 0, 0};     /* several CUs per block: the part decoder's phases (part 0) */
   double host_wait_s = 0, host_total_s = 0;   /* host-side: doorbell rung -> completion seen; whole call */
 };
 
@@ -66,7 +68,10 @@ int srv_init_locked()
   int n = 64;
   if ((e = getenv("NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
     n = atoi(e);
-  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / 2)));
+  const int parts = srv_parts();
+  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / (2 * parts))));
+  if (parts > 1)
+    n = std::max(8, n / 8 * 8); /* a slot's parts sit 8 workgroups apart (same XCD): slots come in eights */
   int idle_us = 20000;
   if ((e = getenv("NRLDPC_HIP_SRV_IDLE_US")) && atoi(e) >= 1)
     idle_us = atoi(e);
@@ -125,7 +130,14 @@ int srv_init_locked()
   a.state = static_cast<uint32_t *>(dp);
   HIP_TRY(hipHostGetDevicePointer(&dp, srv.host_stop, 0));
   a.host_stop = static_cast<const uint32_t *>(dp);
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * SRV_IN_STRIDE));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * parts * SRV_IN_STRIDE)); /* one row per workgroup */
+  a.parts = (uint32_t)parts;
+  if (parts > 1) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.exch), (size_t)n * 2 * parts * SRV_PART_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.meet), (size_t)n * 16 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.go), (size_t)n * 16 * sizeof(unsigned int)));
+    HIP_TRY(hipMemset(a.exch, 0, (size_t)n * 2 * parts * SRV_PART_STRIDE * sizeof(unsigned long long)));
+  }
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.gctl), sizeof(srv_gctl)));
   HIP_TRY(hipMemset(a.gctl, 0, sizeof(srv_gctl)));
   a.idle_ticks = (uint32_t)idle_us * 100u; /* wall_clock64: 100 MHz */
@@ -177,6 +189,10 @@ int srv_ensure_running()
   srv_args a = srv.args;
   a.gen = gcur + 1;
   UseDevice use(g.dev[0]);
+  if (a.parts > 1) { /* a generation starts with its meeting counters and go words at zero (behind the previous one: same stream) */
+    HIP_TRY(hipMemsetAsync(a.meet, 0, (size_t)srv.n_slots * 16 * sizeof(unsigned int), srv.stream));
+    HIP_TRY(hipMemsetAsync(a.go, 0, (size_t)srv.n_slots * 16 * sizeof(unsigned int), srv.stream));
+  }
   HIP_TRY(ldpc_server_launch(a, (uint32_t)srv.n_slots, srv.stream));
   srv.gen.store(gcur + 1, std::memory_order_release);
   return 0;
@@ -247,6 +263,7 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
   q->seg_in_stride = rq.seg_in_stride; q->seg_out_stride = rq.seg_out_stride; q->payload_bytes = rq.payload_bytes;
   q->code_lo = rq.code_lo; q->code_hi = rq.code_hi; q->kb_nseg = rq.kb_nseg;
   q->kind_mode = rq.kind_mode; q->max_pass = rq.max_pass; q->crcE = rq.crcE;
+  q->parts_lo = rq.parts_lo; q->parts_hi = rq.parts_hi;
   __builtin_ia32_sfence();
   __atomic_store_n(&c.req->tag3, seq, __ATOMIC_RELEASE);
   __atomic_store_n(&c.req->tag2, seq, __ATOMIC_RELEASE);
@@ -264,13 +281,19 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
       sched_yield(); /* callers outnumber cores on a loaded box: give the others the CPU while the GPU works */
   }
   h.host_wait_s += srv_now() - t_ring;
+  const int32_t n_rep = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
   if (n_iter)
-    *n_iter = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
+    *n_iter = n_rep;
+  if (n_rep == -2)
+    return set_error("resident server: a workgroup of the slot did not join the decode (protocol fault)");
   const uint32_t sd = c.ctl->t_stage_decode, pp = c.ctl->t_pro_passes;
   h.ticks_stage += sd & 0xffffu;
   h.ticks_decode += sd >> 16;
   h.ticks_prologue += pp & 0xffffu;
   h.ticks_passes += pp >> 16;
+  if (srv.args.parts > 1)
+    for (int k = 0; k < 5; k++)
+      h.ticks_phase[k] += c.ctl->pad1[k];
   return 0;
 }
 
@@ -302,6 +325,11 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   rq.code_lo = (uint32_t)code;
   rq.code_hi = (uint32_t)(code >> 32);
   rq.payload_bytes = (uint32_t)hl.num_llr;
+  if (kind == SRV_KIND_DEC_FAST && ce->dev_parts && srv.args.parts > 1) { /* all of the slot's CUs on this block */
+    const uint64_t pa = reinterpret_cast<uint64_t>(ce->dev_parts);
+    rq.parts_lo = (uint32_t)pa;
+    rq.parts_hi = (uint32_t)(pa >> 32);
+  }
   memcpy(c.in, llr, (size_t)hl.num_llr);
   int32_t n = 0;
   const int rc = srv_submit(c, rq, &n);

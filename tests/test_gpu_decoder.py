@@ -384,3 +384,19 @@ def test_concurrent_callers_of_the_reference_entry_point(hip, tmp_path):
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["failures"] == 0 and d["calls"] == 2400, extra
         assert d["served"] == (0 if extra.get("NRLDPC_HIP_SERVER") == "0" else 2400 + 12), (extra, d)
+
+
+def test_server_with_several_cus_per_block():
+    """NRLDPC_HIP_SRV_SPLIT=2: the resident server decodes a large code's block on two CUs (rows dealt to two workgroups,
+    partial column sums exchanged through device memory every pass: ldpc_dec_fast_part.h) and everything else through the
+    same body as a single part.  Opt-in (it is slower than one CU), but it must stay bit-exact: the oracle-checked
+    per-segment tests run once more under it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NRLDPC_HIP_SRV_SPLIT="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_decoder.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "per_segment or reference_entry or ldpctest_acceptance"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
