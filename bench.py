@@ -256,7 +256,11 @@ def main():
     # ---- strong scaling: one slot's transport blocks sharded over the ranks (configs[4]) --------------
     strong = None
     if not args.no_strong:
-        strong = strong_slot(pkg, torch, dist, world, rank, max(5, min(args.steps, 20)))
+        try:
+            strong = strong_slot(pkg, torch, dist, world, rank, max(5, min(args.steps, 20)))
+        except Exception as e:                      # the secondary experiment must not cost the headline line
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] strong-scaling slot failed on rank {rank}: {strong['error']}", file=sys.stderr, flush=True)
 
     if rank == 0:
         traffic, pmc = None, {}
