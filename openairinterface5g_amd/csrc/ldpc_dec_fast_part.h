@@ -39,6 +39,20 @@
 #define LDPC_PART_MAX_PARTS 4
 #define LDPC_PART_MEET_TIMEOUT_TICKS 2000000ll                 /* 20 ms of the 100 MHz clock */
 
+/* The exchange area is device (global) memory; through a generic pointer the compiler emits FLAT instructions, whose
+ * completion is counted together with the LDS traffic -- every LDS wait in the gather loop then also waits for the last
+ * published store to reach memory.  Typed as global, they are independent of the LDS pipe. */
+typedef __attribute__((address_space(1))) unsigned long long ldpc_gu64;
+typedef __attribute__((address_space(1))) unsigned int ldpc_gu32;
+__device__ __forceinline__ void ldpc_pub64(unsigned long long *p, unsigned long long v)
+{
+  __hip_atomic_store((ldpc_gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ldpc_get64(const unsigned long long *p)
+{
+  return __hip_atomic_load((ldpc_gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* all parts of the slot meet: every store this workgroup made before is visible to the others afterwards (they were
  * agent-scope stores, complete before the arrival is counted) */
 template <class IO> __device__ __forceinline__ void ldpc_part_meet(const IO &io)
@@ -48,7 +62,7 @@ template <class IO> __device__ __forceinline__ void ldpc_part_meet(const IO &io)
   if (io.tid() == 0) {
     const uint32_t target = *io.meet_target() + (uint32_t)io.parts();
     *io.meet_target() = target;
-    unsigned int *cnt = io.meet_counter();
+    ldpc_gu32 *cnt = (ldpc_gu32 *)io.meet_counter();
     __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -193,8 +207,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
           const uint32_t colrec = coltbl[sc];
           ldpc_fast_bn_gather(L, colrec, maxdeg, j, Z, 0, pe[k], po[k]);
           if (parts > 1)
-            __hip_atomic_store(mine + (int)(colrec & 0xffu) * zq + j, (unsigned long long)pe[k] | ((unsigned long long)po[k] << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ldpc_pub64(mine + (int)(colrec & 0xffu) * zq + j, (unsigned long long)pe[k] | ((unsigned long long)po[k] << 32));
         }
       }
     }
@@ -202,7 +215,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
     /* (parts == 1: the whole code in this workgroup -- small codes served by the same kernel: nothing to exchange) */
     if (parts > 1) {
       if (tid == 0)
-        __hip_atomic_store(mine + LDPC_PART_ITEMS_MAX, (unsigned long long)(unsigned int)flags[p & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ldpc_pub64(mine + LDPC_PART_ITEMS_MAX, (unsigned long long)(unsigned int)flags[p & 1]);
       ldpc_part_meet(io);
     }
     LDPC_PART_PHASE(2);
@@ -212,7 +225,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
 #pragma unroll
     for (int q = 0; q < LDPC_PART_MAX_PARTS; q++)
       hv[q] = (parts > 1 && q < parts)
-                  ? __hip_atomic_load(exp + (size_t)q * LDPC_PART_STRIDE + LDPC_PART_ITEMS_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                  ? ldpc_get64(exp + (size_t)q * LDPC_PART_STRIDE + LDPC_PART_ITEMS_MAX)
                   : 0ull;
     if (parts == 1)
       hv[0] = (unsigned long long)(unsigned int)flags[p & 1];
@@ -228,7 +241,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
 #pragma unroll
       for (int q = 0; q < LDPC_PART_MAX_PARTS; q++)
         dv[k][q] = (cidx[k] >= 0 && q < parts && q != part)
-                       ? __hip_atomic_load(exp + (size_t)q * LDPC_PART_STRIDE + cidx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       ? ldpc_get64(exp + (size_t)q * LDPC_PART_STRIDE + cidx[k])
                        : 0ull;
     }
     /* everybody's count of unsatisfied lanes after pass p - 1 (after the channel's hard decisions for p = 1) */
@@ -284,7 +297,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
       __syncthreads();
       if (tid == 0) {
         if (parts > 1)
-          __hip_atomic_store(mine + LDPC_PART_ITEMS_MAX + 1, (unsigned long long)(unsigned int)bad_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ldpc_pub64(mine + LDPC_PART_ITEMS_MAX + 1, (unsigned long long)(unsigned int)bad_own);
         flags[6] = 0;
       }
       if (parts > 1)
@@ -292,8 +305,7 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
       int bad = parts > 1 ? 0 : bad_own;
 #pragma unroll
       for (int q = 0; q < LDPC_PART_MAX_PARTS; q++)
-        bad += (parts > 1 && q < parts) ? (int)__hip_atomic_load(exp + (size_t)q * LDPC_PART_STRIDE + LDPC_PART_ITEMS_MAX + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0;
+        bad += (parts > 1 && q < parts) ? (int)ldpc_get64(exp + (size_t)q * LDPC_PART_STRIDE + LDPC_PART_ITEMS_MAX + 1) : 0;
       LDPC_PART_PHASE(4);
       if (LDPC_UNIFORM(bad) == 0) {
         n_iter = p;
