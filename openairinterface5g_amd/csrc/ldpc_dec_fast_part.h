@@ -35,7 +35,7 @@
 #define LDPC_PART_ITEMS_MAX (LDPC_MAX_CORE * (LDPC_MAX_Z / 4)) /* 2496 */
 #define LDPC_PART_STRIDE (LDPC_PART_ITEMS_MAX + 8)             /* + header words: [0] unsatisfied lanes of the check-node
                                                                    phase, [1] of the sweep after the pass */
-#define LDPC_PART_MAX_ITEMS_PER_THREAD 3                       /* ceil(2496 / 1024) */
+#define LDPC_PART_MAX_ITEMS_PER_THREAD 5                       /* ceil(2496 / 512): workgroups of 512 threads or more */
 #define LDPC_PART_MAX_PARTS 4
 #define LDPC_PART_MEET_TIMEOUT_TICKS 2000000ll                 /* 20 ms of the 100 MHz clock */
 

@@ -26,6 +26,10 @@
  * and reloaded once per request -- there is no scratch access inside the decoder's phases (checked in the
  * disassembly).  With the encoder's phases compiled in as well (SRV_WITH_ENCODER) the spills reach the hot loops, so
  * LDPCencoder calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
+/* the several-CUs server: 8 waves per workgroup and twice the registers per thread -- a part has at most half the check-node
+ * tasks of the whole code, and at the 128-VGPR limit of a 1024-thread workgroup the exchange's extra live state spills into
+ * scratch memory right in its shortest phases */
+#define SRV_THREADS_SPLIT 512
 #ifndef SRV_THREADS
 #define SRV_THREADS 1024
 #endif
@@ -126,7 +130,7 @@ __device__ __forceinline__ uint32_t srv_part_of(uint32_t bid, uint32_t parts) { 
 /* SPLIT: with the several-CUs-per-block path compiled in (launched when srv_args.parts > 1); the one-CU server does not
  * carry its code and registers */
 template <bool SPLIT>
-__global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
+__global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   uint32_t *bc = reinterpret_cast<uint32_t *>(fsm + SRV_BC_OFF); /* [0] doorbell / quit, [1] last served, [2], [3] time stamps, [4..19] request header */
@@ -377,7 +381,7 @@ hipError_t ldpc_server_init(void)
 hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream)
 {
   if (a.parts > 1)
-    hipLaunchKernelGGL(ldpc_server_kernel<true>, dim3(n_slots * a.parts), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(ldpc_server_kernel<true>, dim3(n_slots * a.parts), dim3(SRV_THREADS_SPLIT), SRV_LDS_BYTES, stream, a);
   else
     hipLaunchKernelGGL(ldpc_server_kernel<false>, dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
   return hipGetLastError();
