@@ -505,6 +505,7 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
   a.pull = nullptr;
   a.pull_stride = 0;
   a.n_blocks = 0;
+  a.pull_stagger_ticks = a.pull_first_round = 0;
   for (int i = 0; i < 4; i++)
     a.crc_pow_tbl[i] = G().crc_pow[i];
   if (a.use_crc) {
@@ -755,7 +756,13 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
       a.n_iter = c.iter_direct ? iter_dev + k0 : reinterpret_cast<int32_t *>(stage_out + iter_off) + k0;
       const bool lat = ce->use_latency(n_part, G().n_cus, b->kernel == 3 ? 1 : (b->kernel == 4 ? 2 : 0));
       a.code = lat ? ce->dev_lat : ce->dev;
-      HIP_TRY(ldpc_launch_dec_fast_pull(a, lat ? ce->host_lat : ce->host, n, s));
+      /* first-round stagger of the pull kernel (ticks of 10 ns between groups of 64 workgroups; only the first launch of a
+       * call, and only when it fills the GPU): NRLDPC_HIP_PULL_STAGGER_US, default 25 */
+      static const int stagger_us = [] { const char *e = getenv("NRLDPC_HIP_PULL_STAGGER_US"); return e ? atoi(e) : 25; }();
+      const ldpc_code_desc_t &hsel = lat ? ce->host_lat : ce->host;
+      a.pull_first_round = (uint32_t)(G().n_cus * std::max(1, hsel.f_wg_per_cu));
+      a.pull_stagger_ticks = (k0 == 0 && n >= a.pull_first_round) ? (uint32_t)stagger_us * 100u : 0u;
+      HIP_TRY(ldpc_launch_dec_fast_pull(a, hsel, n, s));
       hipEvent_t ev;
       if (c.event(c.chunks.size(), &ev) != 0)
         return -1;

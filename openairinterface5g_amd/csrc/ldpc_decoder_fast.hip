@@ -78,6 +78,14 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
   const int nb = code->num_llr, tid = (int)threadIdx.x, nt = (int)blockDim.x; /* Zc % 4 == 0: a multiple of 4 bytes */
   const uint8_t *src = reinterpret_cast<const uint8_t *>(a.pull) + (size_t)blockIdx.x * a.pull_stride;
   uint8_t *dst = reinterpret_cast<uint8_t *>(const_cast<int8_t *>(a.llr)) + (size_t)blockIdx.x * a.llr_stride;
+  /* The launch's first workgroups all start together and would pull together -- the link busy, no CU decoding, then the
+   * reverse.  64 workgroups saturate the link, so the first round's workgroups start in groups of 64, pull_stagger_ticks
+   * (10 ns each) apart: the first group decodes while the next one pulls, and the later rounds inherit the stagger. */
+  if (a.pull_stagger_ticks && blockIdx.x < a.pull_first_round) {
+    const long long until = (long long)wall_clock64() + (long long)(blockIdx.x >> 6) * (long long)a.pull_stagger_ticks;
+    while ((long long)wall_clock64() < until)
+      __builtin_amdgcn_s_sleep(32);
+  }
   if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
     const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
     uint4 *d16 = reinterpret_cast<uint4 *>(dst);

@@ -48,6 +48,7 @@ struct ldpc_dec_args {
   const int8_t *pull;
   uint32_t pull_stride;
   uint32_t n_blocks; /* multi-block launches: blocks in the launch (the last workgroup may hold fewer than f_mb) */
+  uint32_t pull_stagger_ticks, pull_first_round; /* pull launches: see ldpc_dec_fast_pull_kernel */
 };
 
 struct ldpc_enc_args {
