@@ -117,7 +117,8 @@ int32_t LDPCshutdown(void);
 /* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
  * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
  * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);
- * numMaxIter+2 when *ab was already set on entry.  Never negative, like the reference: an internal error (bad
+ * numMaxIter+2 when *ab was already set on entry or is raised by another thread while the call is running (looked at
+ * once per pass, decoder.c:556-559; p_out is then left as it was).  Never negative, like the reference: an internal error (bad
  * parameters, HIP failure) is reported as numMaxIter+1 with *ab set, so that callers which only test
  * `<= numMaxIter` (nr_ulsch_decoding.c:219-222) NACK; nrLDPC_hip_last_error() tells why.
  * Calls are served by a resident GPU kernel through per-thread mailboxes (no HIP runtime call per segment); see

@@ -932,7 +932,7 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
   if (ce) {
     rc = 1;
     if (srv_ready() == 0) /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp) */
-      rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter);
+      rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter, ab);
     if (rc == 1) { /* server switched off, or a code it cannot hold: one launch per call on this thread's stream */
       const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
       nrLDPC_hip_dec_batch_t b;

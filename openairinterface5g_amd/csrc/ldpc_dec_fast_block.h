@@ -29,6 +29,10 @@
  *   const uint32_t *crc_pow() x^j mod g, left aligned
  *   int out_mode()            0 packed bits, else one bit per byte
  *   int *tb_abort()           optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559)
+ *   uint32_t abort_load()     resident server: the slot's "caller gave up" word, loaded (past the caches) at the START of a
+ *   bool abort_is(word)       pass and looked at after its check-node phase -- the reference's per-iteration check_abort
+ *                             (decoder.c:556-559) for a caller whose `ab` is raised by another thread while the call is in
+ *                             flight; 0 / false elsewhere
  *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics)
  *   int tid()                 threadIdx.x
  *   uint32_t ld_llr(p)        one dword of src32_prologue()'s row: a plain load, or one that bypasses the caches when the
@@ -164,6 +168,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
+    const uint32_t ab_word = (tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
@@ -203,9 +208,11 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
       if (io.tb_abort() && p >= 2 && __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         flags[3] = 1;
+      if (p >= 2 && io.abort_is(ab_word))
+        flags[3] = 1;
     }
     __syncthreads();
-    if (io.tb_abort() && flags[3]) {
+    if (flags[3]) { /* (zero unless one of the two abort sources exists and fired) */
       n_iter = max_pass + 1;
       break;
     }

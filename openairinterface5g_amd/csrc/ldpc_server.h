@@ -91,6 +91,8 @@ typedef struct srv_args {
   const uint32_t *crc_pow_tbl[4];
   /* one block on several CUs (ldpc_dec_fast_part.h): `parts` workgroups per slot -- part 0 polls the request line and wakes
    * its siblings through go[slot] (sequence number of the request to join; 0xffffffff: leave) */
+  const uint32_t *abort_w; /* per slot (16 words apart), same kind of memory as req: == the request's sequence number when its
+                              caller has given the transport block up (decode_abort_t raised by another thread) */
   uint32_t parts;
   unsigned long long *exch; /* device, per slot: 2 x parts x LDPC_PART_STRIDE words */
   unsigned int *meet;       /* device, per slot (16 words apart): arrival counter; zeroed before every launch */

@@ -97,6 +97,9 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ const uint32_t *crc_pow() const { return a->crc_pow_tbl[LDPC_UNIFORM(rq->kind_mode >> 24) & 3u]; }
   __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu)); }
   __device__ __forceinline__ int *tb_abort() const { return nullptr; }
+  const uint32_t *abw_;
+  __device__ __forceinline__ uint32_t abort_load() const { return srv_ld_sys(abw_); }
+  __device__ __forceinline__ bool abort_is(uint32_t w) const { return w == tag_; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
       const bool resident = bc[20] == (uint32_t)pc && bc[21] == (uint32_t)(pc >> 32);
       srv_part_io io;
       io.rq = rq; io.host_llr = host_in; io.staged = staged; io.hout = hout; io.a = a; io.st = bc + 24; io.tid_ = tid_l;
-      io.resident_ = resident; io.tag_ = d;
+      io.resident_ = resident; io.tag_ = d; io.abw_ = a->abort_w + 16u * SRV_SLOT();
       io.part_ = (int)part; io.parts_ = (int)parts;
       io.exch_ = srv_sgpr(a->exch + (size_t)SRV_SLOT() * 2u * LDPC_UNIFORM(a->parts) * LDPC_PART_STRIDE);
       io.meet_ = srv_sgpr(a->meet + 16u * SRV_SLOT());
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
       const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
       /* bc[20], bc[21]: the code whose tables this workgroup's LDS holds (0: none) */
       const bool resident = bc[20] == LDPC_UNIFORM(rq->code_lo) && bc[21] == LDPC_UNIFORM(rq->code_hi);
-      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d};
+      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d, srv_sgpr(a->abort_w + 16u * SRV_SLOT())};
       n_iter = ldpc_dec_fast_block(fsm, code, io);
       if (threadIdx.x == 0) {
         bc[20] = rq->code_lo;

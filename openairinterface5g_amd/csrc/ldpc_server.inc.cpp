@@ -48,6 +48,7 @@ struct Server {
   srv_slot_ctl *ctl = nullptr;
   srv_req *req = nullptr;   /* request lines and payload areas: device memory written over the BAR, or host memory */
   uint8_t *in_h = nullptr, *out_h = nullptr;
+  uint32_t *abort_h = nullptr; /* per slot, 16 words apart: "the caller of request <seq> has given up" (same memory as req) */
   bool over_bar = false;
   uint32_t *state = nullptr, *host_stop = nullptr;
   hipStream_t stream = nullptr;
@@ -89,11 +90,12 @@ int srv_init_locked()
   srv.over_bar = large_bar == 1 && !(eb && atoi(eb) == 0);
   if (srv.over_bar) {
     uint8_t *blk = nullptr;
-    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&blk), (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE), hipDeviceMallocFinegrained) == hipSuccess) {
-      HIP_TRY(hipMemset(blk, 0, (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE)));
+    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&blk), (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE + 64), hipDeviceMallocFinegrained) == hipSuccess) {
+      HIP_TRY(hipMemset(blk, 0, (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE + 64)));
       HIP_TRY(hipDeviceSynchronize());
       srv.req = reinterpret_cast<srv_req *>(blk);
       srv.in_h = blk + (size_t)n * sizeof(srv_req);
+      srv.abort_h = reinterpret_cast<uint32_t *>(blk + (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE));
     } else {
       (void)hipGetLastError();
       srv.over_bar = false;
@@ -102,7 +104,9 @@ int srv_init_locked()
   if (!srv.over_bar) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.req), (size_t)n * sizeof(srv_req), flags));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.in_h), (size_t)n * SRV_IN_STRIDE, flags));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.abort_h), (size_t)n * 64, flags));
     memset(srv.req, 0, (size_t)n * sizeof(srv_req));
+    memset(srv.abort_h, 0, (size_t)n * 64);
   }
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.out_h), (size_t)n * SRV_OUT_STRIDE, flags));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&small), 256, flags));
@@ -118,7 +122,10 @@ int srv_init_locked()
   if (srv.over_bar) {
     a.req = srv.req;
     a.in_host = srv.in_h;
+    a.abort_w = srv.abort_h;
   } else {
+    HIP_TRY(hipHostGetDevicePointer(&dp, srv.abort_h, 0));
+    a.abort_w = static_cast<const uint32_t *>(dp);
     HIP_TRY(hipHostGetDevicePointer(&dp, srv.req, 0));
     a.req = static_cast<const srv_req *>(dp);
     HIP_TRY(hipHostGetDevicePointer(&dp, srv.in_h, 0));
@@ -249,7 +256,7 @@ void srv_release(const SrvCall &c) { srv.slots[c.slot].busy.store(0, std::memory
 
 /* publish the request header `rq` (tags still unset) in the slot's ctl line and wait for the completion word; returns
  * n_iter via *n_iter.  The payload must already be in the slot's input area. */
-int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
+int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter, decode_abort_t *ab = nullptr)
 {
   SrvSlotHost &h = srv.slots[c.slot];
   h.seq = h.seq + 1 >= 0xfffffff0u ? 1u : h.seq + 1;
@@ -270,9 +277,17 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
   __atomic_store_n(&c.req->tag1, seq, __ATOMIC_RELEASE);
   __atomic_store_n(&c.req->tag0, seq, __ATOMIC_RELEASE); /* (plain stores only: a locked instruction on BAR memory is a bus lock) */
   __builtin_ia32_sfence(); /* push the line out now */
+  bool told = false;
   for (uint32_t spins = 0;; spins++) {
     if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == seq)
       break;
+    /* decoder.c:556-559: the decoder looks at the transport block's abort flag every iteration; another worker may raise
+     * it while this call is in flight -- passed on to the GPU, which looks at the slot's word once per pass */
+    if (ab && !told && __atomic_load_n(reinterpret_cast<const volatile unsigned char *>(&ab->failed), __ATOMIC_RELAXED)) {
+      __atomic_store_n(srv.abort_h + 16 * c.slot, seq, __ATOMIC_RELEASE);
+      __builtin_ia32_sfence();
+      told = true;
+    }
     if ((spins & 7) == 0 && srv_ensure_running() != 0)
       return -1;
     if (spins < 32)
@@ -298,7 +313,7 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter)
 }
 
 /* 0: decoded through the server, 1: this code cannot be served (caller uses the launch path), -1: error */
-int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *llr, int8_t *out, int32_t *n_iter)
+int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *llr, int8_t *out, int32_t *n_iter, decode_abort_t *ab)
 {
   const ldpc_code_desc_t &hl = ce->host_lat;
   uint32_t kind;
@@ -332,10 +347,10 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   }
   memcpy(c.in, llr, (size_t)hl.num_llr);
   int32_t n = 0;
-  const int rc = srv_submit(c, rq, &n);
+  const int rc = srv_submit(c, rq, &n, ab);
   if (rc == 0) {
     *n_iter = n;
-    if (!a.use_crc || n >= 3) { /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
+    if ((!a.use_crc || n >= 3) && n <= (int32_t)p->numMaxIter + 1) { /* (numMaxIter + 2: given up on the way, nothing was written) */ /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
       if (kind == SRV_KIND_DEC_FAST) {
         /* 16-byte units {three output dwords, sequence number} (ldpc_server.h): a unit is there when it shows this call's
          * number; one aligned 16-byte load per look, so a unit is never seen half written */

@@ -114,6 +114,43 @@ def test_reference_entry_point_and_abort(hip):
     assert n == n_ref and np.array_equal(out, out_ref)
 
 
+def test_abort_raised_by_another_thread_during_a_call(hip):
+    """decoder.c:556-559: the decoder looks at the transport block's abort flag at every iteration, so a sibling segment
+    that fails on another worker stops a decode that is already running.  Here: a block that cannot converge with
+    numMaxIter = 250 (3 ms on one CU); another thread raises `ab` 0.3 ms into the call; the call comes back early with
+    numMaxIter + 2 and leaves p_out alone.  (Resident-server path; with NRLDPC_HIP_SERVER=0 the flag is only looked at
+    on entry.)"""
+    import threading
+    import time
+    BG, Z, R = 1, 384, 13
+    rng = np.random.default_rng(77)
+    bad = make_llr(rng, BG, Z, R, "rand")
+    p = hip.make_dec_params(BG, Z, R, 250)
+    out = np.full(hip.ldpc.out_bytes(BG, Z, R), 0x6b, np.uint8)
+    t0 = time.perf_counter()
+    n_full, _ = hip.LDPCdecoder(p, bad, p_out=out.copy())
+    t_full = time.perf_counter() - t0
+    assert n_full == 251                              # never converges: all 251 passes
+    if hip.ldpc.server_stats()["calls"] == 0:
+        pytest.skip("resident server not in use")
+    for _ in range(3):
+        ab = hip.ldpc.decode_abort_t()
+
+        def raise_it():
+            time.sleep(0.0003)
+            ab.failed = True
+        th = threading.Thread(target=raise_it)
+        th.start()
+        t0 = time.perf_counter()
+        n, o = hip.LDPCdecoder(p, bad, p_out=out.copy(), ab=ab)
+        dt = time.perf_counter() - t0
+        th.join()
+        if n == 252:
+            break
+    assert n == 252 and (o == 0x6b).all(), (n, dt, t_full)
+    assert dt < 0.7 * t_full, (dt, t_full)
+
+
 def test_per_segment_entry_point_every_code_and_mode(hip):
     """LDPCdecoder() -- served by the resident kernel through the caller's mailbox (csrc/ldpc_server.h) -- for every
     lifting size and decoder-rate mode of both base graphs, every output mode, parity-check and CRC stop, several
