@@ -33,7 +33,10 @@ while time.time() - t0 < budget:
     K = kbits(BG, Z)
     use_crc = bool(rng.integers(0, 2)) and K % 8 == 0 and K >= 48
     mode = 0 if use_crc else int(rng.integers(0, 3))
-    kern = int(rng.choice([0, 0, 1, 3, 4])) if (Z % 4 == 0 and Z >= 8) else int(rng.choice([0, 1]))
+    if Z % 4 == 0 and Z >= 8:      # 5: several blocks per workgroup (Zc <= 64) / four blocks interleaved (other small Zc)
+        kern = int(rng.choice([0, 0, 1, 3, 4, 5] if Z <= 64 else [0, 0, 1, 3, 4]))
+    else:
+        kern = int(rng.choice([0, 1, 5] if Z <= 30 else [0, 1]))
     base = [make_llr(rng, BG, Z, R, k, random_info(rng, BG, Z, with_crc24b=True)) for k in (-2.0, 0.0, 1.5, "rand", "sat")]
     llr = np.stack([base[int(rng.integers(0, len(base)))] for _ in range(n)])
     pre = np.full((n, (pkg.ldpc.out_bytes(BG, Z, R, mode) + 3) // 4 * 4), 0x33, np.uint8)
