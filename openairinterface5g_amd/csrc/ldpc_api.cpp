@@ -635,7 +635,8 @@ int32_t LDPCshutdown(void)
   /* The reference's LDPCshutdown is a no-op (nrLDPC_decoder.c:167).  Device objects are kept: the loader
    * maps the library RTLD_NODELETE (common/utils/load_module_shlib.c:160) and other threads may still be
    * inside a call.  The resident server kernel is asked to leave (a later call simply starts it again). */
-  srv_stop();
+  srv_stop(srv);
+  srv_stop(srv_e);
   return 0;
 }
 
@@ -931,7 +932,7 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
     set_error("null argument");
   if (ce) {
     rc = 1;
-    if (srv_ready() == 0) /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp) */
+    if (srv_ready(srv) == 0) /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp) */
       rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter, ab);
     if (rc == 1) { /* server switched off, or a code it cannot hold: one launch per call on this thread's stream */
       const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
@@ -1042,7 +1043,7 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
   const unsigned n = last - first;
   /* the reference's four meters (ldpc_encoder_optim8segmulti.c:120-210), with this library's phases: tinput = staging
    * the segments, tprep = nothing, tparity = the encode on the GPU, toutput = handing the code words back */
-  if (!shortened && srv_ready() == 0) {
+  if (!shortened && srv_ready(srv_e) == 0) {
     meter_start(impp->tinput);
     const int rc = srv_encode(ce, (int)impp->Kb, input, output, first, n, impp->tinput, impp->tprep, impp->tparity, impp->toutput);
     if (rc <= 0)

@@ -24,8 +24,8 @@
  * waves and 168 VGPRs (measured, profiles/r02/README.md).  Around the inlined decoders the server loop does not fit in
  * 128 VGPRs: ~20 registers spill, all of them per-thread addresses of the request fetch that are stored before the loop
  * and reloaded once per request -- there is no scratch access inside the decoder's phases (checked in the
- * disassembly).  With the encoder's phases compiled in as well (SRV_WITH_ENCODER) the spills reach the hot loops, so
- * LDPCencoder calls take the launch path (ldpc_api.cpp) and the encoder job type stays switched off. */
+ * disassembly).  With the encoder's phases compiled into the same kernel the spills reach the hot loops, so LDPCencoder
+ * calls are served by a kernel of their own (template parameter ENC: 86 VGPRs, its own slots and stream). */
 /* the several-CUs server: 8 waves per workgroup and twice the registers per thread -- a part has at most half the check-node
  * tasks of the whole code, and at the 128-VGPR limit of a 1024-thread workgroup the exchange's extra live state spills into
  * scratch memory right in its shortest phases */
@@ -34,9 +34,6 @@
 #define SRV_THREADS 1024
 #endif
 #define SRV_ENC_GROUP 128 /* threads per segment of an encoder call: 8 segments side by side in one workgroup */
-#ifndef SRV_WITH_ENCODER
-#define SRV_WITH_ENCODER 0
-#endif
 
 __device__ __forceinline__ uint32_t srv_ld_sys(const uint32_t *p)
 {
@@ -132,7 +129,9 @@ __device__ __forceinline__ uint32_t srv_part_of(uint32_t bid, uint32_t parts) { 
 
 /* SPLIT: with the several-CUs-per-block path compiled in (launched when srv_args.parts > 1); the one-CU server does not
  * carry its code and registers */
-template <bool SPLIT>
+/* ENC: the encoder server -- its own launch with its own slots, serving LDPCencoder calls only: the decoders' kernels do
+ * not carry the encoder's phases (with them inlined next to the decoder the spills reached the decoder's loops) */
+template <bool SPLIT, bool ENC = false>
 __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -241,7 +240,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
     uint8_t *hout = srv_sgpr(a->out_host + (size_t)SRV_SLOT() * SRV_OUT_STRIDE);
     int n_iter = 0;
     const bool split = SPLIT && kind == SRV_KIND_DEC_FAST && (LDPC_UNIFORM(rq->parts_lo) | LDPC_UNIFORM(rq->parts_hi)) != 0u;
-    if (SPLIT && kind == SRV_KIND_DEC_FAST) {
+    if (!ENC && SPLIT && kind == SRV_KIND_DEC_FAST) {
       /* The several-CUs server runs every fast-decoder request through ldpc_dec_fast_part.h -- one decoder body in the
        * kernel, not two competing for its registers: a request with part descriptors on all of the slot's CUs (part 0
        * wakes its siblings, every part takes its descriptor from the request's array), any other as a single part with
@@ -270,7 +269,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
       }
       if (bc[23])
         n_iter = -2; /* a part did not show up at a meeting: the host reports the call as failed */
-    } else if (!SPLIT && kind == SRV_KIND_DEC_FAST) {
+    } else if (!ENC && !SPLIT && kind == SRV_KIND_DEC_FAST) {
       int tid_l = (int)threadIdx.x;
       const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
       /* bc[20], bc[21]: the code whose tables this workgroup's LDS holds (0: none) */
@@ -281,7 +280,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
         bc[20] = rq->code_lo;
         bc[21] = rq->code_hi;
       }
-    } else if (kind == SRV_KIND_DEC_GENERIC) {
+    } else if (!ENC && kind == SRV_KIND_DEC_GENERIC) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       if (threadIdx.x == 0)
         bc[20] = bc[21] = 0; /* this block overwrites the LDS the fast decoder keeps its tables in */
@@ -295,8 +294,11 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
       io.out_mode = LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu));
       io.tb_abort = nullptr;
       n_iter = ldpc_dec_generic_block(reinterpret_cast<int8_t *>(fsm), code, io);
-    } else if (SRV_WITH_ENCODER && kind == SRV_KIND_ENC) {
-      /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases */
+    } else if (ENC && kind == SRV_KIND_ENC) {
+      /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases.  The segment
+       * bytes were written by the host while the kernel runs and are read with ordinary loads: acquire first (what the
+       * caches hold of the slot's payload area is the previous call's). */
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
       const int tid = threadIdx.x, grp = tid / SRV_ENC_GROUP, gt = tid - grp * SRV_ENC_GROUP;
       const int n_seg = LDPC_UNIFORM((int)(rq->kb_nseg >> 16)), Kb = LDPC_UNIFORM((int)(rq->kb_nseg & 0xffffu));
       const int words = ldpc_encp_lds_words(code->ncols, code->kb_full, code->Z, code->nrows, code->nedges);
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
 #undef SRV_PART
 }
 
-int ldpc_server_has_encoder(void) { return SRV_WITH_ENCODER; }
+int ldpc_server_has_encoder(void) { return 1; }
 
 hipError_t ldpc_server_init(void)
 {
@@ -378,12 +380,18 @@ hipError_t ldpc_server_init(void)
                                            SRV_LDS_BYTES);
   if (e != hipSuccess)
     return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SRV_LDS_BYTES);
+  const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SRV_LDS_BYTES);
+  if (e2 != hipSuccess)
+    return e2;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             SRV_LDS_BYTES);
 }
 
-hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream)
+hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream, int encoder)
 {
-  if (a.parts > 1)
+  if (encoder)
+    hipLaunchKernelGGL((ldpc_server_kernel<false, true>), dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
+  else if (a.parts > 1)
     hipLaunchKernelGGL(ldpc_server_kernel<true>, dim3(n_slots * a.parts), dim3(SRV_THREADS_SPLIT), SRV_LDS_BYTES, stream, a);
   else
     hipLaunchKernelGGL(ldpc_server_kernel<false>, dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);

@@ -22,7 +22,7 @@
 #include "ldpc_server.h"
 
 hipError_t ldpc_server_init(void);
-hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream);
+hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream, int encoder);
 int ldpc_server_has_encoder(void);
 
 namespace {
@@ -41,6 +41,7 @@ struct alignas(64) SrvSlotHost {
 };
 
 struct Server {
+  int role = 0;              /* 0: decoder server (LDPCdecoder), 1: encoder server (LDPCencoder): its own kernel, slots and stream */
   std::mutex mu;            /* init / launch / stop only -- never taken by a call that finds the server running */
   std::atomic<int> status{-1}; /* -1 not initialised, 0 usable, 1 disabled or failed */
   int n_slots = 0;
@@ -55,87 +56,93 @@ struct Server {
   std::atomic<uint32_t> gen{0};
   std::atomic<uint32_t> next_slot{0};
   SrvSlotHost *slots = nullptr;
-} srv;
+} srv, srv_e;
+const int srv_e_role_set = (srv_e.role = 1); /* (namespace-scope initialiser: runs before anything can call into the library) */
 
 void srv_stop_at_exit();
 
-int srv_init_locked()
+int srv_init_locked(Server &S)
 {
   const char *e = getenv("NRLDPC_HIP_SERVER");
   if (e && atoi(e) == 0) {
-    srv.status = 1;
+    S.status = 1;
     return 1;
   }
-  int n = 64;
-  if ((e = getenv("NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
+  if (S.role == 1 && (!ldpc_server_has_encoder() || ((e = getenv("NRLDPC_HIP_ENC_SERVER")) && atoi(e) == 0))) {
+    S.status = 1;
+    return 1;
+  }
+  /* the encoder server: LDPCencoder calls carry up to 8 segments each and there are far fewer of them than decoder calls */
+  int n = S.role == 1 ? 16 : 64;
+  if ((e = getenv(S.role == 1 ? "NRLDPC_HIP_ENC_SLOTS" : "NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
     n = atoi(e);
-  const int parts = srv_parts();
+  const int parts = S.role == 1 ? 1 : srv_parts();
   n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / (2 * parts))));
   if (parts > 1)
     n = std::max(8, n / 8 * 8); /* a slot's parts sit 8 workgroups apart (same XCD): slots come in eights */
   int idle_us = 20000;
   if ((e = getenv("NRLDPC_HIP_SRV_IDLE_US")) && atoi(e) >= 1)
     idle_us = atoi(e);
-  srv.status = 1; /* until everything below has worked */
+  S.status = 1; /* until everything below has worked */
   UseDevice use(g.dev[0]); /* the server lives on the primary device */
   HIP_TRY(ldpc_server_init());
   const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
   uint8_t *small = nullptr;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.ctl), (size_t)n * sizeof(srv_slot_ctl), flags));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.ctl), (size_t)n * sizeof(srv_slot_ctl), flags));
   /* request lines + payload areas: in device memory when the host can write there (large BAR), see ldpc_server.h */
   int large_bar = 0;
   if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, g.dev[0].id) != hipSuccess)
     large_bar = 0;
   const char *eb = getenv("NRLDPC_HIP_SRV_BAR");
-  srv.over_bar = large_bar == 1 && !(eb && atoi(eb) == 0);
-  if (srv.over_bar) {
+  S.over_bar = large_bar == 1 && !(eb && atoi(eb) == 0);
+  if (S.over_bar) {
     uint8_t *blk = nullptr;
     if (hipExtMallocWithFlags(reinterpret_cast<void **>(&blk), (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE + 64), hipDeviceMallocFinegrained) == hipSuccess) {
       HIP_TRY(hipMemset(blk, 0, (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE + 64)));
       HIP_TRY(hipDeviceSynchronize());
-      srv.req = reinterpret_cast<srv_req *>(blk);
-      srv.in_h = blk + (size_t)n * sizeof(srv_req);
-      srv.abort_h = reinterpret_cast<uint32_t *>(blk + (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE));
+      S.req = reinterpret_cast<srv_req *>(blk);
+      S.in_h = blk + (size_t)n * sizeof(srv_req);
+      S.abort_h = reinterpret_cast<uint32_t *>(blk + (size_t)n * (sizeof(srv_req) + SRV_IN_STRIDE));
     } else {
       (void)hipGetLastError();
-      srv.over_bar = false;
+      S.over_bar = false;
     }
   }
-  if (!srv.over_bar) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.req), (size_t)n * sizeof(srv_req), flags));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.in_h), (size_t)n * SRV_IN_STRIDE, flags));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.abort_h), (size_t)n * 64, flags));
-    memset(srv.req, 0, (size_t)n * sizeof(srv_req));
-    memset(srv.abort_h, 0, (size_t)n * 64);
+  if (!S.over_bar) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.req), (size_t)n * sizeof(srv_req), flags));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.in_h), (size_t)n * SRV_IN_STRIDE, flags));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.abort_h), (size_t)n * 64, flags));
+    memset(S.req, 0, (size_t)n * sizeof(srv_req));
+    memset(S.abort_h, 0, (size_t)n * 64);
   }
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&srv.out_h), (size_t)n * SRV_OUT_STRIDE, flags));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.out_h), (size_t)n * SRV_OUT_STRIDE, flags));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&small), 256, flags));
-  memset(srv.ctl, 0, (size_t)n * sizeof(srv_slot_ctl));
+  memset(S.ctl, 0, (size_t)n * sizeof(srv_slot_ctl));
   memset(small, 0, 256);
-  srv.state = reinterpret_cast<uint32_t *>(small);
-  srv.host_stop = reinterpret_cast<uint32_t *>(small + 128);
-  srv_args &a = srv.args;
+  S.state = reinterpret_cast<uint32_t *>(small);
+  S.host_stop = reinterpret_cast<uint32_t *>(small + 128);
+  srv_args &a = S.args;
   memset(&a, 0, sizeof(a));
   void *dp = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&dp, srv.ctl, 0));
+  HIP_TRY(hipHostGetDevicePointer(&dp, S.ctl, 0));
   a.ctl = static_cast<srv_slot_ctl *>(dp);
-  if (srv.over_bar) {
-    a.req = srv.req;
-    a.in_host = srv.in_h;
-    a.abort_w = srv.abort_h;
+  if (S.over_bar) {
+    a.req = S.req;
+    a.in_host = S.in_h;
+    a.abort_w = S.abort_h;
   } else {
-    HIP_TRY(hipHostGetDevicePointer(&dp, srv.abort_h, 0));
+    HIP_TRY(hipHostGetDevicePointer(&dp, S.abort_h, 0));
     a.abort_w = static_cast<const uint32_t *>(dp);
-    HIP_TRY(hipHostGetDevicePointer(&dp, srv.req, 0));
+    HIP_TRY(hipHostGetDevicePointer(&dp, S.req, 0));
     a.req = static_cast<const srv_req *>(dp);
-    HIP_TRY(hipHostGetDevicePointer(&dp, srv.in_h, 0));
+    HIP_TRY(hipHostGetDevicePointer(&dp, S.in_h, 0));
     a.in_host = static_cast<const uint8_t *>(dp);
   }
-  HIP_TRY(hipHostGetDevicePointer(&dp, srv.out_h, 0));
+  HIP_TRY(hipHostGetDevicePointer(&dp, S.out_h, 0));
   a.out_host = static_cast<uint8_t *>(dp);
-  HIP_TRY(hipHostGetDevicePointer(&dp, srv.state, 0));
+  HIP_TRY(hipHostGetDevicePointer(&dp, S.state, 0));
   a.state = static_cast<uint32_t *>(dp);
-  HIP_TRY(hipHostGetDevicePointer(&dp, srv.host_stop, 0));
+  HIP_TRY(hipHostGetDevicePointer(&dp, S.host_stop, 0));
   a.host_stop = static_cast<const uint32_t *>(dp);
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * parts * SRV_IN_STRIDE)); /* one row per workgroup */
   a.parts = (uint32_t)parts;
@@ -153,75 +160,89 @@ int srv_init_locked()
   /* its own hardware queue: a kernel that stays resident must not sit in front of other streams' launches */
   int lo = 0, hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  HIP_TRY(hipStreamCreateWithPriority(&srv.stream, hipStreamNonBlocking, hi));
+  HIP_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, hi));
   if (getenv("NRLDPC_HIP_SRV_DEBUG"))
-    fprintf(stderr, "[libldpc_hip] server: %d slots, requests %s, ctl %p in %p out %p state %p | staging %p (%zu B) gctl %p crc_pow %p %p %p %p\n", n,
-            srv.over_bar ? "pushed into device memory over the BAR" : "pulled from host memory",
+    fprintf(stderr, "[libldpc_hip] %s server: %d slots, requests %s, ctl %p in %p out %p state %p | staging %p (%zu B) gctl %p crc_pow %p %p %p %p\n", S.role == 1 ? "encoder" : "decoder", n,
+            S.over_bar ? "pushed into device memory over the BAR" : "pulled from host memory",
             (void *)a.ctl, (const void *)a.in_host, (void *)a.out_host, (void *)a.state, (void *)a.staging, (size_t)n * SRV_IN_STRIDE,
             (void *)a.gctl, (const void *)a.crc_pow_tbl[0], (const void *)a.crc_pow_tbl[1], (const void *)a.crc_pow_tbl[2],
             (const void *)a.crc_pow_tbl[3]);
-  srv.slots = new SrvSlotHost[n];
-  srv.n_slots = n;
-  atexit(srv_stop_at_exit); /* registered after the HIP runtime's own handlers, hence run before them */
-  srv.status = 0;
+  S.slots = new SrvSlotHost[n];
+  S.n_slots = n;
+  static bool at_exit_set = false;
+  if (!at_exit_set) {
+    atexit(srv_stop_at_exit); /* registered after the HIP runtime's own handlers, hence run before them */
+    at_exit_set = true;
+  }
+  S.status = 0;
   return 0;
 }
 
 /* 0: usable */
-int srv_ready()
+int srv_ready(Server &S)
 {
-  int st = srv.status.load(std::memory_order_acquire);
+  int st = S.status.load(std::memory_order_acquire);
   if (st >= 0)
     return st;
   if (ensure_ready() != 0)
     return 1;
-  std::lock_guard<std::mutex> lk(srv.mu);
-  if (srv.status.load() < 0 && srv_init_locked() != 0 && srv.status.load() < 0)
-    srv.status = 1;
-  return srv.status.load();
+  /* Both servers are set up together, before either kernel is launched: the set-up allocates, clears and synchronises,
+   * and every one of those calls waits for a resident kernel to leave (its idle time-out: 20 ms). */
+  static std::mutex init_mu;
+  std::lock_guard<std::mutex> lk(init_mu);
+  for (Server *T : {&srv, &srv_e}) {
+    std::lock_guard<std::mutex> lk2(T->mu);
+    if (T->status.load() < 0 && srv_init_locked(*T) != 0 && T->status.load() < 0)
+      T->status = 1;
+  }
+  return S.status.load();
 }
 
 /* Called by a waiting caller: (re)launch the server if no generation is running or on its way. */
-int srv_ensure_running()
+int srv_ensure_running(Server &S)
 {
-  uint32_t gcur = srv.gen.load(std::memory_order_acquire);
-  uint32_t st = __atomic_load_n(srv.state, __ATOMIC_ACQUIRE);
+  uint32_t gcur = S.gen.load(std::memory_order_acquire);
+  uint32_t st = __atomic_load_n(S.state, __ATOMIC_ACQUIRE);
   if (gcur && st <= 2 * gcur + 1)
     return 0; /* running (== 2g+1) or launched and not started yet (< 2g+1) */
-  std::lock_guard<std::mutex> lk(srv.mu);
-  gcur = srv.gen.load();
-  st = __atomic_load_n(srv.state, __ATOMIC_ACQUIRE);
+  std::lock_guard<std::mutex> lk(S.mu);
+  gcur = S.gen.load();
+  st = __atomic_load_n(S.state, __ATOMIC_ACQUIRE);
   if (gcur && st <= 2 * gcur + 1)
     return 0;
-  srv_args a = srv.args;
+  srv_args a = S.args;
   a.gen = gcur + 1;
   UseDevice use(g.dev[0]);
   if (a.parts > 1) { /* a generation starts with its meeting counters and go words at zero (behind the previous one: same stream) */
-    HIP_TRY(hipMemsetAsync(a.meet, 0, (size_t)srv.n_slots * 16 * sizeof(unsigned int), srv.stream));
-    HIP_TRY(hipMemsetAsync(a.go, 0, (size_t)srv.n_slots * 16 * sizeof(unsigned int), srv.stream));
+    HIP_TRY(hipMemsetAsync(a.meet, 0, (size_t)S.n_slots * 16 * sizeof(unsigned int), S.stream));
+    HIP_TRY(hipMemsetAsync(a.go, 0, (size_t)S.n_slots * 16 * sizeof(unsigned int), S.stream));
   }
-  HIP_TRY(ldpc_server_launch(a, (uint32_t)srv.n_slots, srv.stream));
-  srv.gen.store(gcur + 1, std::memory_order_release);
+  HIP_TRY(ldpc_server_launch(a, (uint32_t)S.n_slots, S.stream, S.role));
+  S.gen.store(gcur + 1, std::memory_order_release);
   return 0;
 }
 
 /* Ask the running generation to leave and wait for it (requests already rung are served first or picked up by the next
  * generation).  Used at exit / LDPCshutdown; nothing on the call path needs it. */
-void srv_stop()
+void srv_stop(Server &S)
 {
-  if (srv.status.load() != 0)
+  if (S.status.load() != 0)
     return;
-  std::lock_guard<std::mutex> lk(srv.mu);
-  const uint32_t gcur = srv.gen.load();
+  std::lock_guard<std::mutex> lk(S.mu);
+  const uint32_t gcur = S.gen.load();
   if (!gcur)
     return;
-  __atomic_store_n(srv.host_stop, gcur, __ATOMIC_RELEASE);
+  __atomic_store_n(S.host_stop, gcur, __ATOMIC_RELEASE);
   UseDevice use(g.dev[0]);
-  (void)hipStreamSynchronize(srv.stream);
+  (void)hipStreamSynchronize(S.stream);
 }
-void srv_stop_at_exit() { srv_stop(); }
+void srv_stop_at_exit()
+{
+  srv_stop(srv);
+  srv_stop(srv_e);
+}
 
-thread_local int tls_srv_slot = -1;
+thread_local int tls_srv_slot[2] = {-1, -1};
 
 inline double srv_now()
 {
@@ -237,12 +258,12 @@ struct SrvCall {
   srv_req *req;
 };
 
-SrvCall srv_acquire()
+SrvCall srv_acquire(Server &S)
 {
-  if (tls_srv_slot < 0)
-    tls_srv_slot = (int)(srv.next_slot.fetch_add(1) % (uint32_t)srv.n_slots);
-  const int s = tls_srv_slot;
-  SrvSlotHost &h = srv.slots[s];
+  if (tls_srv_slot[S.role] < 0)
+    tls_srv_slot[S.role] = (int)(S.next_slot.fetch_add(1) % (uint32_t)S.n_slots);
+  const int s = tls_srv_slot[S.role];
+  SrvSlotHost &h = S.slots[s];
   for (int spins = 0;; spins++) { /* uncontended unless there are more caller threads than slots */
     uint32_t z = 0;
     if (h.busy.compare_exchange_weak(z, 1, std::memory_order_acquire))
@@ -250,15 +271,15 @@ SrvCall srv_acquire()
     if (spins > 64)
       sched_yield();
   }
-  return SrvCall{s, srv.in_h + (size_t)s * SRV_IN_STRIDE, srv.out_h + (size_t)s * SRV_OUT_STRIDE, srv.ctl + s, srv.req + s};
+  return SrvCall{s, S.in_h + (size_t)s * SRV_IN_STRIDE, S.out_h + (size_t)s * SRV_OUT_STRIDE, S.ctl + s, S.req + s};
 }
-void srv_release(const SrvCall &c) { srv.slots[c.slot].busy.store(0, std::memory_order_release); }
+void srv_release(Server &S, const SrvCall &c) { S.slots[c.slot].busy.store(0, std::memory_order_release); }
 
 /* publish the request header `rq` (tags still unset) in the slot's ctl line and wait for the completion word; returns
  * n_iter via *n_iter.  The payload must already be in the slot's input area. */
-int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter, decode_abort_t *ab = nullptr)
+int srv_submit(Server &S, const SrvCall &c, srv_req &rq, int32_t *n_iter, decode_abort_t *ab = nullptr)
 {
-  SrvSlotHost &h = srv.slots[c.slot];
+  SrvSlotHost &h = S.slots[c.slot];
   h.seq = h.seq + 1 >= 0xfffffff0u ? 1u : h.seq + 1;
   h.calls++;
   const uint32_t seq = h.seq;
@@ -284,11 +305,11 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter, decode_abort_t *a
     /* decoder.c:556-559: the decoder looks at the transport block's abort flag every iteration; another worker may raise
      * it while this call is in flight -- passed on to the GPU, which looks at the slot's word once per pass */
     if (ab && !told && __atomic_load_n(reinterpret_cast<const volatile unsigned char *>(&ab->failed), __ATOMIC_RELAXED)) {
-      __atomic_store_n(srv.abort_h + 16 * c.slot, seq, __ATOMIC_RELEASE);
+      __atomic_store_n(S.abort_h + 16 * c.slot, seq, __ATOMIC_RELEASE);
       __builtin_ia32_sfence();
       told = true;
     }
-    if ((spins & 7) == 0 && srv_ensure_running() != 0)
+    if ((spins & 7) == 0 && srv_ensure_running(S) != 0)
       return -1;
     if (spins < 32)
       __builtin_ia32_pause();
@@ -306,7 +327,7 @@ int srv_submit(const SrvCall &c, srv_req &rq, int32_t *n_iter, decode_abort_t *a
   h.ticks_decode += sd >> 16;
   h.ticks_prologue += pp & 0xffffu;
   h.ticks_passes += pp >> 16;
-  if (srv.args.parts > 1)
+  if (S.args.parts > 1)
     for (int k = 0; k < 5; k++)
       h.ticks_phase[k] += c.ctl->pad1[k];
   return 0;
@@ -330,7 +351,8 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   if ((size_t)hl.num_llr > SRV_IN_STRIDE || (size_t)ob * 4 / 3 + 32 > SRV_OUT_STRIDE)
     return 1;
   const double t_call = srv_now();
-  const SrvCall c = srv_acquire();
+  Server &S = srv;
+  const SrvCall c = srv_acquire(S);
   srv_req rq;
   memset(&rq, 0, sizeof(rq));
   rq.kind_mode = kind | ((uint32_t)out_mode << 8) | ((uint32_t)(a.use_crc != 0) << 16) | ((a.use_crc ? (uint32_t)p->crc_type : 0u) << 24);
@@ -347,7 +369,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   }
   memcpy(c.in, llr, (size_t)hl.num_llr);
   int32_t n = 0;
-  const int rc = srv_submit(c, rq, &n, ab);
+  const int rc = srv_submit(S, c, rq, &n, ab);
   if (rc == 0) {
     *n_iter = n;
     if ((!a.use_crc || n >= 3) && n <= (int32_t)p->numMaxIter + 1) { /* (numMaxIter + 2: given up on the way, nothing was written) */ /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
@@ -361,7 +383,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
           __m128i v = _mm_load_si128(src);
           for (uint32_t spins = 0; (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi32(v, 0xff)) != seq; spins++) {
             __builtin_ia32_pause();
-            if ((spins & 0xfff) == 0xfff && srv_ensure_running() != 0)
+            if ((spins & 0xfff) == 0xfff && srv_ensure_running(S) != 0)
               break;
             v = _mm_load_si128(src);
           }
@@ -378,7 +400,7 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
     }
   }
   srv.slots[c.slot].host_total_s += srv_now() - t_call;
-  srv_release(c);
+  srv_release(S, c);
   return rc;
 }
 
@@ -392,7 +414,8 @@ int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, u
   const size_t lds = (size_t)4 * ((ldpc_encp_lds_words(hc.ncols, hc.kb_full, hc.Z, hc.nrows, hc.nedges) + 3) & ~3) * 8;
   if (!ldpc_server_has_encoder() || n > 8 || in_stride * n > SRV_IN_STRIDE || out_stride * n > SRV_OUT_STRIDE || lds > SRV_CODE_LDS_MAX)
     return 1;
-  const SrvCall c = srv_acquire();
+  Server &S = srv_e;
+  const SrvCall c = srv_acquire(S);
   srv_req rq;
   memset(&rq, 0, sizeof(rq));
   rq.kind_mode = SRV_KIND_ENC;
@@ -409,14 +432,14 @@ int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, u
   meter_start(tprep);
   meter_stop(tprep);
   meter_start(tparity);
-  const int rc = srv_submit(c, rq, nullptr);
+  const int rc = srv_submit(S, c, rq, nullptr);
   meter_stop(tparity);
   meter_start(toutput);
   if (rc == 0)
     for (unsigned j = 0; j < n; j++)
       memcpy(output[first + j], c.out + j * out_stride, (size_t)N);
   meter_stop(toutput);
-  srv_release(c);
+  srv_release(S, c);
   return rc;
 }
 
