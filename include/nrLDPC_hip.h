@@ -127,7 +127,8 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
 /* Up to 8 segments per call (ldpc_encoder_optim8segmulti.c:46-213): input[j] K/8 bytes MSB first,
  * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Returns 0, -1 on bad parameters (the
- * reference's callers ignore the value: nr_dlsch_coding.c:171). */
+ * reference's callers ignore the value: nr_dlsch_coding.c:171).  Served by a resident kernel of its own, like the decoder
+ * (NRLDPC_HIP_ENC_SERVER=0: one launch per call). */
 int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp);
 
 /* ===================================================================================================

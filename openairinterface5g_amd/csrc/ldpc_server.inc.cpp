@@ -13,6 +13,7 @@
  * NRLDPC_HIP_SRV_SLOTS=<n> caller slots = workgroups = CUs the server occupies while it is up (default 64, more
  * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
  * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls);
+ * NRLDPC_HIP_ENC_SERVER=0 / NRLDPC_HIP_ENC_SLOTS=<n>: LDPCencoder's own resident kernel off / its slots (default 16);
  * NRLDPC_HIP_SRV_SPLIT=2|4 CUs per slot: large codes are decoded by that many workgroups together (ldpc_dec_fast_part.h).
  */
 #include <emmintrin.h>
