@@ -628,7 +628,15 @@ int32_t nrLDPC_hip_server_stats(int64_t out[8])
   return 0;
 }
 
-int32_t LDPCinit(void) { return ensure_ready() == 0 ? 0 : -1; }
+int32_t LDPCinit(void)
+{
+  if (ensure_ready() != 0)
+    return -1;
+  /* the resident servers' mailboxes and buffers (tens of milliseconds of allocations) are set up here, not inside the
+   * first LDPCdecoder / LDPCencoder call; the kernels themselves start with the first call and leave when idle */
+  (void)srv_ready(srv);
+  return 0;
+}
 
 int32_t LDPCshutdown(void)
 {
