@@ -95,7 +95,12 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu)); }
   __device__ __forceinline__ int *tb_abort() const { return nullptr; }
   const uint32_t *abw_;
-  __device__ __forceinline__ uint32_t abort_load() const { return srv_ld_sys(abw_); }
+  /* (typed as global memory: through a generic pointer this would be a FLAT load, which the LDS waits of the check-node
+   * phase that follows would wait for as well -- 0.9 us per pass on the critical path) */
+  __device__ __forceinline__ uint32_t abort_load() const
+  {
+    return __hip_atomic_load((const __attribute__((address_space(1))) uint32_t *)abw_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __device__ __forceinline__ bool abort_is(uint32_t w) const { return w == tag_; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
   __device__ __forceinline__ int tid() const { return tid_; }

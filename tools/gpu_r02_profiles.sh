@@ -37,6 +37,8 @@ run() { echo "$1 T=$2 case=${4:-mix}: $(env $1 timeout 60 ./tests/abi_threads.bi
   for T in 1 4 16 32 64; do run X=1 $T 1000; done
   for T in 1 16 32; do run NRLDPC_HIP_SERVER=0 $T 300; done; } | tee $O/abi_threads.txt
 timeout 300 python tests/ldpctest_hip.py -l 8448 -s 10 -n 200 > $O/ldpctest_hip_8448.txt 2>&1; tail -3 $O/ldpctest_hip_8448.txt
+timeout 120 python tools/enc_call_latency.py 2000 2>&1 | grep segment | sed "s/^/server: /" > $O/enc_call_latency.txt; NRLDPC_HIP_ENC_SERVER=0 timeout 120 python tools/enc_call_latency.py 1000 2>&1 | grep segment | sed "s/^/launch per call: /" >> $O/enc_call_latency.txt; cat $O/enc_call_latency.txt
+timeout 60 python tools/first_use_latency.py 2>&1 | grep call > $O/first_use_latency.txt
 echo "== host path + ubench"
 timeout 120 python tools/host_path_sweep.py 2>&1 | grep chunk | tee $O/host_path.txt
 NRLDPC_HIP_HOST_PULL=0 timeout 120 python tools/host_path_sweep.py 2>&1 | grep chunk | sed "s/^/copy engine: /" | tee -a $O/host_path.txt
