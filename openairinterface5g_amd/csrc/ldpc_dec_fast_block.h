@@ -30,6 +30,7 @@
  *   int out_mode()            0 packed bits, else one bit per byte
  *   int *tb_abort()           optional: transport-block wide "a segment failed" flag (decoder.c:190-193, 556-559)
  *   uint32_t abort_load()     resident server: the slot's "caller gave up" word, loaded (past the caches) at the START of a
+ *   bool has_abort()          compile-time: does this caller have any abort source (tb_abort / abort_load)?
  *   bool abort_is(word)       pass and looked at after its check-node phase -- the reference's per-iteration check_abort
  *                             (decoder.c:556-559) for a caller whose `ab` is raised by another thread while the call is in
  *                             flight; 0 / false elsewhere
@@ -168,7 +169,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
-    const uint32_t ab_word = (tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
+    const uint32_t ab_word = (io.has_abort() && tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
@@ -212,7 +213,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         flags[3] = 1;
     }
     __syncthreads();
-    if (flags[3]) { /* (zero unless one of the two abort sources exists and fired) */
+    if (io.has_abort() && flags[3]) { /* (set by one of the two abort sources) */
       n_iter = max_pass + 1;
       break;
     }

@@ -42,6 +42,7 @@ template <bool JOBS> struct ldpc_batch_io {
   __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
   __device__ __forceinline__ uint32_t abort_load() const { return 0u; }
   __device__ __forceinline__ bool abort_is(uint32_t) const { return false; }
+  __device__ __forceinline__ bool has_abort() const { return JOBS; }
   __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { *p = make_uint4(x, y, z, t); }
   __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return *p; }
   __device__ __forceinline__ const uint32_t *src32_prologue() const { return src32(); }

@@ -102,6 +102,7 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
     return __hip_atomic_load((const __attribute__((address_space(1))) uint32_t *)abw_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __device__ __forceinline__ bool abort_is(uint32_t w) const { return w == tag_; }
+  __device__ __forceinline__ bool has_abort() const { return true; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }
