@@ -378,5 +378,6 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
     }
   }
   return n_iter;
+#undef LDPC_PART_PHASE
 }
 #endif
