@@ -17,6 +17,7 @@
  * NRLDPC_HIP_SRV_SPLIT=2|4 CUs per slot: large codes are decoded by that many workgroups together (ldpc_dec_fast_part.h).
  */
 #include <emmintrin.h>
+#include <xmmintrin.h>
 #include <atomic>
 #include <sched.h>
 #include <time.h>
@@ -379,6 +380,10 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
          * number; one aligned 16-byte load per look, so a unit is never seen half written */
         const uint32_t seq = srv.slots[c.slot].seq;
         const int n_units = (ob / 4 + 2) / 3;
+        /* the units' cache lines were invalidated by the GPU's writes: ask for all of them at once instead of taking one
+         * miss after the other in the loop below */
+        for (int off = 0; off < 16 * n_units; off += 64)
+          _mm_prefetch(reinterpret_cast<const char *>(c.out) + off, _MM_HINT_T0);
         for (int u = 0; u < n_units; u++) {
           const __m128i *src = reinterpret_cast<const __m128i *>(c.out) + u;
           __m128i v = _mm_load_si128(src);
