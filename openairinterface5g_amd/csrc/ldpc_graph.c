@@ -501,7 +501,7 @@ int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_des
 
 int ldpc_build_code_desc_part(int BG, int Z, int R, int parts, int part, ldpc_code_desc_t *d)
 {
-  static ldpc_code_desc_t full; /* (callers hold the library's build lock) */
+  ldpc_code_desc_t full;
   if (parts < 2 || parts > 8 || part < 0 || part >= parts)
     return -1;
   if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_LATENCY, &full) != 0)
