@@ -104,3 +104,16 @@ def test_reference_meters_are_filled(hip):
         n, _ = hip.LDPCdecoder(p, llr, profiler=prof)
     assert n == 2 and prof.total.trials == 2 and prof.total.diff > 0 and prof.total.meas_flag == 0
     assert prof.cnProc.trials == 0                             # only `total` is written (include/nrLDPC_hip.h)
+
+
+def test_reference_entry_point_without_the_resident_kernel():
+    """NRLDPC_HIP_ENC_SERVER=0: LDPCencoder with one launch per call (the path a box without the resident encoder kernel
+    takes) gives the same code words: the entry-point tests once more under it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NRLDPC_HIP_ENC_SERVER="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_encoder.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "reference_entry_point_macro or meters"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
