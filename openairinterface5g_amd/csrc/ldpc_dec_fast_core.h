@@ -234,6 +234,86 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
+/* A degree-19 row item shared by TWO neighbouring lanes (lane parity = half): half 0 takes the row's edges 0..9, half 1
+ * edges 10..18 -- ten edges in registers each (the one-lane version has to re-read LDS in its second sweep, MODE 2, or
+ * spill), the partial minima / sign xor / parity word are swapped through a DPP move and merged, then every lane writes
+ * its own edges.  The two smallest of a union = {min(m1a, m1b), min(max(m1a, m1b), min(m2a, m2b))}.  Device only (the
+ * CPU emulation calls the one-lane body once per pair: same results). */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t ldpc_swap_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false); }
+template <bool P1>
+__device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int half)
+{
+  constexpr int N = 10;
+  const int t = 4 * j;
+  const int ebase = e0 + (half ? 10 : 0);
+  uint32_t d_lo[N], d_hi[N], g_lo[N], g_hi[N];
+  ldpc_v2u m1l = ldpc_splatu(0xffff), m2l = m1l, m1h = m1l, m2h = m1l;
+  uint32_t sxl = 0, sxh = 0, parw = 0, extl = 0, exth = 0;
+  uint8_t *rrow = L.r + ebase * rstride + t;
+  uint8_t *rpad = rrow + (j == 0 ? Z : 0);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool live = k < N - 1 || !half; /* half 1 has nine edges: its tenth slot is neutral */
+    const int kk = live ? k : N - 2;      /* (address of a real edge; what is read there is not used) */
+    const uint32_t info = L.etbl[ebase + kk];
+    const uint32_t rw = P1 ? 0u : *reinterpret_cast<const uint32_t *>(rrow + kk * rstride);
+    uint32_t dl, dh, pw = 0;
+    ldpc_fast_cn_edge<false, P1>(L, info, t, rw, true, dl, dh, pw, extl, exth);
+    ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
+    ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+    if (!live) {
+      ml = mh = ldpc_splatu(0xffff);
+      dl = dh = 0u;
+      pw = 0u;
+    }
+    d_lo[k] = dl; d_hi[k] = dh;
+    g_lo[k] = ldpc_u2u32(ml); g_hi[k] = ldpc_u2u32(mh);
+    parw ^= pw;
+    sxl ^= dl;
+    sxh ^= dh;
+    m2l = ldpc_pminu(m2l, ldpc_pmaxu(m1l, ml));
+    m1l = ldpc_pminu(m1l, ml);
+    m2h = ldpc_pminu(m2h, ldpc_pmaxu(m1h, mh));
+    m1h = ldpc_pminu(m1h, mh);
+  }
+  { /* merge with the partner lane */
+    const ldpc_v2u p1l = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m1l))), p2l = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m2l)));
+    const ldpc_v2u p1h = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m1h))), p2h = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m2h)));
+    m2l = ldpc_pminu(ldpc_pmaxu(m1l, p1l), ldpc_pminu(m2l, p2l));
+    m1l = ldpc_pminu(m1l, p1l);
+    m2h = ldpc_pminu(ldpc_pmaxu(m1h, p1h), ldpc_pminu(m2h, p2h));
+    m1h = ldpc_pminu(m1h, p1h);
+    sxl ^= ldpc_swap_pair(sxl);
+    sxh ^= ldpc_swap_pair(sxh);
+    parw ^= ldpc_swap_pair(parw);
+  }
+  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
+  m1l = ldpc_pminu(m1l, cap); m2l = ldpc_pminu(m2l, cap);
+  m1h = ldpc_pminu(m1h, cap); m2h = ldpc_pminu(m2h, cap);
+  const uint32_t sl = (ldpc_u2u32(m1l) - 0x80008000u) + ldpc_u2u32(m2l), sh = (ldpc_u2u32(m1h) - 0x80008000u) + ldpc_u2u32(m2h);
+  /* (19 - 1 is even: no sign flip; a neutral slot xor-ed zeros into sx) */
+  const uint32_t sx4 = ldpc_perm(sxh, sxl, 0x07050301u);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool live = k < N - 1 || !half;
+    const uint32_t dl = d_lo[k], dh = d_hi[k];
+    const ldpc_v2u ml = ldpc_as_v2u(g_lo[k]), mh = ldpc_as_v2u(g_hi[k]);
+    const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h));
+    const uint32_t o4 = ldpc_perm(oh, ol, 0x06040200u);
+    const uint32_t n4 = ((sx4 ^ ldpc_perm(dh, dl, 0x07050301u)) >> 7) & 0x01010101u;
+    const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
+    if (live) {
+      *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
+      *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
+    }
+  }
+  uint32_t np = (parw >> 7) & 0x01010101u;
+  np ^= 0x01010101u; /* D = 19 is odd */
+  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+}
+#endif
+
 /* Parity check of one check-node item on its own (no message update): the same 4-bit mask ldpc_fast_cn returns, from the
  * APP signs of the row's core columns and, for an extension row, sat8(llr + r) of its degree-1 column (cnProc.h:940).
  * Used by the latency path (ldpc_dec_fast_block.h, eager check): ~6 VALU per edge instead of a check-node update. */

@@ -173,12 +173,21 @@ __device__ __forceinline__ int ldpc_dec_fast_part(uint8_t *fsm, ldpc_code_ptr_t 
       const int item = code->f_cn_task[task][2] + lane;
       const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
       if (item < gend) {
-        const int gi = item - gstart;
+        /* (a whole code's descriptor, served here as a single part, may pair its degree-19 items: ldpc_graph.h f_pair19) */
+        const bool pair = deg == 19 && code->f_pair19;
+        const int gi = pair ? (item - gstart) >> 1 : item - gstart, half = (item - gstart) & 1;
         const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
         const uint32_t rowrec = rowtbl[srow0 + rig];
         const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
-        const uint32_t m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
-                                  : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
+        uint32_t m;
+        (void)half;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (pair)
+          m = p == 1 ? ldpc_fast_cn19_pair<true>(L, e0, j, Z, rstride, half) : ldpc_fast_cn19_pair<false>(L, e0, j, Z, rstride, half);
+        else
+#endif
+          m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
+                     : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         syn |= m & mask;
       }

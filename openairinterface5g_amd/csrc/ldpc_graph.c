@@ -42,7 +42,7 @@ static int align16(int x) { return (x + 15) & ~15; }
 static int row_has_ext(const ldpc_code_desc_t *d, int r) { return d->e_col[d->row_ptr[r] + d->row_deg[r] - 1] >= d->ncore; }
 
 /* schedules and tables of the "fast" decoder kernel (see ldpc_graph.h) */
-static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
+static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair19)
 {
   const int Z = d->Z;
   d->f_ok = 0;
@@ -51,6 +51,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
   const int zq1 = Z / 4;
   const int zq = zq1 * mb; /* items per lifted row / column: all blocks of the workgroup (mb = 1: the one block) */
   d->f_mb = mb;
+  d->f_pair19 = 0;
   if (d->f_sub != 4)
     d->f_sub = 1;
   d->f_zq = zq1;
@@ -76,7 +77,11 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
     int j = i;
     while (j < d->nrows && rows[j].key == rows[i].key)
       j++;
-    const int gstart = item, gend = item + (j - i) * zq;
+    /* degree-19 rows (the core rows, no extension column): two lanes per item when pair19 */
+    const int paired = pair19 && rows[i].key == 19 && !row_has_ext(d, rows[i].id);
+    if (paired)
+      d->f_pair19 = 1;
+    const int gstart = item, gend = item + (j - i) * zq * (paired ? 2 : 1);
     for (int b = gstart; b < gend; b += 64) {
       if (nt >= LDPC_F_MAX_CN_TASKS)
         return;
@@ -88,7 +93,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
       d->f_cn_task[nt][5] = i;
       /* instruction-count model of a task: ~36 VALU per edge (47 for the degree-19 rows, which re-read LDS in their
        * second sweep) + ~40 of prologue/epilogue */
-      cost[nt] = rows[i].key * (rows[i].key >= 16 ? 47 : 36) + 40;
+      cost[nt] = paired ? 10 * 36 + 60 : rows[i].key * (rows[i].key >= 16 ? 47 : 36) + 40;
       nt++;
     }
     /* a degree group must not mix core rows (no extension column) with extension rows */
@@ -143,7 +148,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb)
   d->f_n_bn_tasks = nb;
 
   /* the magic division must be exact for every item index that occurs */
-  const int max_item = d->nrows * zq > nitems ? d->nrows * zq : nitems;
+  const int max_item = (d->nrows + (d->f_pair19 ? 4 : 0)) * zq > nitems ? (d->nrows + (d->f_pair19 ? 4 : 0)) * zq : nitems;
   for (int i = 0; i < max_item + 64; i++)
     if ((int)(((uint64_t)i * d->f_zqb_magic) >> 32) != i / zq || (int)(((uint64_t)i * d->f_zq_magic) >> 32) != i / zq1)
       return;
@@ -453,7 +458,10 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;
   d->n_threads = waves * 64;
-  build_fast_section(d, shape, 1);
+  {
+    const char *e = getenv("NRLDPC_HIP_PAIR19"); /* tuning knob: 0 = one lane per degree-19 row item */
+    build_fast_section(d, shape, 1, !(e && e[0] == '0'));
+  }
   return 0;
 }
 
@@ -475,7 +483,7 @@ int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d
     d->f_ok = 0;
     return 0;
   }
-  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb);
+  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb, 0);
   return 0;
 }
 
@@ -495,7 +503,7 @@ int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_des
     d->pc_lo[r] *= 4;
   d->Z = 4 * Z; /* (num_llr, ncols, zw and the generic kernel's fields keep describing the real code) */
   d->f_sub = 4;
-  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb);
+  build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb, 0);
   return 0;
 }
 
@@ -549,7 +557,7 @@ int ldpc_build_code_desc_part(int BG, int Z, int R, int parts, int part, ldpc_co
   }
   d->col_ptr[d->ncore] = n;
   /* (col_deg_full stays the whole code's; ncols, num_llr too: a part reads every column's LLRs) */
-  build_fast_section(d, LDPC_SHAPE_LATENCY, 1);
+  build_fast_section(d, LDPC_SHAPE_LATENCY, 1, 0);
   d->f_part = part;
   d->f_parts = parts;
   return 0;

@@ -126,6 +126,9 @@ typedef struct ldpc_code_desc {
    * f_part / f_parts = which part of how many (0 / 1: an ordinary descriptor). */
   int32_t col_deg_full[LDPC_MAX_CORE + 2];
   int32_t f_part, f_parts;
+  /* 1: the items of the degree-19 rows come in PAIRS of neighbouring lanes, each lane taking half of the row's edges
+   * (ldpc_fast_cn19_pair): the group holds 2 x rows x Z/4 items, item = 2 x (row item) + half */
+  int32_t f_pair19;
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus

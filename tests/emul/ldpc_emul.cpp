@@ -227,7 +227,11 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
         const int item = code->f_cn_task[task][2] + lane;
         const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
         if (item < gend) {
-          const int gi = item - gstart;
+          /* degree-19 rows come as pairs of items (two lanes of the kernel share a row item): one call per pair here */
+          const bool pair = deg == 19 && code->f_pair19;
+          if (pair && ((item - gstart) & 1))
+            continue;
+          const int gi = pair ? (item - gstart) >> 1 : item - gstart;
           const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
           const uint32_t rowrec = rowtbl[srow0 + rig];
           const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;

@@ -24,6 +24,13 @@ __device__ __forceinline__ ldpc_fast_lds probe_lds(uint8_t *fsm, const probe_arg
     a.out[threadIdx.x] = ldpc_fast_cn<D, EXT != 0, MODE>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride); \
   }
 CN_PROBE(19, 0, 2) CN_PROBE(10, 0, 0) CN_PROBE(8, 0, 0)
+/* a degree-19 row item shared by two lanes (ldpc_fast_cn19_pair): one lane's instructions */
+extern "C" __global__ void __launch_bounds__(1024) probe_cn_19pair(const probe_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  const ldpc_fast_lds L = probe_lds(fsm, a);
+  a.out[threadIdx.x] = ldpc_fast_cn19_pair<false>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride, (int)threadIdx.x & 1);
+}
 CN_PROBE(3, 1, 0) CN_PROBE(4, 1, 0) CN_PROBE(5, 1, 0) CN_PROBE(6, 1, 0) CN_PROBE(7, 1, 0) CN_PROBE(8, 1, 0) CN_PROBE(9, 1, 0) CN_PROBE(10, 1, 0)
 #define BN_PROBE(M)                                                                        \
   extern "C" __global__ void __launch_bounds__(1024) probe_bn_##M(const probe_args a)       \

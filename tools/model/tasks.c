@@ -11,7 +11,8 @@ int main(int argc, char **argv)
   printf("{\"BG\": %d, \"Z\": %d, \"R\": %d, \"nedges\": %d, \"threads\": %d, \"cn_tasks\": [", BG, Z, R, d.nedges, d.f_n_threads);
   for (int t = 0; t < d.f_n_cn_tasks; t++) {
     int first = d.f_cn_task[t][2], gend = d.f_cn_task[t][4], items = gend - first < 64 ? gend - first : 64;
-    printf("%s{\"deg\": %d, \"ext\": %d, \"items\": %d}", t ? ", " : "", d.f_cn_task[t][0], d.f_cn_task[t][1], items);
+    printf("%s{\"deg\": %d, \"ext\": %d, \"items\": %d, \"pair\": %d}", t ? ", " : "", d.f_cn_task[t][0], d.f_cn_task[t][1], items,
+           d.f_cn_task[t][0] == 19 && d.f_pair19);
   }
   printf("], \"bn_tasks\": [");
   for (int t = 0; t < d.f_n_bn_tasks; t++) {
