@@ -271,6 +271,21 @@ void oracle_ldpctest_channel(oracle_rng_t *s, const uint8_t *coded, int n, int Z
   }
 }
 
+/* openair1/SIMULATION/NR_PHY/ulschsim.c:533-552 = dlschsim.c:527-543: the transport-channel sims' BPSK + AWGN channel on
+ * the rate-matched, interleaved bits f[0..n): +1 for a 0 bit, -1 for a 1 bit, noise sigma * gaussdouble(0, 1), then
+ * `(short)quantize(sigma / 4.0 / 4.0, x, qbits)` -- the 8-bit quantiser's char result widened to the int16 LLR array the
+ * decoding chains take.  Returns the number of hard-decision errors (ulschsim.c:555-562 errors_bit_uncoded). */
+int oracle_schsim_channel(oracle_rng_t *s, const uint8_t *f, int n, double sigma, int qbits, int16_t *llr)
+{
+  int uncoded_errors = 0;
+  for (int i = 0; i < n; i++) {
+    double mod = f[i] == 0 ? 1.0 : -1.0;
+    llr[i] = (int16_t)oracle_quantize(sigma / 4.0 / 4.0, mod + sigma * oracle_gaussdouble(s, 0.0, 1.0), (uint8_t)qbits);
+    uncoded_errors += (llr[i] < 0) != (f[i] != 0);
+  }
+  return uncoded_errors;
+}
+
 /* openair1/PHY/NR_TRANSPORT/nr_tbs_tools.c:50-64 */
 uint32_t oracle_nr_get_E(uint32_t G, uint8_t C, uint8_t Qm, uint8_t Nl, uint8_t r)
 {

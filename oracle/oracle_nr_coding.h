@@ -111,6 +111,8 @@ double oracle_gaussdouble(oracle_rng_t *s, double mean, double variance);
 int8_t oracle_quantize(double D, double x, uint8_t B);
 /* ldpctest.c:294-313: BPSK + AWGN + quantize into llr[2Zc .. 2Zc+n) ; llr[0..2Zc) = 0 */
 void oracle_ldpctest_channel(oracle_rng_t *s, const uint8_t *coded, int n, int Zc, double sigma, int qbits, int8_t *llr);
+/* ulschsim.c:533-552 / dlschsim.c:527-543: channel of the transport-channel sims, int16 LLRs; returns uncoded bit errors */
+int oracle_schsim_channel(oracle_rng_t *s, const uint8_t *f, int n, double sigma, int qbits, int16_t *llr);
 
 #ifdef __cplusplus
 }

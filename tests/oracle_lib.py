@@ -83,6 +83,8 @@ def lib():
         L.oracle_quantize.argtypes = [C.c_double, C.c_double, C.c_uint8]
         L.oracle_quantize.restype = C.c_int8
         L.oracle_ldpctest_channel.argtypes = [C.POINTER(Rng), C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.oracle_schsim_channel.argtypes = [C.POINTER(Rng), C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.oracle_schsim_channel.restype = C.c_int
         _lib = L
     return _lib
 
@@ -304,6 +306,13 @@ class OaiRng:
 
     def gauss(self, mean=0.0, var=1.0):
         return lib().oracle_gaussdouble(C.byref(self.s), mean, var)
+
+    def schsim_channel(self, f, sigma, qbits=8):
+        """ulschsim.c:533-552 / dlschsim.c:527-543: int16 LLRs of the rate-matched bits f; also the uncoded error count"""
+        f = np.ascontiguousarray(f, dtype=np.uint8)
+        llr = np.zeros(f.size, dtype=np.int16)
+        n_err = lib().oracle_schsim_channel(C.byref(self.s), _p(f), f.size, sigma, qbits, _p(llr))
+        return llr, n_err
 
     def ldpctest_channel(self, coded, Zc, sigma, qbits=8, ncols=None):
         coded = np.ascontiguousarray(coded, dtype=np.uint8)
