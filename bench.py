@@ -140,6 +140,13 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
             .clamp(-127, 127).to(torch.int16)
         torch.cuda.synchronize()
     sh = parallel.ShardedUlsch(tbs, device=dev, numMaxIter=MAX_ITER)
+    if dist is not None:
+        # every rank reached the collective section with its inputs built (a rank that raised above never gets here and
+        # the others find out from the watchdog time-out of this all-reduce instead of hanging in the scatter)
+        ready = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ready)
+        if int(ready.item()) != world:
+            raise RuntimeError("not every rank finished the set-up of the strong-scaling slot")
     for _ in range(2):
         out = sh.decode(llr)
     torch.cuda.synchronize()
@@ -162,6 +169,7 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
     return {"workload": "64 PUSCH transport blocks of one slot (273 PRB x 13 symbols, 64QAM, TBS 213 176 bit: 1664 code "
                         "segments) arriving on rank 0: scatter LLRs -> UL-SCH chain on every rank -> gather payloads/ACKs",
             "scaling": "strong", "n_gpus": world, "transport_blocks_per_rank": [int(b - a) for a, b in sh.tb_ranges],
+            "pipeline_chunks_per_rank": [len(c) - 1 for c in sh.chunk_cut],
             "steps": steps, "ms_per_slot": dt / steps * 1e3, "info_gbps": n_tb * A * steps / dt / 1e9,
             "coded_gbps": n_tb * G * steps / dt / 1e9, "llr_bytes_scattered": int(co[-1]) * 2,
             "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
@@ -185,14 +193,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, the same
+        # command line the driver uses (rendezvous on 127.0.0.1, a free port); the ranks' rank-0 JSON line is our output
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())]
+                 + sys.argv[1:])
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     os.environ["NRLDPC_HIP_DEVICE"] = str(local_rank)   # (device-buffer calls run on the tensors' own GPU in any case)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":   # (the knob exercises the RCCL path on a 1-GPU box)
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:                                   # BENCH_FORCE_DIST on one GPU: a rendezvous of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # a rank that dies inside a collective must not leave the others waiting for ever: the watchdog
+        # turns a 3-minute stall into an error on every rank
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
     pkg.LDPCinit()
 
     # ---- inputs resident in HBM ---------------------------------------------------------------------
@@ -261,6 +287,11 @@ def main():
         except Exception as e:                      # the secondary experiment must not cost the headline line
             strong = {"error": f"{type(e).__name__}: {e}"[:300]}
             print(f"[bench] strong-scaling slot failed on rank {rank}: {strong['error']}", file=sys.stderr, flush=True)
+    devices = [torch.cuda.current_device()]
+    if dist is not None:
+        ords = [None] * world
+        dist.all_gather_object(ords, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(local_rank).name))
+        devices = [o[1] for o in sorted(ords)]
 
     if rank == 0:
         traffic, pmc = None, {}
@@ -306,6 +337,10 @@ def main():
                          "binding_resource": binding},
             "operating_point": op,
             "strong_scaling_slot": strong,
+            # how the ranks were really run: the communicator's size (0 = no process group, plain single process) and
+            # the HIP device ordinal of every rank
+            "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+            "rank_devices": devices,
         }
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(llr_fixed[:256].cpu().numpy())

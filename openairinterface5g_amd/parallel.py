@@ -151,17 +151,25 @@ class ShardedUlsch:
     on the rank that owns it and stay there from round to round.
 
     All ranks construct it with the same descriptor list (broadcast it first if only the root has it) and call decode()
-    together; the LLRs -- one flat int16 tensor in the layout of ldpc.tb_layout(tbs) -- are needed on `root` only."""
+    together; the LLRs -- one flat int16 tensor in the layout of ldpc.tb_layout(tbs) -- are needed on `root` only.
+
+    decode() is a pipeline over `chunks` sub-ranges of every peer's range (the reference keeps all segments of a slot in
+    flight together, nr_ulsch_decoding.c:435-468): the root posts the LLR sends of all chunks, chunk-major, and decodes
+    its own range while they drain; a peer posts all its receives, decodes chunk k as soon as it has arrived -- while
+    chunks k+1.. are still on the links -- and returns that chunk's payload / ACKs / pass counts at once; the root's
+    receives of the results were posted behind its sends.  Nothing in it waits on the host with the nccl backend (a
+    work's wait() orders streams); with gloo (CPU tests) the same calls block."""
 
     def __init__(self, tbs: Sequence[dict], root: int = 0, group=None, device=None, numMaxIter: int = 8,
-                 decode_fn: Optional[Callable] = None):
+                 decode_fn: Optional[Callable] = None, chunks: int = 3):
         import torch
         from . import ldpc
         self.ldpc, self.root, self.group, self.numMaxIter, self.decode_fn = ldpc, root, group, numMaxIter, decode_fn
         self.rank, self.world = _rank_world(group)
         self.tbs = [dict(t) for t in tbs]
         self.po, self.co, self.ho, self.segs = ldpc.tb_layout(self.tbs)
-        self.cut = partition_transport_blocks([tb_cost(t) for t in self.tbs], self.world)
+        costs = [tb_cost(t) for t in self.tbs]
+        self.cut = partition_transport_blocks(costs, self.world)
         t0, t1 = self.cut[self.rank], self.cut[self.rank + 1]
         self.t0, self.t1 = t0, t1
         self.local = self.tbs[t0:t1]          # offsets of the local layout = global offsets minus the range start
@@ -171,35 +179,107 @@ class ShardedUlsch:
         self.llr_ranges = [(int(self.co[a]), int(self.co[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.pay_ranges = [(int(self.po[a]), int(self.po[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.tb_ranges = list(zip(self.cut[:-1], self.cut[1:]))
+        # chunk k of rank r = transport blocks [chunk_cut[r][k], chunk_cut[r][k+1]) (global indices), balanced by cost;
+        # the root's own range is one piece (nothing travels)
+        self.chunk_cut = []
+        for r, (a, b) in enumerate(self.tb_ranges):
+            n = 1 if (r == root or self.world == 1) else max(1, min(chunks, b - a))
+            self.chunk_cut.append([a + c for c in partition_transport_blocks(costs[a:b], n)])
         self._buf, self._prepared = None, {}
+
+    # ---- one chunk of this rank's range through the chain --------------------------------------------------------------
+    def _decode_chunk(self, a: int, b: int, llr, rnd: int):
+        """transport blocks [a, b) (global indices, inside this rank's range); llr = this rank's LLR buffer"""
+        if b <= a:
+            return
+        pay, ack, itm = self._buf["pay"], self._buf["ack"], self._buf["itm"]
+        lo = lambda off, i: int(off[i] - off[self.t0])
+        views = (llr[lo(self.co, a):], self.harq[lo(self.ho, a):], pay[lo(self.po, a):], ack[a - self.t0:], itm[a - self.t0:])
+        tbs = self.tbs[a:b]
+        if self.decode_fn is not None:
+            for t in tbs:
+                t["round"] = rnd
+            self.decode_fn(tbs, *views, self.numMaxIter)
+            return
+        # the descriptor array is marshalled once per (LLR buffer, chunk, round) and resubmitted slot after slot
+        key = (llr.data_ptr(), a, b, rnd)
+        if key not in self._prepared:
+            for t in tbs:
+                t["round"] = rnd
+            self._prepared[key] = self.ldpc.PreparedTbBatch(tbs, views[2], views[0], views[1], views[3], views[4], self.numMaxIter)
+        self._prepared[key].decode()
 
     def decode(self, llr_root, rnd: int = 0):
         """Returns (payload uint8 flat in the tb_layout offsets, ack uint8[n_tb], iter_max int32[n_tb]) on root,
         (None, None, None) elsewhere."""
         import torch
+        import torch.distributed as dist
         n_loc = self.t1 - self.t0
+        root, world, rank = self.root, self.world, self.rank
         if self._buf is None:     # persistent local buffers: the per-slot path allocates nothing
             n_llr = max(int(self.co[self.t1] - self.co[self.t0]), 1)
-            self._buf = dict(llr=None if self.rank == self.root else torch.empty((n_llr,), dtype=torch.int16, device=self.device),
+            self._buf = dict(llr=None if rank == root else torch.empty((n_llr,), dtype=torch.int16, device=self.device),
                              pay=torch.zeros((max(int(self.po[self.t1] - self.po[self.t0]), 1),), dtype=torch.uint8, device=self.device),
                              ack=torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=self.device),
                              itm=torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device))
+            if rank == root and world > 1:   # assembled results of the whole slot
+                self._buf.update(pay_all=torch.zeros((int(self.po[-1]),), dtype=torch.uint8, device=self.device),
+                                 ack_all=torch.zeros((len(self.tbs),), dtype=torch.uint8, device=self.device),
+                                 itm_all=torch.zeros((len(self.tbs),), dtype=torch.int32, device=self.device))
         pay, ack, itm = self._buf["pay"], self._buf["ack"], self._buf["itm"]
-        llr = scatter_ranges(llr_root, self.llr_ranges, torch.int16, self.root, self.group, self.device, out=self._buf["llr"])
-        if n_loc:
-            if self.decode_fn is not None:
-                for t in self.local:
-                    t["round"] = rnd
-                self.decode_fn(self.local, llr, self.harq, pay, ack, itm, self.numMaxIter)
+        if world == 1:
+            self._decode_chunk(self.t0, self.t1, llr_root, rnd)
+            total = int(self.po[-1])
+            return (pay[:total] if pay.numel() >= total else torch.cat([pay, pay.new_zeros(total - pay.numel())])), \
+                ack[:len(self.tbs)], itm[:len(self.tbs)]
+        g = self.group
+        peer = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        n_rounds = max(len(c) - 1 for c in self.chunk_cut)
+        if rank == root:
+            works = []
+            for k in range(n_rounds):                                  # LLRs out, chunk-major: every link busy at once
+                ops = [dist.P2POp(dist.isend, llr_root[int(self.co[c[k]]):int(self.co[c[k + 1]])], peer(r), g)
+                       for r, c in enumerate(self.chunk_cut) if r != root and k + 1 < len(c) and c[k + 1] > c[k]]
+                works += dist.batch_isend_irecv(ops) if ops else []
+            self._decode_chunk(self.t0, self.t1, llr_root, rnd)        # own range, while the sends drain
+            pay_all, ack_all, itm_all = self._buf["pay_all"], self._buf["ack_all"], self._buf["itm_all"]
+            for k in range(n_rounds):                                  # results back, in the order the peers produce them
+                ops = []
+                for r, c in enumerate(self.chunk_cut):
+                    if r != root and k + 1 < len(c) and c[k + 1] > c[k]:
+                        a, b = c[k], c[k + 1]
+                        ops += [dist.P2POp(dist.irecv, pay_all[int(self.po[a]):int(self.po[b])], peer(r), g),
+                                dist.P2POp(dist.irecv, ack_all[a:b], peer(r), g),
+                                dist.P2POp(dist.irecv, itm_all[a:b], peer(r), g)]
+                works += dist.batch_isend_irecv(ops) if ops else []
+            if n_loc:
+                pay_all[int(self.po[self.t0]):int(self.po[self.t1])] = pay[:int(self.po[self.t1] - self.po[self.t0])]
+                ack_all[self.t0:self.t1] = ack[:n_loc]
+                itm_all[self.t0:self.t1] = itm[:n_loc]
+            for w in works:
+                w.wait()
+            return pay_all, ack_all, itm_all
+        # ---- a peer ----
+        llr = self._buf["llr"]
+        c = self.chunk_cut[rank]
+        lo = lambda off, i: int(off[i] - off[self.t0])
+        recvs = []
+        for k in range(len(c) - 1):
+            if c[k + 1] > c[k]:
+                recvs.append(dist.batch_isend_irecv([dist.P2POp(dist.irecv, llr[lo(self.co, c[k]):lo(self.co, c[k + 1])], peer(root), g)]))
             else:
-                # the descriptor array is marshalled once per (LLR buffer, round) and resubmitted slot after slot
-                key = (llr.data_ptr(), rnd)
-                if key not in self._prepared:
-                    for t in self.local:
-                        t["round"] = rnd
-                    self._prepared[key] = self.ldpc.PreparedTbBatch(self.local, pay, llr, self.harq, ack, itm, self.numMaxIter)
-                self._prepared[key].decode()
-        pay_all = gather_ranges(pay, self.pay_ranges, int(self.po[-1]), self.root, self.group)
-        ack_all = gather_ranges(ack, self.tb_ranges, len(self.tbs), self.root, self.group)
-        itm_all = gather_ranges(itm, self.tb_ranges, len(self.tbs), self.root, self.group)
-        return pay_all, ack_all, itm_all
+                recvs.append([])
+        sends = []
+        for k in range(len(c) - 1):
+            a, b = c[k], c[k + 1]
+            if b <= a:
+                continue
+            for w in recvs[k]:
+                w.wait()
+            self._decode_chunk(a, b, llr, rnd)
+            sends += dist.batch_isend_irecv([dist.P2POp(dist.isend, pay[lo(self.po, a):lo(self.po, b)], peer(root), g),
+                                             dist.P2POp(dist.isend, ack[a - self.t0:b - self.t0], peer(root), g),
+                                             dist.P2POp(dist.isend, itm[a - self.t0:b - self.t0], peer(root), g)])
+        for w in sends:
+            w.wait()
+        return None, None, None

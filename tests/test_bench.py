@@ -1,0 +1,49 @@
+"""bench.py's launch paths: `--gpus N` spawns its own ranks, and the RCCL path (process group, point-to-point set-up,
+strong-scaling slot) runs on hardware even when the box has one GPU."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_gpus_n_without_a_launcher_spawns_its_own_ranks(built):
+    """`python bench.py --gpus 2` re-executes itself under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1).  Without GPUs the ranks cannot start, but the launcher's report proves both were spawned."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    text = p.stdout + p.stderr
+    assert "launch with torch.distributed.run" not in text
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and "local_rank: 0" in text and ("local_rank: 1" in text or "ChildFailedError" in text), text[-2000:]
+
+
+@pytest.mark.gpu
+def test_rccl_path_runs_on_one_gpu(hip):
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["rank_devices"] == [0] and line["n_gpus"] == 1
+    assert line["value"] > 10.0 and line["roofline"]["frac"] > 0 and line["config"]["mean_passes"] == 9.0
+    s = line["strong_scaling_slot"]
+    assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["transport_blocks_per_rank"] == [64]
+
+
+@pytest.mark.gpu
+def test_plain_single_process_line(hip):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_FORCE_DIST")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-strong"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 0 and line["n_gpus"] == 1 and line["metric"] == "ldpc_decoder_coded_throughput"

@@ -110,6 +110,9 @@ def _tb_worker(rank, world, port, ret):
         tbs = box[0]
         sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6)
         assert sh.cut[0] == 0 and sh.cut[-1] == len(tbs) and 0 < sh.cut[1] < len(tbs)
+        # the peer's range travels and is decoded in three pieces, the root's own range in one
+        assert len(sh.chunk_cut[0]) == 2 and len(sh.chunk_cut[1]) == 4 and sh.chunk_cut[1][0] == sh.cut[1] and sh.chunk_cut[1][-1] == len(tbs)
+        assert sh.chunk_cut[1] == sorted(set(sh.chunk_cut[1]))
         po, co, ho, segs = ldpc.tb_layout(tbs)
         rng = np.random.default_rng(5)
         ref_tbs = [dict(t) for t in tbs]
