@@ -114,6 +114,11 @@ typedef struct {
  * device is usable -- there is no CPU fallback. */
 int32_t LDPCinit(void);
 int32_t LDPCshutdown(void);
+/* Optional loader hook (common/utils/load_module_shlib.c:174-185, checkverfunc_t): called by load_module_version_shlib()
+ * right after dlopen() with the executable's build string; reports this library's and returns 0.  With
+ * NRLDPC_HIP_REQUIRE_BUILD=<text> in the environment it returns -1 -- the loader then refuses the library -- unless the
+ * executable's build string contains <text>. */
+int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion);
 /* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
  * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
  * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);

@@ -52,7 +52,6 @@ struct CodeEntry {
   ldpc_code_desc_t host_multi;      /* small lifting sizes: several blocks per workgroup -- side by side (Zc % 4 == 0) or four
                                        interleaved byte-wise (any Zc, f_sub = 4); f_ok = 0: not for this code */
   ldpc_code_desc_t *dev_multi = nullptr;
-  ldpc_code_desc_t *dev_parts = nullptr; /* resident server, one block on several CUs: srv_parts() part descriptors, or none */
   /* homogeneous launches that fill the GPU with multi-block workgroups at least once */
   bool use_multi(uint32_t n_blocks, int n_cus) const
   {
@@ -225,17 +224,6 @@ Device *device_of_pointer(const void *p)
   return ensure_ready() == 0 ? &g.dev[0] : nullptr;
 }
 
-/* CUs per caller slot of the resident server (ldpc_server.inc.cpp, ldpc_dec_fast_part.h); 1: one block = one CU */
-int srv_parts()
-{
-  static const int v = [] {
-    const char *e = getenv("NRLDPC_HIP_SRV_SPLIT");
-    const int n = e ? atoi(e) : 1;
-    return (n == 2 || n == 4) ? n : 1;
-  }();
-  return v;
-}
-
 int rate_index(int BG, int R)
 {
   if (BG == 1)
@@ -299,19 +287,6 @@ const CodeEntry *get_code(int BG, int Z, int R)
   if (e == hipSuccess && ce->host_multi.f_ok) {
     ce->dev_multi = ce->dev + 2;
     e = hipMemcpy(ce->dev_multi, &ce->host_multi, sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
-  }
-  /* codes whose pass is long on one CU get part descriptors for the server's several-CUs-per-block path */
-  if (e == hipSuccess && srv_parts() > 1 && ce->host_lat.f_ok && ce->host_lat.nedges * ce->host_lat.f_zq >= 8000) {
-    const int np = srv_parts();
-    std::vector<ldpc_code_desc_t> hp(np);
-    bool ok = true;
-    for (int q = 0; q < np && ok; q++)
-      ok = ldpc_build_code_desc_part(BG, Z, R, np, q, &hp[q]) == 0 && hp[q].f_ok;
-    if (ok) {
-      e = hipMalloc(reinterpret_cast<void **>(&ce->dev_parts), np * sizeof(ldpc_code_desc_t));
-      if (e == hipSuccess)
-        e = hipMemcpy(ce->dev_parts, hp.data(), np * sizeof(ldpc_code_desc_t), hipMemcpyHostToDevice);
-    }
   }
   if (prev >= 0)
     (void)hipSetDevice(prev);
@@ -559,7 +534,28 @@ void meter_stop(time_stats_t *ts)
 extern "C" {
 
 const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
-const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.1 (gfx950)"; }
+const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.3 (gfx950)"; }
+
+/* Optional hook of the reference's module loader (common/utils/load_module_shlib.c:174-185: "<modname>_checkbuildver",
+ * modname = "ldpc" whatever the version suffix of the file name, nrLDPC_load.c:48,62): called right after
+ * dlopen() with the executable's build string; a negative return makes the loader refuse the library.  The reference's
+ * in-tree modules demand identical build strings (3gpplte_sse.c:361-372); an out-of-tree library cannot, so the operator
+ * pins what this build was validated against: with NRLDPC_HIP_REQUIRE_BUILD=<text> the library refuses any executable
+ * whose build string does not contain <text> (structure layouts are checked against the reference headers in
+ * tests/test_abi.py -- an executable of another revision may have moved them). */
+int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
+{
+  static char version[] = "libldpc_hip 0.3 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
+  if (shlib_buildversion)
+    *shlib_buildversion = version;
+  const char *need = getenv("NRLDPC_HIP_REQUIRE_BUILD");
+  if (need && *need && (!mainexec_buildversion || !strstr(mainexec_buildversion, need))) {
+    fprintf(stderr, "[libldpc_hip] refusing to load into \"%s\": NRLDPC_HIP_REQUIRE_BUILD=\"%s\"\n",
+            mainexec_buildversion ? mainexec_buildversion : "(null)", need);
+    return -1;
+  }
+  return 0;
+}
 
 int32_t nrLDPC_hip_num_llr(int BG, int Z, int R)
 {
@@ -603,14 +599,6 @@ int32_t nrLDPC_hip_server_stats(int64_t out[8])
     if (n)
       fprintf(stderr, "[libldpc_hip] server, fast decoder per call (only meaningful when every call used it): prologue %.2f us, passes %.2f us\n",
               pro / 100.0 / n, pas / 100.0 / n);
-    if (n && srv.args.parts > 1) {
-      uint64_t ph[5] = {0, 0, 0, 0, 0};
-      for (int i = 0; i < srv.n_slots; i++)
-        for (int k = 0; k < 5; k++)
-          ph[k] += srv.slots[i].ticks_phase[k];
-      fprintf(stderr, "[libldpc_hip] server, %u CUs per block, part 0 per call: check nodes %.2f us, gather + publish %.2f, meeting %.2f, loads + finish %.2f, sweep %.2f\n",
-              srv.args.parts, ph[0] / 100.0 / n, ph[1] / 100.0 / n, ph[2] / 100.0 / n, ph[3] / 100.0 / n, ph[4] / 100.0 / n);
-    }
   }
   for (int i = 0; i < srv.n_slots; i++) {
     out[4] += (int64_t)srv.slots[i].ticks_stage * 10;  /* ns: doorbell seen -> payload staged (GPU clock) */

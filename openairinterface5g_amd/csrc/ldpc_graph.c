@@ -157,7 +157,7 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
    * leaving them in global memory (L2) lets one more workgroup fit on a CU, they are not staged (f_ext_global). */
   const int ext_bytes = (mb > 1 || d->f_sub == 4) ? align16((d->ncols - d->ncore) * d->f_rstride) : align16((d->ncols - d->ncore) * Z);
   const int misc_bytes = (d->f_sub == 4 || mb > 1) ? 1664 : 256; /* ldpc_dec_fast_mblock.h: per-block flag arrays; one block:
-                                                                    16 flag words + the columns' full degrees (ldpc_dec_fast_part.h) */
+                                                                    16 flag words */
   const int llr_bytes = d->f_sub == 4 ? align16(d->ncore * d->f_astride / 2) : 0; /* [ncore][mb][Z] */
   const int fixed = align16(d->nedges * d->f_rstride) + align16(d->ncore * d->f_astride) + align16(d->nedges * 4) +
                     align16(d->f_n_ctbl * 8) + align16(d->nrows * 4) + align16(d->ncore * 4) + align16(mb * (Z + 4)) + misc_bytes + llr_bytes;
@@ -304,10 +304,6 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
         d->col_edge[n++] = ((uint32_t)k << 16) | (d->e_info[k] & 0xffffu);
   }
   d->col_ptr[d->ncore] = n;
-  for (int c = 0; c < d->ncore; c++)
-    d->col_deg_full[c] = d->col_ptr[c + 1] - d->col_ptr[c];
-  d->f_part = 0;
-  d->f_parts = 1;
 
   /* [F6] parity-check lane exclusion.  The reference walks the CNs of one degree class back to back
    * (class = CN group, ascending degree; CNs in base-graph row order, Z lanes each) in 32-lane chunks
@@ -504,61 +500,5 @@ int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_des
   d->Z = 4 * Z; /* (num_llr, ncols, zw and the generic kernel's fields keep describing the real code) */
   d->f_sub = 4;
   build_fast_section(d, LDPC_SHAPE_THROUGHPUT, mb, 0);
-  return 0;
-}
-
-int ldpc_build_code_desc_part(int BG, int Z, int R, int parts, int part, ldpc_code_desc_t *d)
-{
-  ldpc_code_desc_t full;
-  if (parts < 2 || parts > 8 || part < 0 || part >= parts)
-    return -1;
-  if (ldpc_build_code_desc_shape(BG, Z, R, LDPC_SHAPE_LATENCY, &full) != 0)
-    return -1;
-  *d = full;
-  d->f_ok = 0;
-  if (!full.f_ok)
-    return 0;
-  /* rows by degree (descending, stable), dealt round-robin: every part gets its share of every degree class */
-  sort_item_t rows[LDPC_MAX_ROWS];
-  for (int r = 0; r < full.nrows; r++) {
-    rows[r].key = full.row_deg[r];
-    rows[r].id = r;
-  }
-  qsort(rows, full.nrows, sizeof(rows[0]), by_key_desc);
-  int mine[LDPC_MAX_ROWS], nm = 0;
-  for (int k = 0; k < full.nrows; k++)
-    if (k % parts == part)
-      mine[nm++] = rows[k].id;
-  /* keep base-graph order inside the part */
-  for (int a = 1; a < nm; a++)
-    for (int b = a; b > 0 && mine[b] < mine[b - 1]; b--) {
-      const int t = mine[b]; mine[b] = mine[b - 1]; mine[b - 1] = t;
-    }
-  int e = 0;
-  for (int i = 0; i < nm; i++) {
-    const int r = mine[i];
-    d->row_ptr[i] = e;
-    d->row_deg[i] = full.row_deg[r];
-    d->pc_lo[i] = full.pc_lo[r]; /* [F6] is a property of the whole code's degree classes */
-    for (int k = 0; k < full.row_deg[r]; k++, e++) {
-      d->e_col[e] = full.e_col[full.row_ptr[r] + k];
-      d->e_info[e] = full.e_info[full.row_ptr[r] + k];
-    }
-  }
-  d->row_ptr[nm] = e;
-  d->nrows = nm;
-  d->nedges = e;
-  int n = 0;
-  for (int c = 0; c < d->ncore; c++) {
-    d->col_ptr[c] = n;
-    for (int k = 0; k < d->nedges; k++)
-      if (d->e_col[k] == c)
-        d->col_edge[n++] = ((uint32_t)k << 16) | (d->e_info[k] & 0xffffu);
-  }
-  d->col_ptr[d->ncore] = n;
-  /* (col_deg_full stays the whole code's; ncols, num_llr too: a part reads every column's LLRs) */
-  build_fast_section(d, LDPC_SHAPE_LATENCY, 1, 0);
-  d->f_part = part;
-  d->f_parts = parts;
   return 0;
 }

@@ -120,12 +120,6 @@ typedef struct ldpc_code_desc {
    * shifts and pc_lo times 4; num_llr, ncols stay the real code's) and f_mb counts groups of four.  f_lds_llr: the core
    * columns' channel LLRs in the interleaved layout (the bit-node phase reads them every pass).  f_sub = 1 otherwise. */
   int32_t f_sub, f_lds_llr;
-  /* One block on several CUs (resident server, ldpc_dec_fast_part.h): a PART descriptor holds a subset of the rows -- its
-   * edges renumbered, the column adjacency restricted to them -- and all the columns.  col_deg_full[c] = the column's
-   * degree in the whole code (a part sums its own edges' messages; the bias of the total needs the full count);
-   * f_part / f_parts = which part of how many (0 / 1: an ordinary descriptor). */
-  int32_t col_deg_full[LDPC_MAX_CORE + 2];
-  int32_t f_part, f_parts;
   /* 1: the items of the degree-19 rows come in PAIRS of neighbouring lanes, each lane taking half of the row's edges
    * (ldpc_fast_cn19_pair): the group holds 2 x rows x Z/4 items, item = 2 x (row item) + half */
   int32_t f_pair19;
@@ -146,8 +140,6 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
 int ldpc_build_code_desc_multi(int BG, int Z, int R, int mb, ldpc_code_desc_t *d);
 /* any Z: four blocks interleaved byte-wise (f_sub = 4), `mb` such groups per workgroup */
 int ldpc_build_code_desc_interleaved(int BG, int Z, int R, int mb, ldpc_code_desc_t *d);
-/* part `part` of `parts` of the code's rows (degree-sorted rows dealt round-robin), latency shape */
-int ldpc_build_code_desc_part(int BG, int Z, int R, int parts, int part, ldpc_code_desc_t *d);
 /* blocks per workgroup that fill a 64-item task row by row for this lifting size; 1: not worth it */
 int ldpc_multi_blocks_for(int Z);
 /* set index iLS of lifting size Z (38.212 Table 5.3.2-1), -1 if Z is not a lifting size */

@@ -39,7 +39,6 @@
 #define SRV_IN_STRIDE (28u * 1024u)                /* up to 68*384 LLRs, or 8 segments of 1056 B */
 #define SRV_OUT_STRIDE (200u * 1024u)              /* 8 segments x 66*384 coded bytes; decoder: <= 68*384 bytes x 4/3 (tagged units) */
 #define SRV_LDS_BYTES (160 * 1024)
-#define SRV_PART_STRIDE 2504u                      /* = LDPC_PART_STRIDE (ldpc_dec_fast_part.h): 64-bit words per part and parity */
 #define SRV_BC_OFF (SRV_LDS_BYTES - 256)           /* broadcast area at the end of the workgroup's LDS */
 #define SRV_CODE_LDS_MAX SRV_BC_OFF                /* a code is servable when its kernel's LDS fits below */
 
@@ -57,8 +56,7 @@ typedef struct srv_req {   /* ctl line 0, host-written: four chunks of {tag, thr
   uint32_t seg_in_stride, seg_out_stride; /* encoder: bytes between segments in the payload / output area */
   uint32_t payload_bytes;
   uint32_t tag3;
-  uint32_t parts_lo, parts_hi; /* fast decoder on several CUs: device address of the `parts` part descriptors (0: one CU) */
-  uint32_t pad;
+  uint32_t pad[3];
 } srv_req;
 
 typedef struct srv_slot_ctl { /* 64 bytes, GPU-written, in page-locked host memory: */
@@ -89,14 +87,8 @@ typedef struct srv_args {
   uint32_t gen;
   uint32_t idle_ticks;     /* wall_clock64 ticks (100 MHz) */
   const uint32_t *crc_pow_tbl[4];
-  /* one block on several CUs (ldpc_dec_fast_part.h): `parts` workgroups per slot -- part 0 polls the request line and wakes
-   * its siblings through go[slot] (sequence number of the request to join; 0xffffffff: leave) */
   const uint32_t *abort_w; /* per slot (16 words apart), same kind of memory as req: == the request's sequence number when its
                               caller has given the transport block up (decode_abort_t raised by another thread) */
-  uint32_t parts;
-  unsigned long long *exch; /* device, per slot: 2 x parts x LDPC_PART_STRIDE words */
-  unsigned int *meet;       /* device, per slot (16 words apart): arrival counter; zeroed before every launch */
-  unsigned int *go;         /* device, per slot (16 words apart); zeroed before every launch */
 } srv_args;
 
 #endif

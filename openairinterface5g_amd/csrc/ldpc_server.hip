@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 #include "ldpc_server.h"
 #include "ldpc_dec_fast_block.h"
-#include "ldpc_dec_fast_part.h"
 #include "ldpc_dec_generic_block.h"
 #include "ldpc_enc_packed_core.h"
 
@@ -26,10 +25,6 @@
  * and reloaded once per request -- there is no scratch access inside the decoder's phases (checked in the
  * disassembly).  With the encoder's phases compiled into the same kernel the spills reach the hot loops, so LDPCencoder
  * calls are served by a kernel of their own (template parameter ENC: 86 VGPRs, its own slots and stream). */
-/* the several-CUs server: 8 waves per workgroup and twice the registers per thread -- a part has at most half the check-node
- * tasks of the whole code, and at the 128-VGPR limit of a 1024-thread workgroup the exchange's extra live state spills into
- * scratch memory right in its shortest phases */
-#define SRV_THREADS_SPLIT 512
 #ifndef SRV_THREADS
 #define SRV_THREADS 1024
 #endif
@@ -56,9 +51,6 @@ __device__ __forceinline__ void srv_st16_sys(void *p, uint32_t a, uint32_t b, ui
    * third / fourth dwords) */
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
-
-__device__ __forceinline__ uint32_t srv_ld_dev(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void srv_st_dev(unsigned int *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 /* The server loop keeps next to nothing live across a decode: the kernel arguments are re-read from the kernarg segment
  * (scalar loads) where they are needed, the loop state sits in LDS.  Inlined next to a loop with its own live values
@@ -113,48 +105,29 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return srv_ld_sys(p); }
 };
 
-static_assert(SRV_PART_STRIDE == LDPC_PART_STRIDE, "exchange area layout");
-struct srv_part_io : srv_fast_io { /* + what ldpc_dec_fast_part.h needs */
-  int part_, parts_;
-  unsigned long long *exch_;
-  unsigned int *meet_;
-  uint32_t *bcw; /* the workgroup's broadcast words: [22] arrivals expected so far, [23] fault */
-  __device__ __forceinline__ int part() const { return part_; }
-  __device__ __forceinline__ int parts() const { return parts_; }
-  __device__ __forceinline__ unsigned long long *exch() const { return exch_; }
-  __device__ __forceinline__ unsigned int *meet_counter() const { return meet_; }
-  __device__ __forceinline__ uint32_t *meet_target() const { return bcw + 22; }
-  __device__ __forceinline__ uint32_t *fault() const { return bcw + 23; }
-  __device__ __forceinline__ uint32_t *phase_ticks() const { return bcw + 26; }
-};
-
-/* workgroup -> (slot, part): with several parts per slot, the parts of a slot are 8 workgroups apart -- workgroups are
- * dealt to the 8 XCDs round-robin, so a slot's parts share an XCD and its L2 (a performance matter only) */
-__device__ __forceinline__ uint32_t srv_slot_of(uint32_t bid, uint32_t parts) { return parts > 1 ? (bid / (8u * parts)) * 8u + (bid & 7u) : bid; }
-__device__ __forceinline__ uint32_t srv_part_of(uint32_t bid, uint32_t parts) { return parts > 1 ? (bid >> 3) % parts : 0u; }
-
-/* SPLIT: with the several-CUs-per-block path compiled in (launched when srv_args.parts > 1); the one-CU server does not
- * carry its code and registers */
 /* ENC: the encoder server -- its own launch with its own slots, serving LDPCencoder calls only: the decoders' kernels do
  * not carry the encoder's phases (with them inlined next to the decoder the spills reached the decoder's loops) */
-template <bool SPLIT, bool ENC = false>
-__global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
+template <bool ENC = false>
+__global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args args_by_value)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  uint32_t *bc = reinterpret_cast<uint32_t *>(fsm + SRV_BC_OFF); /* [0] doorbell / quit, [1] last served, [2], [3] time stamps, [4..19] request header */
+  /* [0] doorbell / quit, [1] last served, [2], [3] time stamps, [4..19] / [32..47] request header (two copies used in
+   * turn: wave 0 may already be fetching the next request while the other waves still read this one's fields on their way
+   * out of the decoder -- nothing but the PCIe round trip kept them apart before), [20], [21] code whose tables
+   * the LDS holds, [24], [25] the fast decoder's stamps */
+  uint32_t *bc = reinterpret_cast<uint32_t *>(fsm + SRV_BC_OFF);
+  uint32_t hdr = 4; /* where this iteration's header goes: 4 or 32 (wave-uniform, lives in an SGPR) */
   /* laundered wherever it is used: the loads behind it must not be hoisted out of the loop and kept live */
 #define SRV_ARGS() ({ uint64_t p_ = args_u64; asm volatile("" : "+s"(p_)); (srv_args_ptr_t)p_; })
   (void)args_by_value; /* = the kernarg segment, read through the laundered pointer */
   const uint64_t args_u64 = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   srv_args_ptr_t a = SRV_ARGS();
-#define SRV_SLOT() (SPLIT ? srv_slot_of(blockIdx.x, LDPC_UNIFORM(a->parts)) : blockIdx.x)
-#define SRV_PART() (SPLIT ? srv_part_of(blockIdx.x, LDPC_UNIFORM(a->parts)) : 0u)
+#define SRV_SLOT() (blockIdx.x)
   if (threadIdx.x == 0) {
     srv_slot_ctl *slot = a->ctl + SRV_SLOT();
     bc[20] = bc[21] = 0; /* no code's tables in LDS yet */
-    bc[22] = bc[23] = 0; /* several CUs per block: arrivals expected so far (the counter starts at 0 with the kernel); fault */
-    /* part 0: a request the previous generation left unserved shows as doorbell != done; siblings: go words start at 0 */
-    bc[1] = SRV_PART() == 0 ? srv_ld_sys(&slot->done) : 0u;
+    /* a request the previous generation left unserved shows as doorbell != done */
+    bc[1] = srv_ld_sys(&slot->done);
     if (blockIdx.x == 0) {
       atomicMax(&a->gctl->last_activity, (long long)wall_clock64());
       srv_st_sys(a->state, 2u * a->gen + 1u);
@@ -162,30 +135,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
   }
   for (;;) {
     a = SRV_ARGS();
-    if (SPLIT && threadIdx.x < 64 && SRV_PART() != 0) {
-      /* a sibling part waits for part 0's word: the sequence number of a request to join, or 0xffffffff = leave (only
-       * part 0 decides that, so a slot's parts never disagree on whether a request is served) */
-      const int lane = threadIdx.x;
-      const uint32_t last = bc[1];
-      unsigned int *go = a->go + 16u * SRV_SLOT();
-      uint32_t d;
-      for (;;) {
-        d = srv_ld_dev(go);
-        if (d != last)
-          break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      uint32_t word = 0;
-      if (d != 0xffffffffu && lane < 16)
-        word = srv_ld_sys(reinterpret_cast<const uint32_t *>(a->req + SRV_SLOT()) + lane);
-      if (lane < 16)
-        bc[4 + lane] = word;
-      if (lane == 0) {
-        bc[0] = d;
-        bc[2] = (uint32_t)wall_clock64();
-      }
-    }
-    if (threadIdx.x < 64 && SRV_PART() == 0) {
+    if (threadIdx.x < 64) {
       /* wave 0 polls: lanes 0..15 read the 16 words of the slot's request line in ONE load; the request is there when
        * the four chunk tags agree on a number that is not the one served last (ldpc_server.h) */
       const uint32_t *line = reinterpret_cast<const uint32_t *>(a->req + SRV_SLOT());
@@ -218,7 +168,7 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
         __builtin_amdgcn_s_sleep(2);
       }
       if (lane < 16)
-        bc[4 + lane] = word;
+        bc[hdr + lane] = word;
       if (lane == 0) {
         bc[0] = d;
         bc[2] = (uint32_t)wall_clock64();
@@ -226,11 +176,8 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
     }
     __syncthreads();
     const uint32_t d = bc[0];
-    if (d == 0xffffffffu) {
-      if (SPLIT && threadIdx.x == 0 && LDPC_UNIFORM(a->parts) > 1 && SRV_PART() == 0)
-        srv_st_dev(a->go + 16u * SRV_SLOT(), 0xffffffffu); /* the siblings leave with part 0 */
+    if (d == 0xffffffffu)
       break;
-    }
     /* the host wrote the payload before the request line; the poll's load has returned, so the payload loads issued from
      * here on see it -- provided they do not hit in a cache: the fast decoder reads the payload with system-scope loads
      * (srv_fast_io::ld_llr), the generic one behind an acquire fence (below).  A system-scope acquire here would drop
@@ -238,44 +185,15 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
     a = SRV_ARGS();
     if (threadIdx.x == 0)
       bc[3] = (uint32_t)wall_clock64();
-    const srv_req *rq = reinterpret_cast<const srv_req *>(bc + 4);
+    const srv_req *rq = reinterpret_cast<const srv_req *>(bc + hdr);
+    hdr ^= 4u ^ 32u;
     const uint32_t kind = LDPC_UNIFORM(rq->kind_mode) & 0xffu;
     /* (readfirstlane returns int: widen as unsigned, or a low dword >= 2^31 smears ones over the high dword) */
     ldpc_code_ptr_t code = (ldpc_code_ptr_t)(((uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_hi) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_lo));
     const uint8_t *host_in = srv_sgpr(a->in_host + (size_t)SRV_SLOT() * SRV_IN_STRIDE);
     uint8_t *hout = srv_sgpr(a->out_host + (size_t)SRV_SLOT() * SRV_OUT_STRIDE);
     int n_iter = 0;
-    const bool split = SPLIT && kind == SRV_KIND_DEC_FAST && (LDPC_UNIFORM(rq->parts_lo) | LDPC_UNIFORM(rq->parts_hi)) != 0u;
-    if (!ENC && SPLIT && kind == SRV_KIND_DEC_FAST) {
-      /* The several-CUs server runs every fast-decoder request through ldpc_dec_fast_part.h -- one decoder body in the
-       * kernel, not two competing for its registers: a request with part descriptors on all of the slot's CUs (part 0
-       * wakes its siblings, every part takes its descriptor from the request's array), any other as a single part with
-       * the whole code's descriptor. */
-      const uint32_t parts = split ? LDPC_UNIFORM(a->parts) : 1u, part = split ? SRV_PART() : 0u;
-      if (split && part == 0 && threadIdx.x == 0)
-        srv_st_dev(a->go + 16u * SRV_SLOT(), d);
-      const uint64_t pbase = ((uint64_t)(uint32_t)LDPC_UNIFORM(rq->parts_hi) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM(rq->parts_lo);
-      const uint64_t pc = split ? pbase + (uint64_t)part * sizeof(ldpc_code_desc_t)
-                                : (((uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_hi) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM(rq->code_lo));
-      ldpc_code_ptr_t pcode = (ldpc_code_ptr_t)pc;
-      int tid_l = (int)threadIdx.x;
-      const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE); /* one row per workgroup */
-      const bool resident = bc[20] == (uint32_t)pc && bc[21] == (uint32_t)(pc >> 32);
-      srv_part_io io;
-      io.rq = rq; io.host_llr = host_in; io.staged = staged; io.hout = hout; io.a = a; io.st = bc + 24; io.tid_ = tid_l;
-      io.resident_ = resident; io.tag_ = d; io.abw_ = a->abort_w + 16u * SRV_SLOT();
-      io.part_ = (int)part; io.parts_ = (int)parts;
-      io.exch_ = srv_sgpr(a->exch + (size_t)SRV_SLOT() * 2u * LDPC_UNIFORM(a->parts) * LDPC_PART_STRIDE);
-      io.meet_ = srv_sgpr(a->meet + 16u * SRV_SLOT());
-      io.bcw = bc;
-      n_iter = ldpc_dec_fast_part(fsm, pcode, io);
-      if (threadIdx.x == 0) {
-        bc[20] = (uint32_t)pc;
-        bc[21] = (uint32_t)(pc >> 32);
-      }
-      if (bc[23])
-        n_iter = -2; /* a part did not show up at a meeting: the host reports the call as failed */
-    } else if (!ENC && !SPLIT && kind == SRV_KIND_DEC_FAST) {
+    if (!ENC && kind == SRV_KIND_DEC_FAST) {
       int tid_l = (int)threadIdx.x;
       const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
       /* bc[20], bc[21]: the code whose tables this workgroup's LDS holds (0: none) */
@@ -326,12 +244,6 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
      * thread 0 rings, with a system-scope RELEASE store (a plain store was reordered against the result bytes on its way
      * to host memory; a release by the publishing thread alone was overtaken too: about one call in 10^3 came back with
      * stale output bytes). */
-    if (SPLIT && SRV_PART() != 0) { /* a sibling part: nothing to report, back to waiting for part 0's word */
-      __syncthreads();
-      if (threadIdx.x == 0)
-        bc[1] = d;
-      continue;
-    }
     const uint32_t t_decoded = (uint32_t)wall_clock64();
     uint32_t sd = 0, pp = 0;
     if (threadIdx.x == 0) {
@@ -344,9 +256,6 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
     if (kind == SRV_KIND_DEC_FAST) {
       if (threadIdx.x == 0) {
         srv_slot_ctl *slot = a->ctl + SRV_SLOT();
-        if (SPLIT) /* diagnostics: the part decoder's phase clocks (read by the host only with NRLDPC_HIP_SRV_DEBUG) */
-          for (int k = 0; k < 5; k++)
-            srv_st_sys(&slot->pad1[k], bc[26 + k]);
         srv_st16_sys(slot, d, (uint32_t)n_iter, sd, pp);
       }
     } else {
@@ -375,7 +284,6 @@ __global__ void __launch_bounds__(SPLIT ? SRV_THREADS_SPLIT : SRV_THREADS) ldpc_
     srv_st_sys(a->state, 2u * a->gen + 2u);
 #undef SRV_ARGS
 #undef SRV_SLOT
-#undef SRV_PART
 }
 
 int ldpc_server_has_encoder(void) { return 1; }
@@ -386,19 +294,13 @@ hipError_t ldpc_server_init(void)
                                            SRV_LDS_BYTES);
   if (e != hipSuccess)
     return e;
-  const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SRV_LDS_BYTES);
-  if (e2 != hipSuccess)
-    return e2;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             SRV_LDS_BYTES);
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_server_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SRV_LDS_BYTES);
 }
 
 hipError_t ldpc_server_launch(const srv_args &a, uint32_t n_slots, hipStream_t stream, int encoder)
 {
   if (encoder)
-    hipLaunchKernelGGL((ldpc_server_kernel<false, true>), dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
-  else if (a.parts > 1)
-    hipLaunchKernelGGL(ldpc_server_kernel<true>, dim3(n_slots * a.parts), dim3(SRV_THREADS_SPLIT), SRV_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(ldpc_server_kernel<true>, dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
   else
     hipLaunchKernelGGL(ldpc_server_kernel<false>, dim3(n_slots), dim3(SRV_THREADS), SRV_LDS_BYTES, stream, a);
   return hipGetLastError();

@@ -14,7 +14,10 @@
  * threads than slots share them); NRLDPC_HIP_SRV_IDLE_US=<n> the server leaves the GPU after this long without a
  * call (default 20000: ldpctest-style callers spend about a millisecond generating noise between two calls);
  * NRLDPC_HIP_ENC_SERVER=0 / NRLDPC_HIP_ENC_SLOTS=<n>: LDPCencoder's own resident kernel off / its slots (default 16);
- * NRLDPC_HIP_SRV_SPLIT=2|4 CUs per slot: large codes are decoded by that many workgroups together (ldpc_dec_fast_part.h).
+ * NRLDPC_HIP_SRV_WAIT=spin|yield|sleep how a caller waits for its completion line: `spin` never leaves the core (lowest
+ * latency, one core per caller burnt), `yield` (default) spins briefly and then sched_yield()s between looks, `sleep`
+ * sleeps through most of the expected service time (a running average per slot) before it starts looking -- for thread
+ * pools wider than the cores they may burn (profiles/r03/abi_wait_modes.txt has calls/s and CPU-seconds for each).
  */
 #include <emmintrin.h>
 #include <xmmintrin.h>
@@ -38,8 +41,8 @@ struct alignas(64) SrvSlotHost {
   uint64_t calls = 0; /* written by the slot's holder only */
   uint64_t ticks_stage = 0, ticks_decode = 0; /* GPU-side: doorbell seen -> payload staged -> block function returned */
   uint64_t ticks_prologue = 0, ticks_passes = 0; /* fast decoder: staged -> state in LDS -> last pass done */
-  uint64_t ticks_phase[5] = {0, 0, 0, 0, 0};     /* several CUs per block: the part decoder's phases (part 0) */
   double host_wait_s = 0, host_total_s = 0;   /* host-side: doorbell rung -> completion seen; whole call */
+  double avg_wait_s = 0;                      /* running average of the wait (NRLDPC_HIP_SRV_WAIT=sleep) */
 };
 
 struct Server {
@@ -78,13 +81,10 @@ int srv_init_locked(Server &S)
   int n = S.role == 1 ? 16 : 64;
   if ((e = getenv(S.role == 1 ? "NRLDPC_HIP_ENC_SLOTS" : "NRLDPC_HIP_SRV_SLOTS")) && atoi(e) >= 1)
     n = atoi(e);
-  const int parts = S.role == 1 ? 1 : srv_parts();
-  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / (2 * parts))));
-  if (parts > 1)
-    n = std::max(8, n / 8 * 8); /* a slot's parts sit 8 workgroups apart (same XCD): slots come in eights */
+  n = std::min(n, std::min((int)SRV_MAX_SLOTS, std::max(1, g.dev[0].n_cus / 2)));
   int idle_us = 20000;
   if ((e = getenv("NRLDPC_HIP_SRV_IDLE_US")) && atoi(e) >= 1)
-    idle_us = atoi(e);
+    idle_us = std::min(atoi(e), 40000000); /* (idle_ticks is 32 bits of a 100 MHz clock: 42 s) */
   S.status = 1; /* until everything below has worked */
   UseDevice use(g.dev[0]); /* the server lives on the primary device */
   HIP_TRY(ldpc_server_init());
@@ -146,14 +146,7 @@ int srv_init_locked(Server &S)
   a.state = static_cast<uint32_t *>(dp);
   HIP_TRY(hipHostGetDevicePointer(&dp, S.host_stop, 0));
   a.host_stop = static_cast<const uint32_t *>(dp);
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * parts * SRV_IN_STRIDE)); /* one row per workgroup */
-  a.parts = (uint32_t)parts;
-  if (parts > 1) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.exch), (size_t)n * 2 * parts * SRV_PART_STRIDE * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.meet), (size_t)n * 16 * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.go), (size_t)n * 16 * sizeof(unsigned int)));
-    HIP_TRY(hipMemset(a.exch, 0, (size_t)n * 2 * parts * SRV_PART_STRIDE * sizeof(unsigned long long)));
-  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.staging), (size_t)n * SRV_IN_STRIDE)); /* one row per workgroup */
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.gctl), sizeof(srv_gctl)));
   HIP_TRY(hipMemset(a.gctl, 0, sizeof(srv_gctl)));
   a.idle_ticks = (uint32_t)idle_us * 100u; /* wall_clock64: 100 MHz */
@@ -214,11 +207,12 @@ int srv_ensure_running(Server &S)
     return 0;
   srv_args a = S.args;
   a.gen = gcur + 1;
+  /* fault injection for tests/test_gpu_decoder.py: from the n-th launch of the decoder server on, launching fails the way
+   * a HIP error would (NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH=<n>) */
+  static const int fail_from = [] { const char *e = getenv("NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH"); return e ? atoi(e) : 0; }();
+  if (fail_from > 0 && S.role == 0 && (int)a.gen >= fail_from)
+    return set_error("resident server: launch failed (injected by NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH)");
   UseDevice use(g.dev[0]);
-  if (a.parts > 1) { /* a generation starts with its meeting counters and go words at zero (behind the previous one: same stream) */
-    HIP_TRY(hipMemsetAsync(a.meet, 0, (size_t)S.n_slots * 16 * sizeof(unsigned int), S.stream));
-    HIP_TRY(hipMemsetAsync(a.go, 0, (size_t)S.n_slots * 16 * sizeof(unsigned int), S.stream));
-  }
   HIP_TRY(ldpc_server_launch(a, (uint32_t)S.n_slots, S.stream, S.role));
   S.gen.store(gcur + 1, std::memory_order_release);
   return 0;
@@ -245,6 +239,30 @@ void srv_stop_at_exit()
 }
 
 thread_local int tls_srv_slot[2] = {-1, -1};
+
+enum { SRV_WAIT_SPIN = 0, SRV_WAIT_YIELD = 1, SRV_WAIT_SLEEP = 2 };
+int srv_wait_mode()
+{
+  static const int v = [] {
+    const char *e = getenv("NRLDPC_HIP_SRV_WAIT");
+    if (e && !strcmp(e, "spin"))
+      return (int)SRV_WAIT_SPIN;
+    if (e && !strcmp(e, "sleep"))
+      return (int)SRV_WAIT_SLEEP;
+    return (int)SRV_WAIT_YIELD;
+  }();
+  return v;
+}
+
+/* The server cannot be (re)launched any more (HIP error): every later call takes the launch-per-call path, which reports
+ * its own errors; the slot of the call that found out is retired with its request still rung -- a generation that did
+ * start would serve it into the slot's areas while another caller owns them. */
+void srv_give_up(Server &S, int slot)
+{
+  S.status.store(1, std::memory_order_release);
+  tls_srv_slot[S.role] = -1;
+  (void)slot; /* its busy flag stays set: nobody is handed this slot again */
+}
 
 inline double srv_now()
 {
@@ -293,7 +311,6 @@ int srv_submit(Server &S, const SrvCall &c, srv_req &rq, int32_t *n_iter, decode
   q->seg_in_stride = rq.seg_in_stride; q->seg_out_stride = rq.seg_out_stride; q->payload_bytes = rq.payload_bytes;
   q->code_lo = rq.code_lo; q->code_hi = rq.code_hi; q->kb_nseg = rq.kb_nseg;
   q->kind_mode = rq.kind_mode; q->max_pass = rq.max_pass; q->crcE = rq.crcE;
-  q->parts_lo = rq.parts_lo; q->parts_hi = rq.parts_hi;
   __builtin_ia32_sfence();
   __atomic_store_n(&c.req->tag3, seq, __ATOMIC_RELEASE);
   __atomic_store_n(&c.req->tag2, seq, __ATOMIC_RELEASE);
@@ -301,6 +318,13 @@ int srv_submit(Server &S, const SrvCall &c, srv_req &rq, int32_t *n_iter, decode
   __atomic_store_n(&c.req->tag0, seq, __ATOMIC_RELEASE); /* (plain stores only: a locked instruction on BAR memory is a bus lock) */
   __builtin_ia32_sfence(); /* push the line out now */
   bool told = false;
+  const int wait_mode = srv_wait_mode();
+  if (wait_mode == SRV_WAIT_SLEEP && h.avg_wait_s > 30e-6) {
+    /* sleep through ~70 % of what the last calls of this slot took (minus the timer's own slack), then look */
+    struct timespec ts = {0, (long)((h.avg_wait_s * 0.7 - 10e-6) * 1e9)};
+    if (ts.tv_nsec > 0)
+      nanosleep(&ts, nullptr);
+  }
   for (uint32_t spins = 0;; spins++) {
     if (__atomic_load_n(&c.ctl->done, __ATOMIC_ACQUIRE) == seq)
       break;
@@ -312,26 +336,23 @@ int srv_submit(Server &S, const SrvCall &c, srv_req &rq, int32_t *n_iter, decode
       told = true;
     }
     if ((spins & 7) == 0 && srv_ensure_running(S) != 0)
-      return -1;
-    if (spins < 32)
+      return -2; /* the slot is lost with its request rung: the caller retires it */
+    if (spins < 32 || wait_mode == SRV_WAIT_SPIN)
       __builtin_ia32_pause();
     else
       sched_yield(); /* callers outnumber cores on a loaded box: give the others the CPU while the GPU works */
   }
-  h.host_wait_s += srv_now() - t_ring;
+  const double waited = srv_now() - t_ring;
+  h.host_wait_s += waited;
+  h.avg_wait_s = h.avg_wait_s == 0 ? waited : 0.875 * h.avg_wait_s + 0.125 * waited;
   const int32_t n_rep = __atomic_load_n(&c.ctl->n_iter, __ATOMIC_RELAXED);
   if (n_iter)
     *n_iter = n_rep;
-  if (n_rep == -2)
-    return set_error("resident server: a workgroup of the slot did not join the decode (protocol fault)");
   const uint32_t sd = c.ctl->t_stage_decode, pp = c.ctl->t_pro_passes;
   h.ticks_stage += sd & 0xffffu;
   h.ticks_decode += sd >> 16;
   h.ticks_prologue += pp & 0xffffu;
   h.ticks_passes += pp >> 16;
-  if (S.args.parts > 1)
-    for (int k = 0; k < 5; k++)
-      h.ticks_phase[k] += c.ctl->pad1[k];
   return 0;
 }
 
@@ -364,14 +385,13 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
   rq.code_lo = (uint32_t)code;
   rq.code_hi = (uint32_t)(code >> 32);
   rq.payload_bytes = (uint32_t)hl.num_llr;
-  if (kind == SRV_KIND_DEC_FAST && ce->dev_parts && srv.args.parts > 1) { /* all of the slot's CUs on this block */
-    const uint64_t pa = reinterpret_cast<uint64_t>(ce->dev_parts);
-    rq.parts_lo = (uint32_t)pa;
-    rq.parts_hi = (uint32_t)(pa >> 32);
-  }
   memcpy(c.in, llr, (size_t)hl.num_llr);
   int32_t n = 0;
-  const int rc = srv_submit(S, c, rq, &n, ab);
+  int rc = srv_submit(S, c, rq, &n, ab);
+  if (rc == -2) {
+    srv_give_up(S, c.slot);
+    return -1;
+  }
   if (rc == 0) {
     *n_iter = n;
     if ((!a.use_crc || n >= 3) && n <= (int32_t)p->numMaxIter + 1) { /* (numMaxIter + 2: given up on the way, nothing was written) */ /* the reference leaves p_out untouched otherwise (decoder.c:849-861) */
@@ -387,11 +407,26 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
         for (int u = 0; u < n_units; u++) {
           const __m128i *src = reinterpret_cast<const __m128i *>(c.out) + u;
           __m128i v = _mm_load_si128(src);
+          double t_unit = 0;
           for (uint32_t spins = 0; (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi32(v, 0xff)) != seq; spins++) {
             __builtin_ia32_pause();
-            if ((spins & 0xfff) == 0xfff && srv_ensure_running(S) != 0)
-              break;
+            if ((spins & 0xfff) == 0xfff) {
+              /* The completion line has arrived, so the unit's store left the GPU before it: microseconds at most.  A unit
+               * that stays away means the stores were lost with their generation (device reset, process being torn
+               * down): the call FAILS -- never a stale unit copied out under rc 0. */
+              const double now = srv_now();
+              if (t_unit == 0)
+                t_unit = now;
+              if (srv_ensure_running(S) != 0 || now - t_unit > 0.5) {
+                rc = -1;
+                break;
+              }
+            }
             v = _mm_load_si128(src);
+          }
+          if (rc != 0) {
+            set_error("resident server: the output of a completed call never arrived");
+            break;
           }
           const int left = ob - 12 * u;
           if (left >= 12) {
@@ -440,6 +475,10 @@ int srv_encode(const CodeEntry *ce, int Kb, uint8_t **input, uint8_t **output, u
   meter_start(tparity);
   const int rc = srv_submit(S, c, rq, nullptr);
   meter_stop(tparity);
+  if (rc == -2) {
+    srv_give_up(S, c.slot);
+    return -1;
+  }
   meter_start(toutput);
   if (rc == 0)
     for (unsigned j = 0; j < n; j++)

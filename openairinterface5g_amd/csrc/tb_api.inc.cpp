@@ -51,6 +51,12 @@ struct TbPlan {
   size_t ext[6] = {0, 0, 0, 0, 0, 0}; /* [lo, hi) of the payload, coded and harq ranges the blocks touch */
   uint32_t rx_lds_elems = 8; /* LDS the de-matching kernel needs per workgroup (int16 slots) */
   bool out_dense = true; /* the blocks' outputs tile their range: one copy back; else one per block (nothing between them is touched) */
+  /* decode, host buffers: the blocks' soft buffers tile [ext[4], ext[5]) -- one copy each way; otherwise (gaps between
+   * them, a sharded batch whose offsets are not monotonic, another thread's blocks in between) one copy per block each
+   * way, so that a call never writes back soft values it does not own.  (First transmissions are uploaded
+   * too: the kernel clears Ncb values per segment, what lies behind them in the caller's array must come back unchanged.) */
+  bool harq_dense = true;
+  std::vector<size_t> harq_span; /* per block: {first int16, int16 count} */
   size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int threads[2] = {64, 64}, lds[2] = {0, 0};
   size_t n_fast = 0, n_gen = 0;
@@ -185,7 +191,7 @@ namespace {
 /* [lo, hi) ranges of the caller's buffers that the transport blocks tb[0 .. n) touch (bytes / int16 elements) */
 struct TbExtent {
   size_t pay_lo = SIZE_MAX, pay_hi = 0, cod_lo = SIZE_MAX, cod_hi = 0, harq_lo = SIZE_MAX, harq_hi = 0;
-  size_t pay_sum = 0, cod_sum = 0; /* bytes / elements the blocks own: == hi - lo when they tile their range */
+  size_t pay_sum = 0, cod_sum = 0, harq_sum = 0; /* bytes / elements the blocks own: == hi - lo when they tile their range */
   void add(size_t &lo, size_t &hi, size_t a, size_t b)
   {
     lo = std::min(lo, a);
@@ -367,6 +373,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     Arena ar;
     int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
     TbExtent ex;
+    std::vector<size_t> harq_span;
     uint32_t rx_lds_elems = 8;
     /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
     uint32_t n_seg_total = 0;
@@ -407,6 +414,9 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
       ex.add(ex.harq_lo, ex.harq_hi, (size_t)t.harq_off, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
       ex.pay_sum += t.A / 8;
+      ex.harq_sum += (size_t)sg.C * b->harq_stride;
+      harq_span.push_back((size_t)t.harq_off);
+      harq_span.push_back((size_t)sg.C * b->harq_stride);
       uint32_t r_offset = 0;
       int llrLen = t.llrLen;
       for (uint32_t r = 0; r < sg.C; r++) {
@@ -479,6 +489,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     pl.n_seg = n_seg; pl.scratch_top = ar.top;
     pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi; pl.ext[4] = ex.harq_lo; pl.ext[5] = ex.harq_hi;
     pl.out_dense = ex.pay_sum == ex.pay_hi - ex.pay_lo;
+    pl.harq_dense = ex.harq_sum == ex.harq_hi - ex.harq_lo;
+    pl.harq_span.swap(harq_span);
     pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
     pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
     pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
@@ -508,7 +520,15 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         c.io_small.ensure((size_t)ntb * 8 + 64) != 0 || c.small_h.ensure((size_t)ntb * 8 + 64) != 0)
       return -1;
     HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq + harq_lo, harq_n * 2, hipMemcpyHostToDevice, s));
+    {
+      if (pl.harq_dense) {
+        HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq + harq_lo, harq_n * 2, hipMemcpyHostToDevice, s));
+      } else {
+        for (uint32_t i = 0; i < ntb; i++)
+            HIP_TRY(hipMemcpyAsync(c.io_harq.p + (pl.harq_span[2 * i] - harq_lo) * 2, b->harq + pl.harq_span[2 * i], pl.harq_span[2 * i + 1] * 2,
+                                   hipMemcpyHostToDevice, s));
+      }
+    }
     payload = c.io_payload.p - pay_lo;
     llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
     harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
@@ -549,7 +569,13 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         HIP_TRY(hipMemcpyAsync(b->payload + tbs[i].payload_off, c.io_payload.p + (tbs[i].payload_off - pl.ext[0]), tbs[i].A / 8,
                                hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipMemcpyAsync(b->harq + pl.ext[4], c.io_harq.p, (pl.ext[5] - pl.ext[4]) * 2, hipMemcpyDeviceToHost, s));
+    if (pl.harq_dense) {
+      HIP_TRY(hipMemcpyAsync(b->harq + pl.ext[4], c.io_harq.p, (pl.ext[5] - pl.ext[4]) * 2, hipMemcpyDeviceToHost, s));
+    } else {
+      for (uint32_t i = 0; i < ntb; i++)
+        HIP_TRY(hipMemcpyAsync(b->harq + pl.harq_span[2 * i], c.io_harq.p + (pl.harq_span[2 * i] - pl.ext[4]) * 2, pl.harq_span[2 * i + 1] * 2,
+                               hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)ntb * 5, hipMemcpyDeviceToHost, s));
   }
   return 0;

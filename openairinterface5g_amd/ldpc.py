@@ -78,7 +78,7 @@ class nrLDPC_hip_enc_batch_t(C.Structure):
 # any non-NULL pointer selects CRC early stop; the library never calls it (include/nrLDPC_hip.h)
 _CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
 
-EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "LDPCdecoder_batch", "LDPCencoder_batch",
+EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "LDPCdecoder_batch", "LDPCencoder_batch",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
 
@@ -368,17 +368,21 @@ def dlsch_encode_host(tbs, payloads):
     return [coded[co[i]:co[i] + tbs[i]["G"]].copy() for i in range(len(tbs))]
 
 
-def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8):
+def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None):
     """RX chain for a batch of transport blocks, host buffers.  llrs: list of int16[G]; harq: int16 array
     [total segments, HARQ_STRIDE] holding the soft buffers of all TBs back to back (updated in place); each tb dict
-    may carry 'round' and 'llrLen' ('llrLen' is updated).  Returns (payloads, ack bool[n], iter_max int32[n])."""
+    may carry 'round' and 'llrLen' ('llrLen' is updated).  harq_off: explicit int16 offsets of the TBs' soft buffers in
+    `harq` (any order, gaps allowed) instead of back to back.  Returns (payloads, ack bool[n], iter_max int32[n])."""
     L = _tb_lib()
     n = len(tbs)
     po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
     co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
     segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
     ho = np.cumsum([0] + [c * HARQ_STRIDE for c in segs])
-    assert harq.dtype == np.int16 and harq.flags.c_contiguous and harq.size >= ho[-1]
+    if harq_off is not None:
+        ho = list(harq_off)
+        assert len(ho) == n and all(o + c * HARQ_STRIDE <= harq.size for o, c in zip(ho, segs))
+    assert harq.dtype == np.int16 and harq.flags.c_contiguous and harq.size >= max(o + c * HARQ_STRIDE for o, c in zip(ho, segs))
     pay = np.zeros(int(po[-1]) + 16, np.uint8)
     llr = np.zeros(int(co[-1]) + 16, np.int16)
     for i, x in enumerate(llrs):

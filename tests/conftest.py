@@ -23,6 +23,17 @@ def built():
 @pytest.fixture(scope="session")
 def hip(built):
     """The product library, initialised on the GPU. Fails loudly (no fallback) when there is no device."""
+    import hashlib
+    import json
     import openairinterface5g_amd as pkg
+    # the GPU box has no reference tree: prove here, in every `-m gpu` run, that the code tables compiled into the product
+    # and into the oracle are the ones validated against nrLDPC_lut.h / bgs/BG*_I* in the development container
+    # (tests/test_tables.py, which is not gpu-marked and therefore not part of the driver's GPU run)
+    pinned = json.loads((ROOT / "tests" / "golden" / "table_hashes.json").read_text())
+    for name, path in (("product", ROOT / "openairinterface5g_amd" / "csrc" / "nr_ldpc_bg_tables.h"),
+                       ("oracle", ROOT / "oracle" / "oracle_bg_tables.h")):
+        assert hashlib.sha256(path.read_bytes()).hexdigest() == pinned[name]["sha256"], f"{name} tables differ from the validated ones"
+    lib, so_src = pkg.ldpc.LIB_PATH, ROOT / "openairinterface5g_amd" / "csrc" / "nr_ldpc_bg_tables.h"
+    assert lib.stat().st_mtime >= so_src.stat().st_mtime, "libldpc_hip.so is older than its table header"
     pkg.LDPCinit()
     return pkg

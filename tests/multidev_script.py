@@ -32,6 +32,21 @@ res["tx"] = np.concatenate(f)
 segs = [hip.ldpc.nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
 harq = np.zeros((sum(segs), hip.ldpc.HARQ_STRIDE), np.int16)
 rx = [dict(t) for t in tbs]
+# 3. the same two rounds once more with the soft buffers scattered: reverse TB order, one stride of somebody else's data
+#    (a sentinel pattern) between them -- results as in 2., and not one sentinel value may change (a device's
+#    share of a sharded batch must not write back soft values it does not own)
+S = hip.ldpc.HARQ_STRIDE
+off3, pos = [0] * len(tbs), 0
+for i in reversed(range(len(tbs))):
+    pos += S
+    off3[i] = pos
+    pos += segs[i] * S
+harq3 = np.full(pos + S, 0x5A5A, np.int16)
+own = np.zeros(harq3.size, bool)
+for i in range(len(tbs)):
+    harq3[off3[i]:off3[i] + segs[i] * S] = 0
+    own[off3[i]:off3[i] + segs[i] * S] = True
+rx3 = [dict(t) for t in tbs]
 for rnd in range(2):
     llrs = []
     for t, c in zip(rx, f):
@@ -44,5 +59,12 @@ for rnd in range(2):
     res[f"rx{rnd}_ack"], res[f"rx{rnd}_itm"] = np.asarray(ack), np.asarray(itm)
     res[f"rx{rnd}_harq"] = harq.copy()
     res[f"rx{rnd}_llrLen"] = np.array([t.get("llrLen", 0) for t in rx])
+    for t in rx3:
+        t["round"] = rnd
+    outp3, ack3, itm3 = hip.ldpc.ulsch_decode_host(rx3, llrs, harq3, numMaxIter=8, harq_off=off3)
+    same = np.array_equal(np.concatenate(outp3), res[f"rx{rnd}_pay"]) and np.array_equal(ack3, ack) and np.array_equal(itm3, itm)
+    same &= all(np.array_equal(harq3[off3[i]:off3[i] + segs[i] * S].reshape(segs[i], S), harq[sum(segs[:i]):sum(segs[:i + 1])])
+                for i in range(len(tbs)))
+    res[f"rx{rnd}_scattered_equal"] = np.array([same, bool((harq3[~own] == 0x5A5A).all())])
 np.savez(sys.argv[1], **res)
 print("ok")

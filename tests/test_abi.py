@@ -29,10 +29,30 @@ def test_library_exports_every_declared_symbol(built):
     out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.ldpc.LIB_PATH)], capture_output=True, text=True).stdout
     for n in ("LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder"):
         assert re.search(rf"\bT {n}$", out, flags=re.M), n
+    # nothing but the declared functions is visible: OAI loads plugins RTLD_GLOBAL (load_module_shlib.c:160), helper names
+    # (graph builders, kernel launchers, host-side segmentation helpers) must not land in the executable's namespace
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split()[1:2] and l.split()[1] in "TDBR")
+    assert exported == names, sorted(set(exported) ^ set(names))
     # ... and the replacement must not need host-executable symbols the way the reference .so does
     und = subprocess.run(["nm", "-D", "--undefined-only", str(pkg.ldpc.LIB_PATH)], capture_output=True, text=True).stdout
     for bad in ("g_log", "logRecord_mt", "exit_function", "opp_enabled"):
         assert bad not in und
+
+
+def test_loader_version_hook(built):
+    """ldpc_checkbuildver, the hook load_module_version_shlib() calls after dlopen (load_module_shlib.c:174-185): reports
+    the library's build string; NRLDPC_HIP_REQUIRE_BUILD turns a foreign executable into a load-time refusal."""
+    import os
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import openairinterface5g_amd as p; L = p.load_library();"
+            "v = C.c_char_p(); L.ldpc_checkbuildver.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)];"
+            "rc = L.ldpc_checkbuildver(b'Branch: develop Abrev. Hash: 0123abc Date: x', C.byref(v)); print(rc, v.value.decode())" % str(ROOT))
+    for need, rc in ((None, 0), ("0123abc", 0), ("Hash: ffff", -1)):
+        env = {k: v for k, v in os.environ.items() if k != "NRLDPC_HIP_REQUIRE_BUILD"}
+        if need:
+            env["NRLDPC_HIP_REQUIRE_BUILD"] = need
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.stdout.split()[0] == str(rc) and "libldpc_hip" in r.stdout and "gfx950" in r.stdout, (need, r.stdout, r.stderr)
 
 
 def test_introspection_without_gpu(built):

@@ -482,6 +482,8 @@ def test_host_batches_sharded_over_logical_devices(hip, tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert not a["rx0_ack"].all() and a["rx1_ack"].sum() > a["rx0_ack"].sum()   # round 0 loses blocks, combining recovers them
+    for o in outs:      # scattered, gapped, reverse-ordered soft buffers: same results, the gaps untouched
+        assert o["rx0_scattered_equal"].all() and o["rx1_scattered_equal"].all()
 
 
 def test_abort_stops_the_siblings_of_a_failed_segment(hip):
