@@ -49,6 +49,7 @@
  *                             check-node phase when the block has converged); same results, same pass counts */
 
 #define LDPC_EAGER_MAX_BAD_LANES 96
+#define LDPC_TIMING_SLOTS 20
 
 /* next ticket of a task queue (wave-uniform) */
 __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
@@ -126,9 +127,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   if (!have_tables)
     for (int i = tid; i < (Z + 4) >> 2; i += nt)
       reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
-  if (tid < 8)
-    flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen,
-                       [4], [5] task queues of the two phases */
+  if (tid < 16)
+    flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen, [6] eager check,
+                       [8], [9] check-node task queues of even / odd passes, [10], [11] bit-node task queues likewise */
   /* (the message array is not initialised: the first check-node phase takes r = 0 without reading it and writes every
    * message, wrap-around bytes included)
    * APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
@@ -167,19 +168,45 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   const int max_pass = io.max_pass();
   int n_iter = max_pass;
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
+  int cn_ticket = 0;
+#ifdef LDPC_TIMING
+  /* diagnostic build (tools/task_timing.sh): block 0 logs, for pass 2, every task of every wave into its (oversized)
+   * output row as {start << 20 | phase << 8 | degree or loop bound, end} in shader clocks */
+  long long *tlog = reinterpret_cast<long long *>(io.out()) + (tid >> 6) * 2 * LDPC_TIMING_SLOTS;
+  int tlog_n = 0;
+  const long long t_kernel0 = clock64();
+#define LDPC_TLOG_BEGIN() const long long tl0_ = clock64()
+#define LDPC_TLOG_END(phase, deg) \
+  do { \
+    if (blockIdx.x == 0 && p == 2 && lane == 0 && tlog_n < LDPC_TIMING_SLOTS) { \
+      tlog[2 * tlog_n] = ((tl0_ - t_kernel0) << 20) | ((long long)(phase) << 8) | (long long)(deg); \
+      tlog[2 * tlog_n + 1] = clock64() - t_kernel0; \
+      tlog_n++; \
+    } \
+  } while (0)
+#else
+#define LDPC_TLOG_BEGIN() do { } while (0)
+#define LDPC_TLOG_END(phase, deg) do { } while (0)
+#endif
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
     const uint32_t ab_word = (io.has_abort() && tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
+    int *cnq = &flags[8 + (p & 1)], *bnq = &flags[10 + (p & 1)]; /* this pass' task queues */
+    (void)cnq;
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
     /* The phase's tasks are drawn in id order (= most expensive first, ldpc_graph.c) from a queue -- an LDS counter --
      * by whichever wave is free: the SIMD issue arbiter favours a CU's older waves, so static equal shares leave the
      * SIMDs with one or two live waves for the last third of a phase (profiles/r01/task_timeline.txt). */
-    for (;;) {
-      const int task = ldpc_draw(&flags[4], lane);
-      if (task >= n_cn_tasks)
-        break;
+    /* The first ticket of a phase is drawn BEFORE the barrier in front of it (at the end of the other phase; the queues
+     * of odd and even passes are different counters, each reset two barriers ahead of its first draw), so that a wave
+     * comes out of the barrier with its task in hand: the draw is an LDS atomic round trip, and right after a barrier
+     * nobody has work to hide it behind (profiles/r03/timeline_*.txt: 1.3 k clocks between the phases). */
+    if (p == 1)
+      cn_ticket = ldpc_draw(cnq, lane);
+    for (int task = cn_ticket; task < n_cn_tasks; task = ldpc_draw(cnq, lane)) {
+      LDPC_TLOG_BEGIN();
       const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
       const int item = code->f_cn_task[task][2] + lane;
       const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
@@ -203,8 +230,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         syn |= m & mask;
       }
+      LDPC_TLOG_END(0, deg);
     }
 #endif
+    const int bn_ticket = ldpc_draw(bnq, lane);
     {
       /* flags[p & 1] = how many lanes saw an unsatisfied check of the previous pass (0 = none: the stop criterion; the
        * count itself only steers the eager check below) */
@@ -214,7 +243,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     }
     if (tid == 0) {
       flags[2] = 0;
-      flags[5] = 0; /* nobody draws bit-node tasks now */
+      flags[8 + ((p + 1) & 1)] = 0; /* the next pass' queues: last drawn from before the previous pass' barriers, */
+      flags[10 + ((p + 1) & 1)] = 0; /* first drawn from behind the barrier below */
       /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
       if (io.tb_abort() && p >= 2 && __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         flags[3] = 1;
@@ -235,11 +265,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       break;
     }
 #ifndef LDPC_ABLATE_BN
-    for (;;) {
-      const int ticket = ldpc_draw(&flags[5], lane);
-      if (ticket * bn_group >= n_bn_tasks)
-        break;
+    for (int ticket = bn_ticket; ticket * bn_group < n_bn_tasks; ticket = ldpc_draw(bnq, lane)) {
       for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
+        LDPC_TLOG_BEGIN();
         const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
         const int maxdeg = code->f_bn_task[task][2];
         if (item < end) {
@@ -248,13 +276,13 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
           const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
           ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
         }
+        LDPC_TLOG_END(1, maxdeg);
       }
     }
 #endif
-    if (tid == 0) {
+    cn_ticket = ldpc_draw(&flags[8 + ((p + 1) & 1)], lane);
+    if (tid == 0)
       flags[(p + 1) & 1] = 0;
-      flags[4] = 0; /* nobody draws check-node tasks now */
-    }
     __syncthreads();
     if (io.eager_check() && !io.use_crc() && p >= 2 && p < max_pass && bad_prev <= LDPC_EAGER_MAX_BAD_LANES) {
       /* the check the next pass would make first thing (decoder.c:842-848: cnProcPc on this pass' results; p + 1 >= 3 and
@@ -323,6 +351,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     __hip_atomic_store(io.tb_abort(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   /* ---- hard decision ------------------------------------------------------------------------------------- */
+#ifdef LDPC_TIMING
+  if (blockIdx.x == 0)
+    return n_iter; /* (its output row holds the log) */
+#endif
   if ((!io.use_crc() || n_iter >= 3) && n_iter <= max_pass) {
     /* output dword w: packed bits 32w .. 32w+31 MSB first (bnProc.h:1353-1380), resp. bits 4w .. 4w+3 one per byte */
     auto bits_word = [&](int w) -> uint32_t {

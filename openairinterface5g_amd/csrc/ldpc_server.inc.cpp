@@ -209,7 +209,8 @@ int srv_ensure_running(Server &S)
   a.gen = gcur + 1;
   /* fault injection for tests/test_gpu_decoder.py: from the n-th launch of the decoder server on, launching fails the way
    * a HIP error would (NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH=<n>) */
-  static const int fail_from = [] { const char *e = getenv("NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH"); return e ? atoi(e) : 0; }();
+  const char *fe = getenv("NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH"); /* (read per launch: a test arms it after its own set-up) */
+  const int fail_from = fe ? atoi(fe) : 0;
   if (fail_from > 0 && S.role == 0 && (int)a.gen >= fail_from)
     return set_error("resident server: launch failed (injected by NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH)");
   UseDevice use(g.dev[0]);

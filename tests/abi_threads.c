@@ -56,7 +56,7 @@ static void *worker(void *arg)
       fprintf(stderr, "thread %d call %d at %.3f ms\n", tid, i, (t.tv_sec - t_start.tv_sec) * 1e3 + (t.tv_nsec - t_start.tv_nsec) / 1e6);
     }
     const int n = dec(&p, 0, 0, 0, llr[c], (int8_t *)out, NULL, NULL);
-    if (allow_nack && n == prm[c].numMaxIter + 1 && n != expect_iter[c]) {
+    if (allow_nack && n == prm[c].numMaxIter + 1) { /* (also for a case that fails to decode anyway: a real failure writes p_out) */
       int touched = 0;
       for (int k = 0; k < out_len[c]; k++) touched |= out[k] != 0xA5;
       if (!touched) { __sync_fetch_and_add(&nacked, 1); continue; }
@@ -115,6 +115,8 @@ int main(int argc, char **argv)
     expect_iter[c] = dec(&p, 0, 0, 0, llr[c], (int8_t *)expect[c], NULL, NULL);
     if (expect_iter[c] < 0) { fprintf(stderr, "case %d failed single-threaded\n", c); return 1; }
   }
+  if (getenv("ABI_FAIL_LAUNCHES_FROM_NOW")) /* fault injection: the resident server cannot be (re)launched any more */
+    setenv("NRLDPC_HIP_SRV_TEST_FAIL_LAUNCH", "1", 1);
   pthread_t th[256];
   struct timespec a, b;
   struct rusage ru0, ru1;
