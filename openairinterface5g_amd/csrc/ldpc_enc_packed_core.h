@@ -60,6 +60,13 @@ LDPC_ENCP_HOSTDEV int ldpc_encp_threads(int nrows, int Z)
   return n < 64 ? 64 : (n > LDPC_ENCP_MAX_THREADS ? LDPC_ENCP_MAX_THREADS : n);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+LDPC_HD void ldpc_encp_xor_into(uint32_t *p, uint32_t v) { atomicXor(p, v); }
+#else
+LDPC_HD void ldpc_encp_xor_into(uint32_t *p, uint32_t v) { *p ^= v; } /* (CPU emulation: one thread at a time) */
+#endif
+#define LDPC_ENCP_LAMBDA_SLICES 4 /* lanes that share one (core row, word) item of phase 2 */
+
 /* 32 bits of the bit string s starting at bit offset o */
 LDPC_HD uint32_t ldpc_bits_at(const uint32_t *s, uint32_t o)
 {
@@ -118,8 +125,8 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
     }
     for (int c = tid; c < ncols; c += nt)
       L.B[c * bs + W] = 0u;
-    if (tid < 4)
-      L.LB[tid * bs + W] = 0u;
+    for (int i = tid; i < 4 * bs; i += nt)
+      L.LB[i] = 0u; /* phase 2 accumulates into it */
     for (int e = tid; e < code->nedges; e += nt)
       L.ET[e] = ((uint32_t)code->e_col[e] << 16) | (code->e_info[e] & 0xffffu);
     for (int r = tid; r <= code->nrows; r += nt)
@@ -127,18 +134,34 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
   } else if (phase == 1) {
     ldpc_encp_extend(L.B, L.X, kbf, Z, tid, nt);
   } else if (phase == 2) {
-    /* lambda_row = XOR over the information edges of core row `row` */
-    for (int i = tid; i < 4 * W; i += nt) {
-      const int row = i / W, w = i - row * W;
+    /* lambda_row = XOR over the information edges of core row `row`.  A core row has up to 19 edges: an item (row, word)
+     * is shared by LDPC_ENCP_LAMBDA_SLICES lanes, each taking every SLICES-th edge (table reads and windows of a lane are
+     * independent loads), and the partial sums are XOR-ed into LB, which phase 0 cleared -- 48 lanes walking 19 dependent
+     * steps each were the longest phase of the kernel (profiles/r03/tb_tx_phases.txt). */
+    for (int i = tid; i < 4 * W * LDPC_ENCP_LAMBDA_SLICES; i += nt) {
+      const int sl = i % LDPC_ENCP_LAMBDA_SLICES, rw = i / LDPC_ENCP_LAMBDA_SLICES, row = rw / W, w = rw - row * W;
       const int e0 = (int)L.RP[row], e1 = (int)L.RP[row + 1];
-      uint32_t acc = 0;
-      for (int e = e0; e < e1; e++) {
-        const uint32_t et = L.ET[e];
-        const int c = (int)(et >> 16);
-        if (c < Kb)
-          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (et & 0xffffu));
+      uint32_t et[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) { /* 19 edges / 4 slices */
+        const int e = e0 + sl + k * LDPC_ENCP_LAMBDA_SLICES;
+        et[k] = L.ET[e < e1 ? e : e1 - 1];
       }
-      L.LB[row * bs + w] = acc & ldpc_encp_mask(Z, w);
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int e = e0 + sl + k * LDPC_ENCP_LAMBDA_SLICES, c = (int)(et[k] >> 16);
+        const uint32_t v = ldpc_bits_at(L.X + (c < kbf ? c : 0) * cw, (uint32_t)(32 * w) + (et[k] & 0xffffu));
+        acc ^= (e < e1 && c < Kb) ? v : 0u;
+      }
+      for (int e = e0 + sl + 5 * LDPC_ENCP_LAMBDA_SLICES; e < e1; e += LDPC_ENCP_LAMBDA_SLICES) { /* (not for NR's base graphs) */
+        const uint32_t t = L.ET[e];
+        if ((int)(t >> 16) < Kb)
+          acc ^= ldpc_bits_at(L.X + (t >> 16) * cw, (uint32_t)(32 * w) + (t & 0xffffu));
+      }
+      acc &= ldpc_encp_mask(Z, w);
+      if (acc)
+        ldpc_encp_xor_into(&L.LB[row * bs + w], acc);
     }
   } else if (phase == 3) {
     ldpc_encp_extend(L.LB, L.LX, 4, Z, tid, nt);
@@ -176,14 +199,28 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
     for (int i = tid; i < nitems; i += nt) {
       const int rr = i / W, w = i - rr * W, row = 4 + rr;
       const int e0 = (int)L.RP[row], e1 = (int)L.RP[row + 1] - 1;
+      /* an extension row has at most 9 edges besides its own column: all table entries first, then all windows (two LDS
+       * round trips per item instead of two per edge) */
+      uint32_t et[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++)
+        et[k] = L.ET[e0 + k < e1 ? e0 + k : e1];
+      const uint32_t own = L.ET[e1];
       uint32_t acc = 0;
-      for (int e = e0; e < e1; e++) {
-        const uint32_t et = L.ET[e];
-        const int c = (int)(et >> 16);
-        if (c < Kb || c >= kbf)
-          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (et & 0xffffu));
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int c = (int)(et[k] >> 16);
+        const bool use = e0 + k < e1 && (c < Kb || c >= kbf);
+        const uint32_t v = ldpc_bits_at(L.X + (c < kbf + 4 ? c : 0) * cw, (uint32_t)(32 * w) + (et[k] & 0xffffu));
+        acc ^= use ? v : 0u;
       }
-      L.B[(L.ET[e1] >> 16) * bs + w] = acc & ldpc_encp_mask(Z, w);
+      for (int e = e0 + 9; e < e1; e++) { /* (not for NR's base graphs) */
+        const uint32_t t = L.ET[e];
+        const int c = (int)(t >> 16);
+        if (c < Kb || c >= kbf)
+          acc ^= ldpc_bits_at(L.X + c * cw, (uint32_t)(32 * w) + (t & 0xffffu));
+      }
+      L.B[(own >> 16) * bs + w] = acc & ldpc_encp_mask(Z, w);
     }
   } else {
     /* out[i] = bit i of the code word without its first two columns */
@@ -202,4 +239,88 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
     }
   }
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+/* Phases 4 .. 11 (the four core parity columns along the dual diagonal) walked by ONE wavefront without workgroup
+ * barriers: at most W <= 12 (solve) resp. cw <= 25 (periodic extension) lanes have work in any of the eight steps, a
+ * step is a few dependent LDS reads, and a wave's LDS accesses execute in order -- the fences only stop the compiler from
+ * moving them across a step.  All the solve parameters of the descriptor are requested up front (one scalar-load round
+ * trip; read where they are used they were a chain of a dozen).  Called by every lane of one wave; the caller's
+ * workgroup barrier follows.  Same results as ldpc_encp_phase(4 .. 11) (the CPU emulation runs those). */
+__device__ __forceinline__ void ldpc_encp_core_parity_wave(ldpc_code_ptr_t code, const ldpc_encp_lds &L, int lane)
+{
+  const int Z = code->Z, kbf = code->kb_full, W = ldpc_encp_W(Z), cw = ldpc_encp_cw(Z), bs = W + 1;
+  const uint32_t zmagic = 0xffffffffu / (uint32_t)Z + 1u;
+  int p0 = code->enc_p0_shift, row[3], unk[3], us[3], nk[3], kc[3][4], ks[3][4];
+#pragma unroll
+  for (int st = 0; st < 3; st++) {
+    row[st] = code->enc_row[st]; unk[st] = code->enc_unk[st]; us[st] = code->enc_ushift[st]; nk[st] = code->enc_nk[st];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      kc[st][k] = code->enc_kcol[st][k];
+      ks[st][k] = code->enc_kshift[st][k];
+    }
+  }
+  /* periodic string of the masked column `base` -> X, cw words: lane wp < cw builds word wp */
+  auto extend = [&](const uint32_t *base, uint32_t *X) {
+    if (lane < cw) {
+      const uint32_t o = 32u * (uint32_t)lane;
+      uint32_t p = o - __umulhi(o, zmagic) * (uint32_t)Z, v = 0; /* o mod Z */
+      int filled = 0;
+      while (filled < 32) {
+        int n = Z - (int)p;
+        n = n > 32 - filled ? 32 - filled : n;
+        uint32_t chunk = ldpc_bits_at(base, p);
+        if (n < 32)
+          chunk &= (1u << n) - 1u;
+        v |= chunk << filled;
+        filled += n;
+        p = 0;
+      }
+      X[lane] = v;
+    }
+  };
+  auto step_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  { /* first core parity column: sum of the four core rows, sum[t] = p0[(t + s0) mod Z] */
+    p0 = p0 >= Z ? p0 - (p0 / Z) * Z : p0;
+    const uint32_t back = p0 == 0 ? 0u : (uint32_t)(Z - p0);
+    if (lane < W) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        acc ^= ldpc_bits_at(L.LX + r * cw, 32u * (uint32_t)lane + back);
+      L.B[kbf * bs + lane] = acc & ldpc_encp_mask(Z, lane);
+    }
+    step_sync();
+    extend(L.B + kbf * bs, L.X + kbf * cw);
+    step_sync();
+  }
+#pragma unroll
+  for (int st = 0; st < 3; st++) {
+    int u = us[st];
+    u = u >= Z ? u - (u / Z) * Z : u;
+    const uint32_t back = u == 0 ? 0u : (uint32_t)(Z - u);
+    if (lane < W) {
+      uint32_t acc = ldpc_bits_at(L.LX + row[st] * cw, 32u * (uint32_t)lane + back);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t sh = back + (uint32_t)ks[st][k];
+        sh = sh >= (uint32_t)Z ? sh - (uint32_t)Z : sh;
+        sh = sh >= (uint32_t)Z ? sh - (sh / (uint32_t)Z) * (uint32_t)Z : sh; /* (shifts are stored reduced: never taken) */
+        const uint32_t v = ldpc_bits_at(L.X + (kbf + (k < nk[st] ? kc[st][k] : 0)) * cw, 32u * (uint32_t)lane + sh);
+        acc ^= k < nk[st] ? v : 0u;
+      }
+      L.B[(kbf + unk[st]) * bs + lane] = acc & ldpc_encp_mask(Z, lane);
+    }
+    step_sync();
+    extend(L.B + (kbf + unk[st]) * bs, L.X + (kbf + unk[st]) * cw);
+    step_sync();
+  }
+}
+#elif defined(__HIPCC__)
+/* (host pass of the kernels' translation units: never called) */
+__device__ inline void ldpc_encp_core_parity_wave(ldpc_code_ptr_t, const ldpc_encp_lds &, int) {}
+#endif
 #endif

@@ -43,7 +43,14 @@ __global__ void __launch_bounds__(512) ldpc_enc_packed_kernel(const ldpc_enc_arg
   const uint8_t *in = a.in + (job ? (size_t)job->in_off : (size_t)blk * a.in_stride);
   uint8_t *out = a.out + (job ? (size_t)job->out_off : (size_t)blk * a.out_stride);
   const int Kb = job ? job->Kb : a.Kb;
-  for (int ph = 0; ph < LDPC_ENCP_NUM_PHASES; ph++) {
+  for (int ph = 0; ph <= 3; ph++) {
+    ldpc_encp_phase(ph, code, Kb, in, L, out, threadIdx.x, blockDim.x);
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) /* phases 4 .. 11: one wave, no workgroup barriers in between */
+    ldpc_encp_core_parity_wave(code, L, (int)threadIdx.x);
+  __syncthreads();
+  for (int ph = 12; ph < LDPC_ENCP_NUM_PHASES; ph++) {
     ldpc_encp_phase(ph, code, Kb, in, L, out, threadIdx.x, blockDim.x);
     __syncthreads();
   }

@@ -267,6 +267,11 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, j.E, &rm) != 0)
           return set_error("nr_rate_matching: invalid parameters");
         j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+        j.tb = i;
+        if (r + 1 == sg.C) { /* the TB CRC bytes sit at the end of the last segment's share of b */
+          j.crc_len = (B - t.A) / 8;
+          j.crc_pos = t.A / 8 - r * ((sg.Kprime - sg.L) >> 3);
+        }
         r_offset += j.E;
         sj.push_back(j);
         ldpc_enc_job e;
@@ -315,11 +320,14 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(pl.jobs_d.p + o_seg);
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
   HIP_TRY(tb_launch_tx_crc(d_tb, ntb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
-                           payload, c.scratch.p, d_acc, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
+                           payload, c.scratch.p, d_acc, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], fused ? 0 : 1, s));
   const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(pl.jobs_d.p + o_enc);
   if (fused) {
-    HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, enc_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
-                               G().crc_pow[NR_HIP_CRC24_B], s));
+    /* workgroup size: 256 threads let every CU hold eight segments (a whole 1664-segment slot is resident at once);
+     * a launch that does not even fill the GPU four deep takes 512 and halves the rounds of its long stages */
+    const int fused_threads = n_seg <= (size_t)4 * (size_t)G().n_cus ? 512 : enc_threads;
+    HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, fused_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
+                               G().crc_pow[NR_HIP_CRC24_B], d_acc, s));
   } else {
     HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, G().crc_pow[NR_HIP_CRC24_B], s));
     ldpc_enc_args ea;

@@ -28,6 +28,10 @@ struct tb_tx_seg_job {     /* one per code block */
   uint64_t out_off;        /* coded output: TB offset + sum of the previous segments' E */
   uint32_t r, C, Kprime, L, K; /* segment index, segments, bits incl. CB CRC, CB CRC length, K */
   uint32_t E, Qm, Foffset, Fin, V, rank0;
+  uint32_t tb;             /* transport block (index of its CRC accumulator) */
+  /* fused kernel, segment that carries the TB CRC (the last one): crc_pos = byte of the segment where the CRC starts,
+   * crc_len = 3 (CRC24A) / 2 (CRC16); crc_len = 0: no TB CRC bytes in this segment */
+  uint32_t crc_pos, crc_len;
   uint32_t pad;
 };
 struct tb_rx_seg_job {
@@ -54,17 +58,19 @@ struct tb_rx_tb_job {
 
 /* TB CRC attach in two steps: per-chunk partial CRCs XOR-ed into acc[tb], then the CRC bytes.  acc[] must be zero on
  * entry and is zero again on exit (uploaded as zeros with the plan; no memset per call) */
+/* with_final = 0: only the partial CRCs (the fused TX kernel places the CRC bytes itself and clears acc) */
 hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_crc_chunk_job *chunks, uint32_t n_chunks,
                             const uint8_t *payload, uint8_t *scratch, uint32_t *acc, const uint32_t *pow24a,
-                            const uint32_t *pow16, hipStream_t s);
+                            const uint32_t *pow16, int with_final, hipStream_t s);
 hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s);
 hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const uint8_t *scratch, uint8_t *coded, hipStream_t s);
 /* segmentation + CB CRC + encoding + rate matching + interleaving in one kernel (bit-packed encoder); lds_bytes =
  * the encoder's LDS (ldpc_enc_launch_shape) + TB_TX_FUSED_EXTRA_LDS */
-#define TB_TX_FUSED_EXTRA_LDS (8 + 1056 + 16)
+#define TB_TX_SEL_SYMS 2048 /* modulation symbols per selection chunk: Qm sub-streams of that many bits are staged in LDS */
+#define TB_TX_FUSED_EXTRA_LDS (8 + 1056 + 16 + 8 * (TB_TX_SEL_SYMS / 32 + 1) * 4)
 struct ldpc_enc_job;
 hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
-                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s);
+                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, uint32_t *acc, hipStream_t s);
 /* lds_elems = the largest tb_rx_lds_elems() over the jobs (int16 slots of LDS a workgroup needs) */
 __host__ __device__ static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t Fin, uint32_t Ncb)
 {

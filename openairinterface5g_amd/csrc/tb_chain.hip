@@ -191,8 +191,9 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_ratematch_kernel(const tb_tx
 /* ---- TX 2+3 fused: segmentation + CB CRC + bit-packed LDPC encoding + rate matching + interleaving --------------
  * One workgroup per code block; the segment bytes, the code word (ldpc_enc_packed_core.h) and the selection all stay
  * in LDS: HBM traffic = the segment's payload bytes in, E output bytes out (no c / d round trip through scratch). */
+typedef uint32_t tb_u32x4_t __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, const uint8_t *scratch,
-                                                          uint8_t *coded, const uint32_t *pow24b)
+                                                          uint8_t *coded, const uint32_t *pow24b, uint32_t *acc)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   typedef const tb_tx_seg_job LDPC_CONST_AS *seg_ptr_t;
@@ -205,42 +206,200 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
   ldpc_encp_carve(reinterpret_cast<uint32_t *>(fsm), code, L);
   uint32_t *red = L.RP + code->nrows + 1;
   uint8_t *c = reinterpret_cast<uint8_t *>(red + 2);
+#ifdef TB_TIMING /* diagnostic build (tools/tb_tx_timing.py): workgroup 0 logs the clock after every phase into the first
+                    bytes BEHIND the last segment's output (the tool's buffer is that much longer) */
+  long long *tlog = reinterpret_cast<long long *>(coded + ((jobs[gridDim.x - 1].out_off + jobs[gridDim.x - 1].E + 15) & ~15ull));
+  int tlog_n = 0;
+#define TB_TLOG() do { if (blockIdx.x == 0 && threadIdx.x == 0) tlog[tlog_n++] = clock64(); } while (0)
+#else
+#define TB_TLOG() do { } while (0)
+#endif
+  TB_TLOG();
 
-  /* c_r = b[r*(K'-L) ..] || CRC24B (C > 1) || zero fillers (nr_segmentation.c:147-175) */
+  /* c_r = b[r*(K'-L) ..] || CRC24B (C > 1) || zero fillers (nr_segmentation.c:147-175).  Everything the later phases
+   * read from global memory is requested here, in one go: the segment's bytes, the encoder's edge table (the first part
+   * of its phase 0), the eight table seeds and this thread's power of x for the CRC. */
   const uint32_t Kprime = j->Kprime, Lcrc = j->L, segbytes = (Kprime - Lcrc) >> 3, kbytes = (j->K + 7) >> 3;
   const uint8_t *src = scratch + j->b_off + (size_t)j->r * segbytes;
-  for (uint32_t q = tid; q < segbytes; q += nt)
-    c[q] = src[q];
+  uint32_t *tab = reinterpret_cast<uint32_t *>(c + 1056 + 16); /* CRC byte table: the selection area is free until the end */
+  const bool with_crc = j->C > 1;
+  /* CRC piece of this thread: bytes [8 tid, 8 tid + 8) of the segment; n_after = bits behind the piece */
+  const uint32_t q0 = 8u * (uint32_t)tid, qn = q0 < segbytes ? (segbytes - q0 < 8u ? segbytes - q0 : 8u) : 0u;
+  const uint32_t n_after = 8u * (segbytes - q0 - qn);
+  uint32_t xq = 0;
+  if (with_crc) {
+    tb_build_crc_tab(pow24b, tab);
+    if (qn && n_after >= 24u)
+      xq = pow24b[n_after - 24u]; /* x^n_after mod g, left aligned (pow[j] = x^(j + 24) mod g) */
+  }
+  /* the segment that ends the transport block takes the TB CRC from the accumulator the partial-CRC kernel left (and
+   * clears it for the next call): no kernel of its own for three bytes per transport block */
+  const uint32_t crc_len = j->crc_len, crc_pos = j->crc_pos;
+  const uint32_t tb_crc = crc_len ? acc[j->tb] : 0u;
+  for (uint32_t q = tid; q < segbytes; q += nt) {
+    const uint32_t k = q - crc_pos; /* (wraps for q < crc_pos) */
+    c[q] = k < crc_len ? (uint8_t)(tb_crc >> (24 - 8 * k)) : src[q];
+  }
   for (uint32_t q = (Kprime >> 3) + tid; q < kbytes + 8; q += nt)
     c[q] = 0;
-  if (j->C > 1) {
-    const uint32_t crc = tb_block_crc(src, Kprime - Lcrc, pow24b, red);
-    if (tid == 0) {
-      c[segbytes] = (uint8_t)(crc >> 24);
-      c[segbytes + 1] = (uint8_t)(crc >> 16);
-      c[segbytes + 2] = (uint8_t)(crc >> 8);
+  if (tid == 0)
+    red[0] = 0;
+  {
+    const int W = ldpc_encp_W(Z), bs = W + 1;
+    for (int col = tid; col < code->ncols; col += nt)
+      L.B[col * bs + W] = 0u;
+    for (int i = tid; i < 4 * bs; i += nt)
+      L.LB[i] = 0u;
+    for (int e = tid; e < code->nedges; e += nt)
+      L.ET[e] = ((uint32_t)code->e_col[e] << 16) | (code->e_info[e] & 0xffffu);
+    for (int r = tid; r <= code->nrows; r += nt)
+      L.RP[r] = (uint32_t)code->row_ptr[r];
+  }
+  __syncthreads();
+  if (crc_len && tid == 0)
+    acc[j->tb] = 0; /* (every thread has its copy by now) */
+  TB_TLOG();
+  if (with_crc) {
+    /* CB CRC24B over the segment's bytes in LDS: a thread runs the byte-table recurrence of crc_byte.c:184-218 over its
+     * 8 bytes, then moves its 24-bit register R to the end of the string: R(x) * x^n_after mod g, one Horner step per
+     * coefficient of R with x^n_after mod g from the power table (one load per thread, requested above).  The first
+     * version looked up one power per set BIT in global memory, one dependent load after the other: 40 % of the kernel. */
+    uint32_t reg = 0;
+    for (uint32_t i = 0; i < qn; i++)
+      reg = (reg << 8) ^ tab[(reg >> 24) ^ c[q0 + i]];
+    uint32_t x = reg;
+    if (qn && n_after) {
+      if (n_after >= 24u) {
+        x = 0;
+#pragma unroll
+        for (int k = 31; k >= 8; k--) {
+          x = (x << 1) ^ ((uint32_t)((int32_t)x >> 31) & 0x80006300u); /* x * X mod g (crc_byte.c:50: poly24b) */
+          x ^= (0u - ((reg >> k) & 1u)) & xq;
+        }
+      } else { /* 8 or 16 bits behind the piece: as many zero bytes through the table */
+        for (uint32_t b = 0; b < n_after; b += 8)
+          x = (x << 8) ^ tab[x >> 24];
+      }
+    }
+    for (int off = 32; off; off >>= 1)
+      x ^= __shfl_xor(x, off);
+    if ((tid & 63) == 0 && x)
+      atomicXor(&red[0], x);
+    __syncthreads();
+    if (tid < 3)
+      c[segbytes + tid] = (uint8_t)(red[0] >> (24 - 8 * tid));
+    __syncthreads();
+  }
+  TB_TLOG();
+  {
+    /* the rest of the encoder's phase 0: information columns from the MSB-first bytes */
+    const int kbf = code->kb_full, W = ldpc_encp_W(Z), bs = W + 1, nin = (kbf * Z + 7) >> 3;
+    for (int i = tid; i < kbf * W; i += nt) {
+      const int col = i / W, w = i - col * W;
+      const uint32_t b0 = (uint32_t)(col * Z + 32 * w), j0 = b0 >> 3;
+      uint64_t v = 0;
+      for (int q = 0; q < 5; q++)
+        v = (v << 8) | ((int)j0 + q < nin ? c[j0 + q] : 0u);
+      const uint32_t m = (uint32_t)(v >> (8 - (b0 & 7u)));
+      L.B[col * bs + w] = __builtin_bitreverse32(m) & ldpc_encp_mask(Z, w);
     }
   }
   __syncthreads();
-  for (int ph = 0; ph < LDPC_ENCP_SOLVE_PHASES; ph++) {
+  TB_TLOG();
+  for (int ph = 1; ph <= 3; ph++) {
     ldpc_encp_phase(ph, code, ej->Kb, c, L, nullptr, tid, nt);
     __syncthreads();
+    TB_TLOG();
   }
-  /* f[i + jj*Qm] = e[i*E/Qm + jj], e[k] = d[position of rank (rank0 + k) mod V], d[p] = code word bit p + 2Z */
+  /* phases 4 .. 11 -- the four core parity columns, one after the other, W <= 12 items each: ONE wave walks them without
+   * workgroup barriers (ldpc_encp_core_parity_wave), the others wait at the barrier below.  Eight barrier-separated phases of 12 active lanes were 10 k of the kernel's 62 k clocks. */
+  if (tid < 64)
+    ldpc_encp_core_parity_wave(code, L, tid);
+  __syncthreads();
+  TB_TLOG();
+  ldpc_encp_phase(12, code, ej->Kb, c, L, nullptr, tid, nt);
+  __syncthreads();
+  TB_TLOG();
+  /* Bit selection + interleaving (nr_rate_matching.c:424-501, :240-303): f[i + jj*Qm] = e[i*E/Qm + jj],
+   * e[k] = d[position of rank (rank0 + k) mod V], d[p] = code word bit p + 2Z.  In two steps per chunk of TB_TX_SEL_SYMS
+   * modulation symbols: (1) the Qm sub-streams e[i*E/Qm + jj0 ..] are packed into LDS, 32 bits per item, gathered from
+   * the code word in runs (a run ends at the circular buffer's wrap, at the filler gap, at the end of a lifted column);
+   * (2) one thread per ALIGNED 16 bytes of the output: every byte is one bit look-up in the sub-streams, the store is one
+   * dwordx4.  (The first version stored one byte per thread and bit, strided by Qm: 1664 segments x 9450 one-byte
+   * stores were most of the kernel's 50 us.) */
   uint8_t *__restrict__ f = coded + j->out_off;
   const uint32_t E = j->E, Qm = j->Qm, EQ = E / Qm, V = j->V, rank0 = j->rank0, Foffset = j->Foffset, Fin = j->Fin;
   const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u, bs = (uint32_t)ldpc_encp_W(Z) + 1u, twoZ = 2u * (uint32_t)Z;
-  for (uint32_t jj = tid; jj < EQ; jj += nt) {
-    uint32_t rank = (rank0 + jj) % V;
-    const uint32_t step = EQ % V;
-    for (uint32_t i = 0; i < Qm; i++) {
-      const uint32_t p = (rank < Foffset ? rank : rank + Fin) + twoZ;
-      const uint32_t col = __umulhi(p, z_magic), t = p - col * (uint32_t)Z;
-      f[jj * Qm + i] = (uint8_t)((L.B[col * bs + (t >> 5)] >> (t & 31u)) & 1u);
-      rank += step;
-      if (rank >= V)
-        rank -= V;
+  uint32_t *sel = reinterpret_cast<uint32_t *>(c + 1056 + 16); /* [Qm][TB_TX_SEL_SYMS / 32 + 1], behind the segment bytes */
+  const uint32_t sel_stride = TB_TX_SEL_SYMS / 32 + 1;
+  for (uint32_t jj0 = 0; jj0 < EQ; jj0 += TB_TX_SEL_SYMS) {
+    const uint32_t nsym = EQ - jj0 < TB_TX_SEL_SYMS ? EQ - jj0 : TB_TX_SEL_SYMS, nw = (nsym + 31) >> 5;
+    for (uint32_t it = tid; it < Qm * nw; it += nt) {
+      const uint32_t i = it / nw, w = it - i * nw;
+      const uint32_t k = i * EQ + jj0 + 32u * w;
+      uint32_t nbits = nsym - 32u * w;
+      nbits = nbits > 32u ? 32u : nbits;
+      uint32_t r = (rank0 + k) % V, v = 0, filled = 0;
+      while (filled < nbits) {
+        const uint32_t p = (r < Foffset ? r : r + Fin) + twoZ;
+        const uint32_t col = __umulhi(p, z_magic), t = p - col * (uint32_t)Z;
+        uint32_t n = nbits - filled;
+        n = n < V - r ? n : V - r;
+        if (r < Foffset)
+          n = n < Foffset - r ? n : Foffset - r;
+        n = n < (uint32_t)Z - t ? n : (uint32_t)Z - t;
+        uint32_t chunk = ldpc_bits_at(L.B + col * bs, t);
+        if (n < 32u)
+          chunk &= (1u << n) - 1u;
+        v |= chunk << filled;
+        filled += n;
+        r += n;
+        r = r >= V ? r - V : r;
+      }
+      sel[i * sel_stride + w] = v;
     }
+    __syncthreads();
+    TB_TLOG();
+    /* output bytes [m0, m1) of this chunk, in 16-byte blocks aligned in memory */
+    const uint32_t m0 = jj0 * Qm, m1 = (jj0 + nsym) * Qm;
+    const uintptr_t fa = reinterpret_cast<uintptr_t>(f + m0);
+    const uint32_t lead = (uint32_t)(fa & 15u), nblk = (lead + (m1 - m0) + 15u) >> 4;
+    const uint32_t qm_magic = 0xffffffffu / Qm + 1u; /* m / Qm for m < 2^24 and Qm in {1, 2, 4, 6, 8} (checked on the host: E < 2^24) */
+    for (uint32_t b = tid; b < nblk; b += nt) {
+      const int32_t first = (int32_t)(16u * b) - (int32_t)lead; /* offset of the block's first byte from m0 (may be < 0) */
+      const bool whole = first >= 0 && (uint32_t)first + 16u <= m1 - m0;
+      /* byte m of the chunk = bit (m % Qm) of symbol m / Qm; the 16 look-ups are unconditional (a byte outside the
+       * segment reads a clamped position and is not stored) */
+      const uint32_t mfirst = first >= 0 ? (uint32_t)first : 0u;
+      uint32_t sy = __umulhi(mfirst, qm_magic), i = mfirst - sy * Qm;
+      uint32_t wv[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const uint32_t bit = (sel[i * sel_stride + (sy >> 5)] >> (sy & 31u)) & 1u;
+        wv[q >> 2] |= bit << (8 * (q & 3));
+        if (first + q >= 0) { /* (always, in a whole block) */
+          i++;
+          if (i == Qm) {
+            i = 0;
+            sy++;
+          }
+        }
+        sy = sy < nsym ? sy : nsym - 1u;
+      }
+      uint8_t *dst = f + m0 + first;
+      if (whole) {
+        *reinterpret_cast<tb_u32x4_t *>(dst) = (tb_u32x4_t){wv[0], wv[1], wv[2], wv[3]};
+      } else { /* the segment's first / last block: only its own bytes (the neighbours' are written by their workgroups) */
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int32_t mo = first + q;
+          if (mo >= 0 && (uint32_t)mo < m1 - m0)
+            dst[q] = (uint8_t)(wv[q >> 2] >> (8 * (q & 3)));
+        }
+      }
+    }
+    __syncthreads();
+    TB_TLOG();
   }
 }
 
@@ -484,12 +643,13 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_t
 
 hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_crc_chunk_job *chunks, uint32_t n_chunks,
                             const uint8_t *payload, uint8_t *scratch, uint32_t *acc, const uint32_t *pow24a,
-                            const uint32_t *pow16, hipStream_t s)
+                            const uint32_t *pow16, int with_final, hipStream_t s)
 {
   if (n_tb == 0)
     return hipSuccess;
   hipLaunchKernelGGL(tb_tx_crc_partial_kernel, dim3(n_chunks), dim3(TB_THREADS), 0, s, jobs, chunks, payload, scratch, acc, pow24a, pow16);
-  hipLaunchKernelGGL(tb_tx_crc_final_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, scratch, acc);
+  if (with_final)
+    hipLaunchKernelGGL(tb_tx_crc_final_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, scratch, acc);
   return hipGetLastError();
 }
 hipError_t tb_launch_tx_segment(const tb_tx_seg_job *jobs, uint32_t n, uint8_t *scratch, const uint32_t *pow24b, hipStream_t s)
@@ -501,11 +661,11 @@ hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const u
   TB_LAUNCH(tb_tx_ratematch_kernel, n, s, jobs, scratch, coded);
 }
 hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
-                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, hipStream_t s)
+                              const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, uint32_t *acc, hipStream_t s)
 {
   if (n == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(tb_tx_fused_kernel, dim3(n), dim3(n_threads), lds_bytes, s, jobs, ejobs, scratch, coded, pow24b);
+  hipLaunchKernelGGL(tb_tx_fused_kernel, dim3(n), dim3(n_threads), lds_bytes, s, jobs, ejobs, scratch, coded, pow24b, acc);
   return hipGetLastError();
 }
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
