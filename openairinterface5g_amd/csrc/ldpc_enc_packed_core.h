@@ -128,7 +128,7 @@ LDPC_HD void ldpc_encp_phase(int phase, ldpc_code_ptr_t code, int Kb, const uint
     for (int i = tid; i < 4 * bs; i += nt)
       L.LB[i] = 0u; /* phase 2 accumulates into it */
     for (int e = tid; e < code->nedges; e += nt)
-      L.ET[e] = ((uint32_t)code->e_col[e] << 16) | (code->e_info[e] & 0xffffu);
+      L.ET[e] = code->enc_et[e];
     for (int r = tid; r <= code->nrows; r += nt)
       L.RP[r] = (uint32_t)code->row_ptr[r];
   } else if (phase == 1) {

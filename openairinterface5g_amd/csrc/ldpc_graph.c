@@ -290,6 +290,7 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
     for (int k = 0; k < deg[r]; k++, e++) {
       d->e_col[e] = col[e];
       d->e_info[e] = ((uint32_t)(col[e] * Z) << 16) | (uint32_t)(sh[e] % Z);
+      d->enc_et[e] = ((uint32_t)col[e] << 16) | (uint32_t)(sh[e] % Z);
     }
   }
   d->row_ptr[d->nrows] = e;

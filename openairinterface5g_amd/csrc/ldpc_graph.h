@@ -56,6 +56,7 @@ typedef struct ldpc_code_desc {
   /* per edge (row-major): lo16 = shift mod Z, hi16 = col*Z (byte offset of the column in a [col][Z] array) */
   uint32_t e_info[LDPC_MAX_EDGES + 4];
   int32_t e_col[LDPC_MAX_EDGES + 4];
+  uint32_t enc_et[LDPC_MAX_EDGES + 4]; /* per edge: column << 16 | shift mod Z (the bit-packed encoder's edge table, one load per edge) */
   /* core columns (c < ncore): edges touching the column, as (edge << 16) | shift */
   int32_t col_ptr[LDPC_MAX_CORE + 2];
   uint32_t col_edge[LDPC_MAX_EDGES + 4];

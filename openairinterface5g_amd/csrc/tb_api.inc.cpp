@@ -222,6 +222,10 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     Arena ar;
     int enc_threads = 64, enc_lds = 0;
     TbExtent ex;
+    size_t total_payload = 0;
+    for (uint32_t i = 0; i < ntb; i++)
+      total_payload += tbs[i].A / 8;
+    const uint32_t crc_chunk = total_payload <= 256u * 1024u ? TB_CRC_CHUNK_SMALL : TB_CRC_CHUNK; /* tb_chain.h */
     for (uint32_t i = 0; i < ntb; i++) {
       const nrLDPC_hip_tb_t &t = tbs[i];
       if (tb_validate(t) != 0)
@@ -242,8 +246,8 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       ex.add(ex.pay_lo, ex.pay_hi, (size_t)t.payload_off, (size_t)t.payload_off + t.A / 8);
       ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
       ex.cod_sum += t.G;
-      for (uint32_t fb = 0; fb < t.A / 8; fb += TB_CRC_CHUNK)
-        cj.push_back(tb_crc_chunk_job{i, fb});
+      for (uint32_t fb = 0; fb < t.A / 8; fb += crc_chunk)
+        cj.push_back(tb_crc_chunk_job{i, fb | (crc_chunk == TB_CRC_CHUNK_SMALL ? 0x80000000u : 0u)});
       const ldpc_code_desc_t &hc = ce->host;
       const int N = (hc.ncols - 2) * hc.Z;
       int nthr, nlds;
@@ -301,7 +305,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
     pl.remember(tbs, ntb, fused ? 1u : 0u);
   }
-  if (c.scratch.ensure(pl.scratch_top) != 0)
+  if (c.scratch.ensure(pl.scratch_top + 16) != 0) /* (+16: the fused kernel reads whole dwords around a segment's bytes) */
     return -1;
   const size_t n_seg = pl.n_seg;
   const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_enc = pl.off[2], o_chk = pl.off[3], o_acc = pl.off[4];

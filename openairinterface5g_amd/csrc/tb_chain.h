@@ -16,10 +16,15 @@ struct tb_tx_tb_job {      /* one per transport block */
   uint32_t A, B, crc_type; /* CRC24_A (0) or CRC16 (2) */
   uint32_t pad;
 };
-struct tb_crc_chunk_job {  /* one per TB_CRC_CHUNK bytes of a transport block: the TB CRC is computed by many workgroups */
+struct tb_crc_chunk_job {  /* one per chunk of a transport block: the TB CRC is computed by many workgroups */
   uint32_t tb;             /* index into the per-TB job array */
-  uint32_t first_byte;     /* byte range [first_byte, first_byte + TB_CRC_CHUNK) of the TB */
+  uint32_t first_byte;     /* byte range [first_byte, first_byte + chunk) of the TB; chunk = TB_CRC_CHUNK_SMALL when bit 31 is set */
 };
+/* bytes of a transport block per workgroup of the TB CRC kernel: 8 or 32 per thread.  The byte-table recurrence over a
+ * thread's bytes is a chain of dependent look-ups (short pieces = short latency: one transport block 30.6 -> 26.9 us),
+ * but every piece costs ~200 instructions and a power-table load to move to the end of the string (long pieces = less
+ * work: a 64-block slot's CRC kernels take twice as long with the short ones) -- the plan picks by the call's size. */
+#define TB_CRC_CHUNK_SMALL 2048u
 #define TB_CRC_CHUNK 8192u
 struct tb_tx_seg_job {     /* one per code block */
   uint64_t b_off;          /* the TB's b */

@@ -74,7 +74,20 @@ __device__ __forceinline__ void tb_build_crc_tab(const uint32_t *__restrict__ po
  * (reg = (reg << 8) ^ tab[(reg >> 24) ^ byte], LDS look-ups), then moves the piece's register R to the end of the
  * string: R(x) * x^n_after mod g = XOR over the set bits b of R of pow[b - 32 + n_after] (or the bit itself, shifted,
  * while it still fits under the generator's degree).  Valid in lane 0 of every wave. */
-template <int SPAN>
+/* R(x) * Q(x) mod g for left-aligned registers of a degree-DEG generator (poly = x^DEG mod g, left aligned): one Horner
+ * step per coefficient of R -- the power Q = x^n mod g is ONE table look-up, where summing pow[] over the set bits of R
+ * was a dozen dependent global loads per thread (the TB CRC kernels spent most of their 13-17 us there). */
+template <int DEG> __device__ __forceinline__ uint32_t tb_crc_mulmod(uint32_t R, uint32_t Q, uint32_t poly)
+{
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 31; k >= 32 - DEG; k--) {
+    x = (x << 1) ^ ((uint32_t)((int32_t)x >> 31) & poly);
+    x ^= (0u - ((R >> k) & 1u)) & Q;
+  }
+  return x;
+}
+template <int SPAN, int DEG>
 __device__ __forceinline__ uint32_t tb_partial_crc(const uint8_t *__restrict__ data, uint32_t nbits, uint32_t first, uint32_t count,
                                                    const uint32_t *__restrict__ pow, const uint32_t *tab)
 {
@@ -96,13 +109,11 @@ __device__ __forceinline__ uint32_t tb_partial_crc(const uint8_t *__restrict__ d
       for (uint32_t i = 0; i < n; i++)
         reg = (reg << 8) ^ tab[(reg >> 24) ^ data[q0 + i]];
     }
-    const int n_after = (int)(nbits - 8 * (q0 + n));
-    while (reg) {
-      const int b = 31 - __clz(reg);
-      const int jx = b - 32 + n_after;
-      x ^= jx >= 0 ? pow[jx] : (1u << (32 + jx));
-      reg &= ~(1u << b);
-    }
+    const uint32_t n_after = nbits - 8 * (q0 + n);
+    if (n_after == 0)
+      x ^= reg;
+    else /* x^n_after mod g, left aligned: pow[j] = x^(j + DEG) mod g */
+      x ^= tb_crc_mulmod<DEG>(reg, n_after >= (uint32_t)DEG ? pow[n_after - DEG] : 1u << (32 - DEG + n_after), pow[0]);
   }
   for (int off = 32; off; off >>= 1)
     x ^= __shfl_xor(x, off);
@@ -115,18 +126,36 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_
                                                                        const uint32_t *pow24a, const uint32_t *pow16)
 {
   __shared__ uint32_t tab[256];
-  const tb_crc_chunk_job ch = chunks[blockIdx.x];
+  tb_crc_chunk_job ch = chunks[blockIdx.x];
+  const bool small = (ch.first_byte >> 31) != 0;
+  ch.first_byte &= 0x7fffffffu;
+  const uint32_t chunk = small ? TB_CRC_CHUNK_SMALL : TB_CRC_CHUNK;
   const tb_tx_tb_job j = jobs[ch.tb];
   const uint32_t *pow = j.crc_type == 0 ? pow24a : pow16;
   tb_build_crc_tab(pow, tab);
   const uint8_t *a = payload + j.payload_off;
   uint8_t *b = scratch + j.b_off;
   const uint32_t nbytes = j.A >> 3;
-  const uint32_t count = ch.first_byte + TB_CRC_CHUNK <= nbytes ? TB_CRC_CHUNK : nbytes - ch.first_byte;
-  for (uint32_t q = ch.first_byte + threadIdx.x; q < ch.first_byte + count; q += blockDim.x)
-    b[q] = a[q];
+  const uint32_t count = ch.first_byte + chunk <= nbytes ? chunk : nbytes - ch.first_byte;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u) == 0) { /* (chunks start at multiples of 16) */
+    const uint4 *a16 = reinterpret_cast<const uint4 *>(a + ch.first_byte);
+    uint4 *b16 = reinterpret_cast<uint4 *>(b + ch.first_byte);
+    for (uint32_t q = threadIdx.x; q < (count >> 4); q += blockDim.x)
+      b16[q] = a16[q];
+    for (uint32_t q = ch.first_byte + (count & ~15u) + threadIdx.x; q < ch.first_byte + count; q += blockDim.x)
+      b[q] = a[q];
+  } else {
+    for (uint32_t q = ch.first_byte + threadIdx.x; q < ch.first_byte + count; q += blockDim.x)
+      b[q] = a[q];
+  }
   __syncthreads();
-  const uint32_t x = tb_partial_crc<32>(a, j.A, ch.first_byte, count, pow, tab);
+  uint32_t x;
+  if (small)
+    x = j.crc_type == 0 ? tb_partial_crc<8, 24>(a, j.A, ch.first_byte, count, pow, tab)
+                        : tb_partial_crc<8, 16>(a, j.A, ch.first_byte, count, pow, tab);
+  else
+    x = j.crc_type == 0 ? tb_partial_crc<32, 24>(a, j.A, ch.first_byte, count, pow, tab)
+                        : tb_partial_crc<32, 16>(a, j.A, ch.first_byte, count, pow, tab);
   if ((threadIdx.x & 63) == 0 && x)
     atomicXor(&acc[ch.tb], x);
 }
@@ -191,8 +220,62 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_ratematch_kernel(const tb_tx
 /* ---- TX 2+3 fused: segmentation + CB CRC + bit-packed LDPC encoding + rate matching + interleaving --------------
  * One workgroup per code block; the segment bytes, the code word (ldpc_enc_packed_core.h) and the selection all stay
  * in LDS: HBM traffic = the segment's payload bytes in, E output bytes out (no c / d round trip through scratch). */
+/* Interleaver output of one chunk of modulation symbols from its QM packed sub-streams (tb_tx_fused_kernel):
+ * f[sy * QM + i] = bit sy of sub-stream i.  A thread takes 8 symbols: one byte of every sub-stream in, 8 QM bytes out, every
+ * shift a compile-time constant (2 VALU per output byte; the first version did a division and a look-up per byte).
+ * `dst` = where the chunk's first symbol goes; its alignment decides the store width. */
+template <int QM>
+__device__ __forceinline__ void tb_tx_store_syms(const uint32_t *sel, uint32_t sel_stride, uint32_t nsym, uint8_t *__restrict__ dst, int tid,
+                                                 int nt)
+{
+  const uint32_t ngrp = nsym >> 3, al = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+  for (uint32_t g = tid; g < ngrp; g += nt) {
+    uint32_t win[QM];
+#pragma unroll
+    for (int i = 0; i < QM; i++)
+      win[i] = sel[i * sel_stride + (g >> 2)] >> (8u * (g & 3u));
+    /* output dword w of the group (compile-time shifts); formed right where it is stored, so that at most one is live
+     * (all 2 QM of them next to the eight windows pushed the kernel to 99 VGPRs = four waves per SIMD, and a 1664-segment
+     * slot then runs in two rounds of workgroups) */
+    auto word = [&](int w) -> uint32_t {
+      uint32_t v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int m = 4 * w + b, sy = m / QM, i = m - sy * QM;
+        v |= ((win[i] >> sy) & 1u) << (8 * b);
+      }
+      return v;
+    };
+    uint8_t *o = dst + (size_t)g * (8 * QM);
+    if (al == 0) {
+#pragma unroll
+      for (int w = 0; w < 2 * QM; w++)
+        reinterpret_cast<uint32_t *>(o)[w] = word(w);
+    } else if (al == 2) {
+#pragma unroll
+      for (int w = 0; w < 2 * QM; w++) {
+        const uint32_t v = word(w);
+        reinterpret_cast<uint16_t *>(o)[2 * w] = (uint16_t)v;
+        reinterpret_cast<uint16_t *>(o)[2 * w + 1] = (uint16_t)(v >> 16);
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < 2 * QM; w++) {
+        const uint32_t v = word(w);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          o[4 * w + b] = (uint8_t)(v >> (8 * b));
+      }
+    }
+  }
+  for (uint32_t m = ngrp * 8u * QM + tid; m < nsym * QM; m += nt) { /* the last, partial group */
+    const uint32_t sy = m / QM, i = m - sy * QM;
+    dst[m] = (uint8_t)((sel[i * sel_stride + (sy >> 5)] >> (sy & 31u)) & 1u);
+  }
+}
+
 typedef uint32_t tb_u32x4_t __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, const uint8_t *scratch,
+__global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, const uint8_t *scratch,
                                                           uint8_t *coded, const uint32_t *pow24b, uint32_t *acc)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -211,6 +294,11 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
   long long *tlog = reinterpret_cast<long long *>(coded + ((jobs[gridDim.x - 1].out_off + jobs[gridDim.x - 1].E + 15) & ~15ull));
   int tlog_n = 0;
 #define TB_TLOG() do { if (blockIdx.x == 0 && threadIdx.x == 0) tlog[tlog_n++] = clock64(); } while (0)
+  /* + first / last clock (and the wall clock, 100 MHz) of every 128th workgroup behind the phase log: dispatch skew */
+  if ((blockIdx.x & 127u) == 0 && threadIdx.x == 0) {
+    tlog[32 + 4 * (blockIdx.x >> 7)] = clock64();
+    tlog[32 + 4 * (blockIdx.x >> 7) + 2] = wall_clock64();
+  }
 #else
 #define TB_TLOG() do { } while (0)
 #endif
@@ -223,8 +311,11 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
   const uint8_t *src = scratch + j->b_off + (size_t)j->r * segbytes;
   uint32_t *tab = reinterpret_cast<uint32_t *>(c + 1056 + 16); /* CRC byte table: the selection area is free until the end */
   const bool with_crc = j->C > 1;
-  /* CRC piece of this thread: bytes [8 tid, 8 tid + 8) of the segment; n_after = bits behind the piece */
-  const uint32_t q0 = 8u * (uint32_t)tid, qn = q0 < segbytes ? (segbytes - q0 < 8u ? segbytes - q0 : 8u) : 0u;
+  /* CRC piece of this thread: bytes [P tid, P tid + P) of the segment, P = the fewest bytes that fit the pieces into ONE wave (the
+   * recurrence over a piece is a chain of dependent table look-ups, but moving a piece's register to the end of the string
+   * costs ~200 VALU instructions per wave that has a piece: the kernel is issue bound when a slot's segments fill the GPU); n_after = bits behind the piece */
+  const uint32_t P = (segbytes + 63u) / 64u < 4u ? 4u : (segbytes + 63u) / 64u;
+  const uint32_t q0 = P * (uint32_t)tid, qn = q0 < segbytes ? (segbytes - q0 < P ? segbytes - q0 : P) : 0u;
   const uint32_t n_after = 8u * (segbytes - q0 - qn);
   uint32_t xq = 0;
   if (with_crc) {
@@ -236,11 +327,61 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
    * clears it for the next call): no kernel of its own for three bytes per transport block */
   const uint32_t crc_len = j->crc_len, crc_pos = j->crc_pos;
   const uint32_t tb_crc = crc_len ? acc[j->tb] : 0u;
-  for (uint32_t q = tid; q < segbytes; q += nt) {
-    const uint32_t k = q - crc_pos; /* (wraps for q < crc_pos) */
-    c[q] = k < crc_len ? (uint8_t)(tb_crc >> (24 - 8 * k)) : src[q];
+  /* every global load of the stage goes out before anything is consumed (written as separate loops the compiler waited
+   * for each one in turn: four round trips for the segment's bytes alone): the segment as aligned dwords -- two per LDS
+   * dword, the source is only byte aligned --, the edge table, the row pointers */
+  const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u), ndw = (segbytes + 3u) >> 2;
+  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src - a0);
+  uint32_t g_lo[5], g_hi[5], g_et[5], g_rp = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t w = (uint32_t)tid + (uint32_t)k * (uint32_t)nt;
+    g_lo[k] = g_hi[k] = g_et[k] = 0;
+    if (w < ndw) {
+      g_lo[k] = src32[w];
+      g_hi[k] = src32[w + 1];
+    }
+    if (w < (uint32_t)code->nedges)
+      g_et[k] = code->enc_et[w];
   }
-  for (uint32_t q = (Kprime >> 3) + tid; q < kbytes + 8; q += nt)
+  if (tid <= code->nrows)
+    g_rp = (uint32_t)code->row_ptr[tid];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t w = (uint32_t)tid + (uint32_t)k * (uint32_t)nt;
+    if (w < ndw) {
+      uint32_t v = __builtin_amdgcn_alignbyte(g_hi[k], g_lo[k], a0);
+#pragma unroll
+      for (int b = 0; b < 4; b++) { /* TB CRC bytes (last segment only); nothing behind the segment's last byte */
+        const uint32_t q = 4u * w + (uint32_t)b, kk = q - crc_pos;
+        if (kk < crc_len)
+          v = (v & ~(0xffu << (8 * b))) | (((tb_crc >> (24 - 8 * kk)) & 0xffu) << (8 * b));
+        if (q >= segbytes)
+          v &= ~(0xffu << (8 * b));
+      }
+      reinterpret_cast<uint32_t *>(c)[w] = v;
+    }
+    if (w < (uint32_t)code->nedges)
+      L.ET[w] = g_et[k];
+  }
+  for (uint32_t w = (uint32_t)tid + 5u * (uint32_t)nt; w < ndw; w += nt) { /* (workgroups of fewer than 64 threads: never) */
+    uint32_t v = __builtin_amdgcn_alignbyte(src32[w + 1], src32[w], a0);
+    for (int b = 0; b < 4; b++) {
+      const uint32_t q = 4u * w + (uint32_t)b, kk = q - crc_pos;
+      if (kk < crc_len)
+        v = (v & ~(0xffu << (8 * b))) | (((tb_crc >> (24 - 8 * kk)) & 0xffu) << (8 * b));
+      if (q >= segbytes)
+        v &= ~(0xffu << (8 * b));
+    }
+    reinterpret_cast<uint32_t *>(c)[w] = v;
+  }
+  for (int e = tid + 5 * nt; e < code->nedges; e += nt)
+    L.ET[e] = code->enc_et[e];
+  if (tid <= code->nrows)
+    L.RP[tid] = g_rp;
+  for (int r = tid + nt; r <= code->nrows; r += nt)
+    L.RP[r] = (uint32_t)code->row_ptr[r];
+  for (uint32_t q = 4u * ndw + tid; q < kbytes + 8; q += nt) /* fillers (and the CRC bytes' place, until they are known) */
     c[q] = 0;
   if (tid == 0)
     red[0] = 0;
@@ -250,10 +391,6 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
       L.B[col * bs + W] = 0u;
     for (int i = tid; i < 4 * bs; i += nt)
       L.LB[i] = 0u;
-    for (int e = tid; e < code->nedges; e += nt)
-      L.ET[e] = ((uint32_t)code->e_col[e] << 16) | (code->e_info[e] & 0xffffu);
-    for (int r = tid; r <= code->nrows; r += nt)
-      L.RP[r] = (uint32_t)code->row_ptr[r];
   }
   __syncthreads();
   if (crc_len && tid == 0)
@@ -261,7 +398,7 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
   TB_TLOG();
   if (with_crc) {
     /* CB CRC24B over the segment's bytes in LDS: a thread runs the byte-table recurrence of crc_byte.c:184-218 over its
-     * 8 bytes, then moves its 24-bit register R to the end of the string: R(x) * x^n_after mod g, one Horner step per
+     * piece, then moves its 24-bit register R to the end of the string: R(x) * x^n_after mod g, one Horner step per
      * coefficient of R with x^n_after mod g from the power table (one load per thread, requested above).  The first
      * version looked up one power per set BIT in global memory, one dependent load after the other: 40 % of the kernel. */
     uint32_t reg = 0;
@@ -270,12 +407,7 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
     uint32_t x = reg;
     if (qn && n_after) {
       if (n_after >= 24u) {
-        x = 0;
-#pragma unroll
-        for (int k = 31; k >= 8; k--) {
-          x = (x << 1) ^ ((uint32_t)((int32_t)x >> 31) & 0x80006300u); /* x * X mod g (crc_byte.c:50: poly24b) */
-          x ^= (0u - ((reg >> k) & 1u)) & xq;
-        }
+        x = tb_crc_mulmod<24>(reg, xq, 0x80006300u); /* (crc_byte.c:50: poly24b) */
       } else { /* 8 or 16 bits behind the piece: as many zero bytes through the table */
         for (uint32_t b = 0; b < n_after; b += 8)
           x = (x << 8) ^ tab[x >> 24];
@@ -324,8 +456,7 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
    * e[k] = d[position of rank (rank0 + k) mod V], d[p] = code word bit p + 2Z.  In two steps per chunk of TB_TX_SEL_SYMS
    * modulation symbols: (1) the Qm sub-streams e[i*E/Qm + jj0 ..] are packed into LDS, 32 bits per item, gathered from
    * the code word in runs (a run ends at the circular buffer's wrap, at the filler gap, at the end of a lifted column);
-   * (2) one thread per ALIGNED 16 bytes of the output: every byte is one bit look-up in the sub-streams, the store is one
-   * dwordx4.  (The first version stored one byte per thread and bit, strided by Qm: 1664 segments x 9450 one-byte
+   * (2) one thread per 8 symbols: a byte of every sub-stream in, 8 Qm output bytes out (tb_tx_store_syms).  (The first version stored one byte per thread and bit, strided by Qm: 1664 segments x 9450 one-byte
    * stores were most of the kernel's 50 us.) */
   uint8_t *__restrict__ f = coded + j->out_off;
   const uint32_t E = j->E, Qm = j->Qm, EQ = E / Qm, V = j->V, rank0 = j->rank0, Foffset = j->Foffset, Fin = j->Fin;
@@ -360,47 +491,29 @@ __global__ void __launch_bounds__(512) tb_tx_fused_kernel(const tb_tx_seg_job *j
     }
     __syncthreads();
     TB_TLOG();
-    /* output bytes [m0, m1) of this chunk, in 16-byte blocks aligned in memory */
-    const uint32_t m0 = jj0 * Qm, m1 = (jj0 + nsym) * Qm;
-    const uintptr_t fa = reinterpret_cast<uintptr_t>(f + m0);
-    const uint32_t lead = (uint32_t)(fa & 15u), nblk = (lead + (m1 - m0) + 15u) >> 4;
-    const uint32_t qm_magic = 0xffffffffu / Qm + 1u; /* m / Qm for m < 2^24 and Qm in {1, 2, 4, 6, 8} (checked on the host: E < 2^24) */
-    for (uint32_t b = tid; b < nblk; b += nt) {
-      const int32_t first = (int32_t)(16u * b) - (int32_t)lead; /* offset of the block's first byte from m0 (may be < 0) */
-      const bool whole = first >= 0 && (uint32_t)first + 16u <= m1 - m0;
-      /* byte m of the chunk = bit (m % Qm) of symbol m / Qm; the 16 look-ups are unconditional (a byte outside the
-       * segment reads a clamped position and is not stored) */
-      const uint32_t mfirst = first >= 0 ? (uint32_t)first : 0u;
-      uint32_t sy = __umulhi(mfirst, qm_magic), i = mfirst - sy * Qm;
-      uint32_t wv[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const uint32_t bit = (sel[i * sel_stride + (sy >> 5)] >> (sy & 31u)) & 1u;
-        wv[q >> 2] |= bit << (8 * (q & 3));
-        if (first + q >= 0) { /* (always, in a whole block) */
-          i++;
-          if (i == Qm) {
-            i = 0;
-            sy++;
-          }
+    /* output bytes [jj0 Qm, (jj0 + nsym) Qm) of the segment */
+    uint8_t *dst = f + (size_t)jj0 * Qm;
+    switch (Qm) {
+      case 1: tb_tx_store_syms<1>(sel, sel_stride, nsym, dst, tid, nt); break;
+      case 2: tb_tx_store_syms<2>(sel, sel_stride, nsym, dst, tid, nt); break;
+      case 4: tb_tx_store_syms<4>(sel, sel_stride, nsym, dst, tid, nt); break;
+      case 6: tb_tx_store_syms<6>(sel, sel_stride, nsym, dst, tid, nt); break;
+      case 8: tb_tx_store_syms<8>(sel, sel_stride, nsym, dst, tid, nt); break;
+      default: /* (no such modulation in NR; kept correct) */
+        for (uint32_t m = tid; m < nsym * Qm; m += nt) {
+          const uint32_t sy = m / Qm, i = m - sy * Qm;
+          dst[m] = (uint8_t)((sel[i * sel_stride + (sy >> 5)] >> (sy & 31u)) & 1u);
         }
-        sy = sy < nsym ? sy : nsym - 1u;
-      }
-      uint8_t *dst = f + m0 + first;
-      if (whole) {
-        *reinterpret_cast<tb_u32x4_t *>(dst) = (tb_u32x4_t){wv[0], wv[1], wv[2], wv[3]};
-      } else { /* the segment's first / last block: only its own bytes (the neighbours' are written by their workgroups) */
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const int32_t mo = first + q;
-          if (mo >= 0 && (uint32_t)mo < m1 - m0)
-            dst[q] = (uint8_t)(wv[q >> 2] >> (8 * (q & 3)));
-        }
-      }
     }
     __syncthreads();
     TB_TLOG();
   }
+#ifdef TB_TIMING
+  if ((blockIdx.x & 127u) == 0 && threadIdx.x == 0) {
+    tlog[32 + 4 * (blockIdx.x >> 7) + 1] = clock64();
+    tlog[32 + 4 * (blockIdx.x >> 7) + 3] = wall_clock64();
+  }
+#endif
 }
 
 /* ---- RX 1: de-interleave + rate de-match (HARQ combining) + decoder input pack --------------------------------
@@ -604,7 +717,11 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_assemble_kernel(const tb_rx_
   }
   if (j.C > 1 && ok) {
     __syncthreads(); /* the CRC below re-reads b */
-    const uint32_t x = tb_partial_crc<32>(b, j.B, first, count, pow, tab);
+    uint32_t x; /* short pieces when the launch is small (latency), long ones when it fills the GPU (work): tb_chain.h */
+    if (gridDim.x <= 512u)
+      x = j.crc_type == 0 ? tb_partial_crc<8, 24>(b, j.B, first, count, pow, tab) : tb_partial_crc<8, 16>(b, j.B, first, count, pow, tab);
+    else
+      x = j.crc_type == 0 ? tb_partial_crc<32, 24>(b, j.B, first, count, pow, tab) : tb_partial_crc<32, 16>(b, j.B, first, count, pow, tab);
     if ((threadIdx.x & 63) == 0 && x)
       atomicXor(&acc[sj.tb], x);
   }

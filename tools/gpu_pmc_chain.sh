@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the chain kernels (own pass per group, --kernel-trace only): tools/gpu_pmc_chain.sh
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r02; mkdir -p $O; export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r03; mkdir -p $O; export TMPDIR=/tmp
 run() {
   cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_chain_$1" -- python "$GRAFT_REPO_ROOT/tools/slot_chain.py" 5 > "$GRAFT_REPO_ROOT/$O/pmc_chain_$1.log" 2>&1
   cd "$GRAFT_REPO_ROOT"; python - <<PY

@@ -32,3 +32,9 @@ names = ["loads -> LDS", "CB CRC", "unpack", "extend info", "lambda", "extend la
 for k in range(1, len(names) + 1):
     print("%-22s %7d clocks" % (names[k - 1], t[k] - t[k - 1]))
 print("%-22s %7d clocks" % ("total", t[len(names)] - t[0]))
+
+x = coded[off + 8 * 32:off + 8 * 32 + 8 * 4 * 14].cpu().numpy().view(np.int64).reshape(14, 4)
+w0 = x[0, 2]
+for k in range((sum(segs) + 127) // 128):
+    print("workgroup %4d: runs %6d clocks; starts %6.2f us, ends %6.2f us after workgroup 0 started (wall clock)" % (
+        128 * k, x[k, 1] - x[k, 0], (x[k, 2] - w0) / 100.0, (x[k, 3] - w0) / 100.0))
