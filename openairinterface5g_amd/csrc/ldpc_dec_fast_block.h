@@ -15,6 +15,8 @@
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_core.h"
 
+typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are read through the constant address space */
+
 /* The caller's view of a block is a type IO with these (wave-uniform) accessors, evaluated where the value is needed --
  * not up front -- so that what is only used after the last pass (output row, CRC table) or once per pass (abort flag)
  * is not carried in registers through the check-node loops (the kernel sits at the VGPR limit and already keeps part of

@@ -34,16 +34,39 @@
 #define LDPC_MB_NIT (16 + 4 * LDPC_MB_MAX)
 #define LDPC_MB_OUT (16 + 5 * LDPC_MB_MAX) /* needs 16 + 6 * 64 ints = 1600 bytes with SUB = 4 */
 
+/* Where a workgroup's blocks come from and go to.  JOBS = false: blocks first .. of a homogeneous launch, addressed by
+ * strides.  JOBS = true: a group of the transport-block chain's jobs (ldpc_kernels.h ldpc_dec_mgroup): buffers, report slot
+ * and transport-block abort flag per job; iteration cap, CRC length and CRC polynomial are the group's. */
+template <bool JOBS> struct ldpc_mb_io {
+  const ldpc_dec_args &a;
+  uint32_t first;
+  ldpc_job_ptr_t jobs; /* the group's first job (JOBS) */
+  int max_iter, crcE;
+  const uint32_t *crc_pow;
+  __device__ __forceinline__ const int8_t *llr(int b) const
+  {
+    return a.llr + (JOBS ? (size_t)jobs[b].llr_off : (size_t)(first + (uint32_t)b) * a.llr_stride);
+  }
+  __device__ __forceinline__ int8_t *out(int b) const
+  {
+    return a.out + (JOBS ? (size_t)jobs[b].out_off : (size_t)(first + (uint32_t)b) * a.out_stride);
+  }
+  __device__ __forceinline__ uint32_t iter_slot(int b) const { return JOBS ? (uint32_t)jobs[b].iter_idx : first + (uint32_t)b; }
+  __device__ __forceinline__ int *tb_abort(int b) const
+  {
+    return (JOBS && a.tb_abort && jobs[b].abort_idx >= 0) ? a.tb_abort + jobs[b].abort_idx : nullptr;
+  }
+};
+
 /* hard decisions of one block -> its output row (bnProc.h:1353-1380 packing).  SUB = 4: the block is byte `sub` of every
  * dword of group `v`. */
 template <int SUB>
-__device__ __forceinline__ void ldpc_mb_write_out(const ldpc_fast_lds &L, ldpc_code_ptr_t code, const ldpc_dec_args &a, uint32_t blk_global,
+__device__ __forceinline__ void ldpc_mb_write_out(const ldpc_fast_lds &L, ldpc_code_ptr_t code, const ldpc_dec_args &a, int8_t *orow,
                                                   int v, int sub, int tid, int nt)
 {
   const int Zv = code->Z, zr = Zv / SUB, astride = code->f_astride, pa = 2 * Zv;
   const int num_llr = code->num_llr, ncz = code->ncore * zr;
   const uint32_t zr_magic = 0xffffffffu / (uint32_t)zr + 1u;
-  int8_t *orow = a.out + (size_t)blk_global * a.out_stride;
   if (SUB == 1 && a.out_mode == 0) {
     uint32_t *o = reinterpret_cast<uint32_t *>(orow);
     const int nwords = (num_llr + 31) >> 5;
@@ -91,9 +114,10 @@ __device__ __forceinline__ void ldpc_mb_write_out(const ldpc_fast_lds &L, ldpc_c
 }
 
 /* blocks first .. first + n_valid - 1 of the launch (n_valid <= f_mb * SUB); results to a.out / a.n_iter */
-template <int SUB>
-__device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_dec_args &a, uint32_t first, int n_valid)
+template <int SUB, bool JOBS>
+__device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_mb_io<JOBS> &io, int n_valid)
 {
+  const ldpc_dec_args &a = io.a;
   const int Z = code->Z, zq = code->f_zq, zqb = code->f_zqb, rstride = code->f_rstride, astride = code->f_astride;
   const int pr = Z + 4, pa = 2 * Z; /* a block's bytes inside a message / extension row, inside an APP row */
   const uint32_t zq_magic = code->f_zq_magic, zqb_magic = code->f_zqb_magic;
@@ -116,12 +140,9 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
   const int n_app = ncore * zq, n_ext = (code->ncols - ncore) * zq;
   const int zr = Z / SUB; /* the real code's lifting size */
   const int n_groups = (n_valid + SUB - 1) / SUB; /* groups (SUB = 1: blocks) that hold at least one real block */
-  const uint32_t stride4 = a.llr_stride >> 2;
-  const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(a.llr + (size_t)first * a.llr_stride);
-  const int8_t *__restrict__ src8 = a.llr + (size_t)first * a.llr_stride;
   uint32_t *llr_lds = reinterpret_cast<uint32_t *>(fsm + code->f_lds_llr); /* SUB = 4: [ncore][f_mb][Z / 4] interleaved channel LLRs */
-  (void)src32; (void)src8; (void)llr_lds; (void)ncz; (void)z_magic; (void)zr; (void)num_llr;
-  const int max_pass = a.num_max_iter + 1;
+  (void)llr_lds; (void)ncz; (void)z_magic; (void)zr; (void)num_llr;
+  const int max_pass = io.max_iter + 1;
 
   /* ---- tables and state into LDS ------------------------------------------------------------------------ */
   const uint32_t lds0 = ldpc_lds_addr(fsm);
@@ -154,7 +175,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
   /* APP := channel LLR (both copies) and the extension columns' LLRs, block by block */
   if (SUB == 1) {
     for (int b = 0; b < n_valid; b++) {
-      const uint32_t *sb = src32 + (size_t)b * stride4;
+      const uint32_t *sb = reinterpret_cast<const uint32_t *>(io.llr(b));
       for (int i = tid; i < n_app; i += nt) {
         const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
         const uint32_t w = sb[i] ^ 0x80808080u;
@@ -171,14 +192,17 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
     /* dword (column c, real lane t) of group v = the four blocks' LLR bytes at c * zr + t (zero for a block beyond the
      * batch); n_app / n_ext count exactly these dwords per group (zq = Z / 4 = zr) */
     for (int v = 0; v < n_groups; v++) {
-      const int8_t *sb = src8 + (size_t)(SUB * v) * a.llr_stride;
       const int nsub = n_valid - SUB * v; /* real blocks in this group (>= 1) */
+      const int8_t *sb[SUB];
+#pragma unroll
+      for (int q = 0; q < SUB; q++)
+        sb[q] = io.llr(SUB * v + (q < nsub ? q : 0));
       for (int i = tid; i < n_app + n_ext; i += nt) {
         uint32_t w = 0;
 #pragma unroll
         for (int q = 0; q < SUB; q++)
           if (q < nsub)
-            w |= (uint32_t)(uint8_t)sb[(size_t)q * a.llr_stride + i] << (8 * q);
+            w |= (uint32_t)(uint8_t)sb[q][i] << (8 * q);
         const uint32_t wb = w ^ 0x80808080u;
         if (i < n_app) {
           const int c = (int)ldpc_umulhi((uint32_t)i, zq_magic), j = i - c * zq;
@@ -213,7 +237,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
       return;
     for (int blk = 0; blk < n_valid; blk++)
       if (flags[LDPC_MB_OUT + blk] && (!use_crc || flags[LDPC_MB_NIT + blk] >= 3))
-        ldpc_mb_write_out<SUB>(L, code, a, first + blk, blk / SUB, blk % SUB, tid, nt);
+        ldpc_mb_write_out<SUB>(L, code, a, io.out(blk), blk / SUB, blk % SUB, tid, nt);
   };
   for (int p = 1; p <= max_pass; ++p) {
     for (;;) {
@@ -255,6 +279,16 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
       flags[LDPC_MB_OUT + tid] = 1;
       atomicAdd(&flags[2], 1);
     }
+    if (JOBS && tid < n_valid && flags[LDPC_MB_ACT + tid] && p >= 2) {
+      /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass
+       * (pass count max_pass + 1, nothing written) */
+      int *ab = io.tb_abort(tid);
+      if (ab && __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        flags[LDPC_MB_NIT + tid] = max_pass + 1;
+        flags[LDPC_MB_ACT + tid] = 0;
+        atomicAdd(&flags[2], 1);
+      }
+    }
     __syncthreads();
     flush_stopped();
     if (flags[2] >= n_valid)
@@ -277,7 +311,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
           if (b < n_groups && group_active(b)) {
             const uint32_t colrec = coltbl[sc];
             const int c = (int)(colrec & 0xffu);
-            const uint32_t lw = SUB == 1 ? src32[(size_t)b * stride4 + (uint32_t)(c * zq + j)] : llr_lds[(c * code->f_mb + b) * zq + j];
+            const uint32_t lw = SUB == 1 ? reinterpret_cast<const uint32_t *>(io.llr(b))[c * zq + j] : llr_lds[(c * code->f_mb + b) * zq + j];
             ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw, b * pr, b * pa);
           }
         }
@@ -291,8 +325,8 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
     }
     __syncthreads();
     if (use_crc && p >= 3) { /* decoder.c:849-861, per block; see ldpc_dec_generic_block.h for the CRC argument */
-      const int crcE = a.E;
-      const uint32_t *crc_pow = a.crc_pow;
+      const int crcE = io.crcE;
+      const uint32_t *crc_pow = io.crc_pow;
       for (int blk = 0; blk < n_valid; blk++) {
         if (!flags[LDPC_MB_ACT + blk])
           continue;
@@ -343,13 +377,20 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
    * stopped ------------------------------------------------------------------------------------------------ */
   for (int blk = 0; blk < n_valid; blk++) {
     const int n_iter = flags[LDPC_MB_NIT + blk];
-    if (use_crc && n_iter < 3)
-      continue; /* decoder.c:849-861: p_out stays untouched */
+    if ((use_crc && n_iter < 3) || n_iter > max_pass)
+      continue; /* decoder.c:849-861: p_out stays untouched; a block given up with its transport block writes nothing */
     if (SUB != 1 && !flags[LDPC_MB_ACT + blk])
       continue; /* written when it stopped */
-    ldpc_mb_write_out<SUB>(L, code, a, first + blk, blk / SUB, blk % SUB, tid, nt);
+    ldpc_mb_write_out<SUB>(L, code, a, io.out(blk), blk / SUB, blk % SUB, tid, nt);
   }
-  if (tid < n_valid)
-    a.n_iter[first + tid] = flags[LDPC_MB_NIT + tid];
+  if (tid < n_valid) {
+    const int n_iter = flags[LDPC_MB_NIT + tid];
+    a.n_iter[io.iter_slot(tid)] = n_iter;
+    if (JOBS && n_iter == max_pass) { /* decoder.c:190-193: a failed segment gives the whole transport block up */
+      int *ab = io.tb_abort(tid);
+      if (ab)
+        __hip_atomic_store(ab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 #endif

@@ -15,7 +15,6 @@
 
 /* a block of a batch launch: addressed by strides (homogeneous batch) or by its job record; everything is read from
  * the kernel arguments / the job record where it is needed (scalar loads), see ldpc_dec_fast_block.h */
-typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t;
 template <bool JOBS> struct ldpc_batch_io {
   const ldpc_dec_args &a;
   ldpc_job_ptr_t job; /* nullptr without JOBS: known at compile time, so the selects below fold away */
@@ -142,15 +141,29 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_kernel(const ldpc_de
   const uint32_t per_wg = (uint32_t)code->f_mb * SUB;
   const uint32_t first = blockIdx.x * per_wg;
   const uint32_t left = a.n_blocks - first;
-  ldpc_dec_fast_mblock<SUB>(fsm, code, a, first, left < per_wg ? (int)left : (int)per_wg);
+  const ldpc_mb_io<false> io{a, first, (ldpc_job_ptr_t) nullptr, a.num_max_iter, a.E, a.crc_pow};
+  ldpc_dec_fast_mblock<SUB, false>(fsm, code, io, left < per_wg ? (int)left : (int)per_wg);
+}
+/* the same for a group of jobs of the transport-block chain (small segments of one code, cap and CRC) */
+template <int SUB>
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ldpc_dec_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  typedef const ldpc_dec_mgroup LDPC_CONST_AS *grp_ptr_t;
+  const grp_ptr_t gr = (grp_ptr_t)a.mgroups + blockIdx.x;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)gr->code;
+  const ldpc_mb_io<true> io{a, gr->first_job, (ldpc_job_ptr_t)a.jobs + gr->first_job, gr->num_max_iter, gr->E, a.crc_pow_tbl[gr->crc_type & 3]};
+  ldpc_dec_fast_mblock<SUB, true>(fsm, code, io, (int)gr->n_valid);
 }
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[5] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+  const void *k[7] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>)};
-  for (int i = 0; i < 5; i++) {
+                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4>)};
+  for (int i = 0; i < 7; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -182,6 +195,20 @@ hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a0, const ldpc_code_d
     hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<4>, grid, block, hc.f_lds_total, stream, a);
   else
     hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<1>, grid, block, hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_fast_multi_jobs(const ldpc_dec_args &a, int sub, int n_threads, int lds_bytes, uint32_t n_groups,
+                                           hipStream_t stream)
+{
+  if (n_groups == 0)
+    return hipSuccess;
+  if (!a.jobs || !a.mgroups)
+    return hipErrorInvalidValue;
+  if (sub == 4)
+    hipLaunchKernelGGL(ldpc_dec_fast_multi_jobs_kernel<4>, dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_multi_jobs_kernel<1>, dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -21,6 +21,15 @@ struct ldpc_dec_job {
   int32_t abort_idx;            /* index into ldpc_dec_args.tb_abort of the block's transport block, -1: none */
   int32_t pad;
 };
+/* several jobs of ONE small code, the same iteration cap and the same CRC in one workgroup (ldpc_dec_fast_mblock.h): the
+ * transport-block chain groups a batch's small segments this way; the jobs of a group are consecutive in the job array */
+struct ldpc_dec_mgroup {
+  const ldpc_code_desc_t *code; /* device: the code's several-blocks-per-workgroup descriptor */
+  uint32_t first_job;           /* index into ldpc_dec_args.jobs */
+  uint32_t n_valid;             /* jobs in this workgroup, <= f_mb * f_sub */
+  int32_t num_max_iter, E, crc_type;
+  int32_t pad;
+};
 struct ldpc_enc_job {
   const ldpc_code_desc_t *code; /* device, full-rate descriptor */
   uint64_t in_off, out_off;     /* bytes from ldpc_enc_args.in / .out */
@@ -43,6 +52,7 @@ struct ldpc_dec_args {
   const ldpc_dec_job *jobs; /* NULL: homogeneous batch addressed by strides */
   const uint32_t *crc_pow_tbl[4]; /* per crc_type, used with jobs */
   int *tb_abort;            /* with jobs: per transport block "a segment failed" flags (zero on entry), or NULL */
+  const ldpc_dec_mgroup *mgroups; /* ldpc_launch_dec_fast_multi_jobs: one group per workgroup */
   /* host-buffer batches (ldpc_launch_dec_fast_pull): the workgroup first fetches its row from `pull` -- page-locked host
    * memory, device-mapped address -- into its row of `llr` (device memory, written here), then decodes from there */
   const int8_t *pull;
@@ -80,6 +90,10 @@ hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_des
 /* small lifting sizes, homogeneous batch: host_code.f_mb blocks per workgroup (ldpc_dec_fast_mblock.h) */
 hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                       hipStream_t stream);
+/* the same for groups of jobs (a.jobs, a.mgroups): sub = 1 or 4 = f_sub of the groups' descriptors; workgroup size and LDS =
+ * the maxima over the groups */
+hipError_t ldpc_launch_dec_fast_multi_jobs(const ldpc_dec_args &a, int sub, int n_threads, int lds_bytes, uint32_t n_groups,
+                                           hipStream_t stream);
 /* encoder: one workgroup per code block; workgroup size and dynamic LDS of the selected encoder kernel for a code */
 int ldpc_enc_is_packed(void); /* 1: bit-packed kernel selected (default), 0: NRLDPC_HIP_ENC_KERNEL=bytes */
 void ldpc_enc_launch_shape(const ldpc_code_desc_t &host_code, int *n_threads, int *lds_bytes);

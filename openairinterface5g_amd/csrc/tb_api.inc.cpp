@@ -57,9 +57,15 @@ struct TbPlan {
    * too: the kernel clears Ncb values per segment, what lies behind them in the caller's array must come back unchanged.) */
   bool harq_dense = true;
   std::vector<size_t> harq_span; /* per block: {first int16, int16 count} */
-  size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int threads[2] = {64, 64}, lds[2] = {0, 0};
-  size_t n_fast = 0, n_gen = 0;
+  size_t off[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int threads[4] = {64, 64, 64, 64}, lds[4] = {0, 0, 0, 0};
+  size_t n_fast = 0, n_gen = 0; /* encode */
+  /* decode: the decoder launches of the batch.  A job-array launch has ONE workgroup shape (threads, LDS) = the maxima over
+   * its jobs, so a batch that mixes code sizes is cut into launches by how many workgroups of a job's shape a CU holds
+   * (1, 2, 4, 8, 16+): a Zc = 8 segment does not occupy the LDS of a Zc = 384 one.  kind 0: fast kernel, 1: generic
+   * kernel, 2 / 3: several small segments per workgroup (f_sub = 1 / 4; grp_off = their ldpc_dec_mgroup array) */
+  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; };
+  std::vector<DecLaunch> dec;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
   /* the descriptors tb[0 .. n_tb) of a call (one device's share of the batch) */
   bool matches(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, uint32_t salt) const
@@ -135,6 +141,26 @@ int tb_wait_upload(TbCtx &c)
 
 /* NRLDPC_HIP_TB_ABORT=0: every segment of a lost transport block is decoded to the end (the reference's behaviour when its
  * workers never overlap); default: siblings of a failed segment give up at their next pass (decoder.c:190-193, 556-559) */
+/* NRLDPC_HIP_TB_MULTI=0: every segment of the chain gets a workgroup of its own.  Default: when a batch holds enough
+ * segments to fill the GPU anyway, small segments of the same code, iteration cap and CRC share workgroups
+ * (ldpc_dec_fast_mblock.h: a lifted row of a small code fills only a fraction of a 64-item task). */
+/* NRLDPC_HIP_TB_CLASSES=0: one decoder launch per kernel for the whole batch (workgroup shape = the largest segment's) */
+bool tb_classes_enabled()
+{
+  static const int v = [] {
+    const char *e = getenv("NRLDPC_HIP_TB_CLASSES");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return v != 0;
+}
+#define TB_MULTI_MIN_PER_CU 64 /* shared workgroups from this many small segments per CU on (see profiles/r03/README.md) */
+/* read when a plan is built (not cached: the tests switch it between calls) */
+int tb_multi_mode()
+{
+  const char *e = getenv("NRLDPC_HIP_TB_MULTI");
+  return e ? atoi(e) : 1;
+}
+
 bool tb_abort_enabled()
 {
   static const int v = [] {
@@ -381,9 +407,9 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     std::vector<uint8_t> key_tb((const uint8_t *)tbs, (const uint8_t *)tbs + (size_t)ntb * sizeof(nrLDPC_hip_tb_t));
     std::vector<tb_rx_tb_job> tbj(ntb);
     std::vector<tb_rx_seg_job> sj;
-    std::vector<ldpc_dec_job> fast_jobs, gen_jobs;
+    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; };
+    std::vector<ShapedJob> single; /* segments that get a workgroup of their own */
     Arena ar;
-    int fast_threads = 64, fast_lds = 0, gen_threads = 64, gen_lds = 0;
     TbExtent ex;
     std::vector<size_t> harq_span;
     uint32_t rx_lds_elems = 8;
@@ -396,6 +422,22 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         n_seg_total += sg.C;
     }
     const bool lat_shape = n_seg_total <= (uint32_t)G().n_cus;
+    const int multi_mode = tb_multi_mode();
+    const bool multi_ok = multi_mode != 0 && n_seg_total >= 2u * (uint32_t)G().n_cus;
+    const bool classes = tb_classes_enabled() && !lat_shape;
+    auto add_single = [&](const CodeEntry *ce, const ldpc_dec_job &dj) {
+      const ldpc_code_desc_t &hc = ce->host, &shape = lat_shape ? ce->host_lat : ce->host;
+      const double cost = (double)hc.num_llr * dj.num_max_iter;
+      if (hc.f_ok)
+        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, shape.f_lds_total, cost});
+      else
+        single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost});
+    };
+    struct MultiCand { const CodeEntry *ce; ldpc_dec_job dj; };
+    std::vector<MultiCand> cands;
+    std::vector<ldpc_dec_job> mjobs[2];
+    std::vector<ldpc_dec_mgroup> mgrp[2];
+    int m_threads[2] = {64, 64}, m_lds[2] = {0, 0};
     for (uint32_t i = 0; i < ntb; i++) {
       nrLDPC_hip_tb_t &t = tbs[i];
       if (tb_validate(t) != 0)
@@ -454,7 +496,6 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         rx_lds_elems = std::max(rx_lds_elems, tb_rx_lds_elems(E, rm.Fin, rm.Ncb));
         j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
         ldpc_dec_job dj;
-        const ldpc_code_desc_t &shape = lat_shape ? ce->host_lat : ce->host;
         dj.code = (hc.f_ok && lat_shape) ? ce->dev_lat : ce->dev;
         dj.llr_off = j.l_off;
         dj.out_off = tj.c_off0 + (uint64_t)r * cstride;
@@ -466,26 +507,88 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         dj.pad = 0;
         if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
           return set_error("CRC length outside the code block");
-        if (hc.f_ok) {
-          fast_jobs.push_back(dj);
-          fast_threads = std::max(fast_threads, shape.f_n_threads);
-          fast_lds = std::max(fast_lds, shape.f_lds_total);
-        } else {
-          gen_jobs.push_back(dj);
-          gen_threads = std::max(gen_threads, hc.n_threads);
-          gen_lds = std::max(gen_lds, hc.lds_total);
-        }
+        if (multi_ok && ce->dev_multi) /* candidates for a shared workgroup; sorted into groups below */
+          cands.push_back(MultiCand{ce, dj});
+        else
+          add_single(ce, dj);
         sj.push_back(j);
         r_offset += E;
       }
       t.llrLen = llrLen;
     }
+    /* the candidates, grouped by (code, iteration cap, CRC length and type): a group of at least four shares workgroups of
+     * f_mb * f_sub segments each; smaller groups go back to one workgroup per segment */
+    if (multi_mode != 2 && cands.size() < (size_t)TB_MULTI_MIN_PER_CU * (size_t)G().n_cus) { /* they all fit side by side as they are */
+      for (const MultiCand &q : cands)
+        add_single(q.ce, q.dj);
+      cands.clear();
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const MultiCand &x, const MultiCand &y) {
+      if (x.ce != y.ce) return x.ce < y.ce;
+      if (x.dj.num_max_iter != y.dj.num_max_iter) return x.dj.num_max_iter < y.dj.num_max_iter;
+      if (x.dj.E != y.dj.E) return x.dj.E < y.dj.E;
+      return x.dj.crc_type < y.dj.crc_type;
+    });
+    for (size_t i0 = 0; i0 < cands.size();) {
+      size_t i1 = i0;
+      while (i1 < cands.size() && cands[i1].ce == cands[i0].ce && cands[i1].dj.num_max_iter == cands[i0].dj.num_max_iter &&
+             cands[i1].dj.E == cands[i0].dj.E && cands[i1].dj.crc_type == cands[i0].dj.crc_type)
+        i1++;
+      const CodeEntry *ce = cands[i0].ce;
+      const ldpc_code_desc_t &hm = ce->host_multi;
+      if (i1 - i0 >= 4) {
+        const int cls = hm.f_sub == 4 ? 1 : 0;
+        const size_t per_wg = (size_t)hm.f_mb * (size_t)hm.f_sub;
+        for (size_t k = i0; k < i1; k += per_wg) {
+          ldpc_dec_mgroup gq;
+          memset(&gq, 0, sizeof(gq));
+          gq.code = ce->dev_multi;
+          gq.first_job = (uint32_t)mjobs[cls].size();
+          gq.n_valid = (uint32_t)std::min(per_wg, i1 - k);
+          gq.num_max_iter = cands[i0].dj.num_max_iter; gq.E = cands[i0].dj.E; gq.crc_type = cands[i0].dj.crc_type;
+          for (size_t q = k; q < k + gq.n_valid; q++)
+            mjobs[cls].push_back(cands[q].dj);
+          mgrp[cls].push_back(gq);
+        }
+        m_threads[cls] = std::max(m_threads[cls], hm.f_n_threads);
+        m_lds[cls] = std::max(m_lds[cls], hm.f_lds_total);
+      } else {
+        for (size_t q = i0; q < i1; q++)
+          add_single(ce, cands[q].dj);
+      }
+      i0 = i1;
+    }
+    /* one launch per (kernel, workgroups of that shape a CU holds), the heaviest segments first in each */
+    auto wg_class = [&](const ShapedJob &j) {
+      if (!classes)
+        return 0;
+      const int per_cu = std::min(2048 / std::max(j.threads, 64), (160 * 1024) / std::max(j.lds, 1024));
+      return per_cu >= 16 ? 4 : per_cu >= 8 ? 3 : per_cu >= 4 ? 2 : per_cu >= 2 ? 1 : 0;
+    };
+    std::stable_sort(single.begin(), single.end(), [&](const ShapedJob &x, const ShapedJob &y) {
+      const int cx = wg_class(x) * 2 + x.kind, cy = wg_class(y) * 2 + y.kind;
+      return cx != cy ? cx < cy : (classes && x.cost > y.cost);
+    });
+    std::vector<ldpc_dec_job> single_jobs(single.size());
+    std::vector<TbPlan::DecLaunch> dec;
+    for (size_t q = 0; q < single.size(); q++) {
+      single_jobs[q] = single[q].dj;
+      if (q == 0 || wg_class(single[q]) != wg_class(single[q - 1]) || single[q].kind != single[q - 1].kind)
+        dec.push_back(TbPlan::DecLaunch{single[q].kind, q * sizeof(ldpc_dec_job), 0, 0, 64, 0});
+      TbPlan::DecLaunch &dl = dec.back();
+      dl.n++;
+      dl.threads = std::max(dl.threads, single[q].threads);
+      dl.lds = std::max(dl.lds, single[q].lds);
+    }
     const size_t n_seg = sj.size();
     const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
-                 o_fast = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
-                 o_gen = o_fast + align_up(fast_jobs.size() * sizeof(ldpc_dec_job), 16),
-                 o_acc = o_gen + align_up(gen_jobs.size() * sizeof(ldpc_dec_job), 16), /* CRC accumulators, then the per-TB
-                                                                                           abort flags: uploaded as zeros */
+                 o_single = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
+                 o_mj0 = o_single + align_up(single_jobs.size() * sizeof(ldpc_dec_job), 16),
+                 o_mg0 = o_mj0 + align_up(mjobs[0].size() * sizeof(ldpc_dec_job), 16),
+                 o_mj1 = o_mg0 + align_up(mgrp[0].size() * sizeof(ldpc_dec_mgroup), 16),
+                 o_mg1 = o_mj1 + align_up(mjobs[1].size() * sizeof(ldpc_dec_job), 16),
+                 o_acc = o_mg1 + align_up(mgrp[1].size() * sizeof(ldpc_dec_mgroup), 16), /* CRC accumulators, then the per-TB
+                                                                                            abort flags: uploaded as zeros */
                  jobs_bytes = o_acc + align_up((size_t)ntb * 2 * sizeof(uint32_t), 16),
                  o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
     if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
@@ -494,18 +597,38 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
     memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
     memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
-    memcpy(c.jobs_h.p + o_fast, fast_jobs.data(), fast_jobs.size() * sizeof(ldpc_dec_job));
-    memcpy(c.jobs_h.p + o_gen, gen_jobs.data(), gen_jobs.size() * sizeof(ldpc_dec_job));
+    memcpy(c.jobs_h.p + o_single, single_jobs.data(), single_jobs.size() * sizeof(ldpc_dec_job));
+    memcpy(c.jobs_h.p + o_mj0, mjobs[0].data(), mjobs[0].size() * sizeof(ldpc_dec_job));
+    memcpy(c.jobs_h.p + o_mg0, mgrp[0].data(), mgrp[0].size() * sizeof(ldpc_dec_mgroup));
+    memcpy(c.jobs_h.p + o_mj1, mjobs[1].data(), mjobs[1].size() * sizeof(ldpc_dec_job));
+    memcpy(c.jobs_h.p + o_mg1, mgrp[1].data(), mgrp[1].size() * sizeof(ldpc_dec_mgroup));
     if (tb_upload_jobs(c, pl.jobs_d.p, jobs_bytes, s) != 0)
       return -1;
+    /* a launch too short to be worth its own tail (one segment's latency at the end of every launch) joins the launch of
+     * the next larger shape before it: the jobs are consecutive */
+    for (size_t k = 1; k < dec.size();) {
+      if (dec[k].kind == dec[k - 1].kind && dec[k].n < (uint32_t)G().n_cus / 2) {
+        dec[k - 1].n += dec[k].n;
+        dec[k - 1].threads = std::max(dec[k - 1].threads, dec[k].threads);
+        dec[k - 1].lds = std::max(dec[k - 1].lds, dec[k].lds);
+        dec.erase(dec.begin() + (long)k);
+      } else {
+        k++;
+      }
+    }
+    for (TbPlan::DecLaunch &dl : dec)
+      dl.jobs_off += o_single;
+    if (!mgrp[0].empty())
+      dec.push_back(TbPlan::DecLaunch{2, o_mj0, o_mg0, (uint32_t)mgrp[0].size(), m_threads[0], m_lds[0]});
+    if (!mgrp[1].empty())
+      dec.push_back(TbPlan::DecLaunch{3, o_mj1, o_mg1, (uint32_t)mgrp[1].size(), m_threads[1], m_lds[1]});
+    pl.dec.swap(dec);
     pl.n_seg = n_seg; pl.scratch_top = ar.top;
     pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi; pl.ext[4] = ex.harq_lo; pl.ext[5] = ex.harq_hi;
     pl.out_dense = ex.pay_sum == ex.pay_hi - ex.pay_lo;
     pl.harq_dense = ex.harq_sum == ex.harq_hi - ex.harq_lo;
     pl.harq_span.swap(harq_span);
-    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_fast; pl.off[3] = o_gen; pl.off[4] = o_iter; pl.off[5] = o_acc;
-    pl.threads[0] = fast_threads; pl.lds[0] = fast_lds; pl.threads[1] = gen_threads; pl.lds[1] = gen_lds;
-    pl.n_fast = fast_jobs.size(); pl.n_gen = gen_jobs.size();
+    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[4] = o_iter; pl.off[5] = o_acc;
     pl.rx_lds_elems = rx_lds_elems;
     pl.llr_len.resize(ntb);
     for (uint32_t i = 0; i < ntb; i++)
@@ -516,8 +639,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   if (c.scratch.ensure(pl.scratch_top) != 0)
     return -1;
   const size_t n_seg = pl.n_seg;
-  const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_fast = pl.off[2], o_gen = pl.off[3], o_iter = pl.off[4], o_acc = pl.off[5];
-  const int fast_threads = pl.threads[0], fast_lds = pl.lds[0], gen_threads = pl.threads[1], gen_lds = pl.lds[1];
+  const size_t o_tb = pl.off[0], o_seg = pl.off[1], o_iter = pl.off[4], o_acc = pl.off[5];
   int32_t *d_iter = reinterpret_cast<int32_t *>(pl.jobs_d.p + o_iter);
   uint8_t *payload = b->payload;
   const int16_t *llr = static_cast<const int16_t *>(b->coded);
@@ -561,13 +683,16 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   da.crc_pow_tbl[NR_HIP_CRC24_A] = G().crc_pow_24a_long;
   int *d_abort = reinterpret_cast<int *>(pl.jobs_d.p + o_acc) + ntb; /* zero on entry, left zero by the verdict kernel */
   da.tb_abort = d_abort;
-  if (pl.n_fast) {
-    da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_fast);
-    HIP_TRY(ldpc_launch_dec_fast_jobs(da, fast_threads, fast_lds, (uint32_t)pl.n_fast, s));
-  }
-  if (pl.n_gen) {
-    da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + o_gen);
-    HIP_TRY(ldpc_launch_dec_generic_jobs(da, gen_threads, gen_lds, (uint32_t)pl.n_gen, s));
+  for (size_t k = 0; k < pl.dec.size(); k++) {
+    const TbPlan::DecLaunch &dl = pl.dec[k];
+    da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + dl.jobs_off);
+    da.mgroups = reinterpret_cast<const ldpc_dec_mgroup *>(pl.jobs_d.p + dl.grp_off);
+    if (dl.kind == 0)
+      HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s));
+    else if (dl.kind == 1)
+      HIP_TRY(ldpc_launch_dec_generic_jobs(da, dl.threads, dl.lds, dl.n, s));
+    else
+      HIP_TRY(ldpc_launch_dec_fast_multi_jobs(da, dl.kind == 3 ? 4 : 1, dl.threads, dl.lds, dl.n, s));
   }
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
   HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), ntb,

@@ -1,6 +1,8 @@
 """-m gpu: transport-block chain on the GPU (TB CRC, segmentation, encode, rate matching, interleaving; and back:
 de-interleaving, rate de-matching with HARQ combining, pack, decode with CRC stop, reassembly, TB CRC) vs the same
 chain composed from the oracle pieces the way the reference composes its functions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -281,6 +283,55 @@ def test_repeated_descriptors_reuse_the_plan(hip):
             for r in range(segs[i]):
                 assert np.array_equal(harq_gpu[row + r], harq_ref[r]), (call, i, r)
             row += segs[i]
+
+
+def test_small_transport_blocks_share_workgroups(hip):
+    """A batch with enough segments to fill the GPU: the small single-segment transport blocks of the same code, cap and
+    CRC length are decoded several to a workgroup (tb_api.inc.cpp groups them, ldpc_dec_fast_mblock.h decodes a group --
+    side by side for Zc % 4 == 0, four byte-interleaved for the other lifting sizes), the rest one per workgroup as
+    before.  All 93 sizes of 38.214 Table 5.1.3.2-1 at two rates, six copies each with their own payload and noise level
+    (clean, marginal, hopeless): ACK, pass count, payload, soft buffer and llrLen of every block equal the oracle
+    chain's."""
+    tbs_table = [24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 208, 224,
+                 240, 256, 272, 288, 304, 320, 336, 352, 368, 384, 408, 432, 456, 480, 504, 528, 552, 576, 608, 640, 672, 704,
+                 736, 768, 808, 848, 888, 928, 984, 1032, 1064, 1128, 1160, 1192, 1224, 1256, 1288, 1320, 1352, 1416, 1480,
+                 1544, 1608, 1672, 1736, 1800, 1864, 1928, 2024, 2088, 2152, 2216, 2280, 2408, 2472, 2536, 2600, 2664, 2728,
+                 2792, 2856, 2976, 3104, 3240, 3368, 3496, 3624, 3752, 3824]
+    rng = np.random.default_rng(214)
+    tbs, copies = [], 6
+    for A in tbs_table:
+        for rate in (0.3, 0.75):
+            BG = 2 if (A <= 292 or rate <= 0.25 or (A <= 3824 and rate <= 0.67)) else 1
+            Qm = int(rng.choice([2, 4, 6]))
+            G = max(int(A / rate) // Qm, 4) * Qm
+            for _ in range(copies):
+                tbs.append(dict(A=A, G=G, BG=BG, Qm=Qm, Nl=1, rv=0, tbslbrm=0))
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    coded = hip.ldpc.dlsch_encode_host(tbs, pays)
+    llrs = []
+    for k, f in enumerate(coded):
+        sigma = (1.5, 3.0, 4.5, 2.2, 6.0, 12.0)[k % copies]
+        llrs.append(np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + sigma * rng.standard_normal(f.size)), -200, 200).astype(np.int16))
+    rx = [dict(t, round=0, llrLen=0) for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    harq_gpu = np.zeros((len(tbs), stride), np.int16)
+    os.environ["NRLDPC_HIP_TB_MULTI"] = "2" # share whatever the batch size (the default waits for 64 small segments per CU)
+    try:
+        out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq_gpu, numMaxIter=8)
+    finally:
+        del os.environ["NRLDPC_HIP_TB_MULTI"]
+    n_ack = 0
+    for i, t in enumerate(tbs):
+        harq_ref = [np.zeros(stride, np.int16)]
+        p_ref, ack_ref, its, state = O.ulsch_decode(dict(t), llrs[i], harq_ref, 8, 0, 0, vec=True)
+        assert bool(ack[i]) == ack_ref and itm[i] == min(max(its), 9) and rx[i]["llrLen"] == state, (i, t, its, int(itm[i]), bool(ack[i]))
+        if ack_ref:
+            assert np.array_equal(out[i], p_ref), t
+            n_ack += 1
+        else:
+            assert not out[i].any(), t               # a lost block delivers zeros
+        assert np.array_equal(harq_gpu[i], harq_ref[0]), t
+    assert 0.3 * len(tbs) < n_ack < 0.9 * len(tbs), n_ack
 
 
 def test_every_small_tbs_of_38214(hip):
