@@ -215,6 +215,21 @@ typedef struct nrLDPC_hip_tb_batch {
 } nrLDPC_hip_tb_batch_t;
 int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b);
 int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b);
+/* ---------------------------------------------------------------------------------------------------
+ * The reference's OFFLOAD plugin slot (`ldpc_interface_offload`, loaded with the suffix "_t2": nr_init.c:138-139).  Same
+ * signatures as LDPCdecoder / LDPCencoder, the semantics of nrLDPC_decoder/nrLDPC_decoder_offload.c:1036-1140: one
+ * segment per call, rate (de)matching + (de)interleaving + HARQ combining inside, soft buffers kept on the device per
+ * (ulsch_id, segment).  libldpc_hip_t2.so (csrc/ldpc_t2_shim.c) exports them under the plugin names.
+ *   decoder: p_llr = E int8 LLRs in transmission order; p_decParams: BG, Z, R, numMaxIter + E, Qm, rv, F, setCombIn
+ *     (0: the soft buffer starts afresh, 1: combine); C = segment number r; p_out = ceil(K/8) decoded bytes.  Parity-check
+ *     stop.  Returns the passes run (> numMaxIter: not decoded), < 0 on a hard error (nr_ulsch_decoding.c:269).
+ *   encoder: input[0] = the segment's K - F bits (CB CRC attached by the caller), output[0] = E rate-matched,
+ *     interleaved bits, one per byte; impp: BG, Zc, K, F, Kb, E, Qm, rv.  Returns 0 / -1.
+ * ------------------------------------------------------------------------------------------------- */
+int32_t nrLDPC_hip_offload_init(void);
+int32_t nrLDPC_hip_offload_decoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
+                                   int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
+int32_t nrLDPC_hip_offload_encoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp);
 /* helpers with the reference's semantics (nr_segmentation parameter part, nr_get_E, nr_get_R_ldpc_decoder) */
 int32_t nrLDPC_hip_segmentation(uint32_t B, uint8_t BG, uint32_t *C, uint32_t *K, uint32_t *Zc, uint32_t *F); /* returns Kb, -1 */
 uint32_t nrLDPC_hip_get_E(uint32_t G, uint32_t C, uint32_t Qm, uint32_t Nl, uint32_t r);

@@ -1097,3 +1097,4 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
 } /* extern "C" */
 
 #include "tb_api.inc.cpp"
+#include "tb_offload.inc.cpp"

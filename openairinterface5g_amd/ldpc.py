@@ -227,6 +227,67 @@ def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=No
     return [o[:N] for o in outs]
 
 
+# ---- the reference's offload plugin slot (ldpc_interface_offload, "_t2"): libldpc_hip_t2.so ------------------------------
+EXPORTS += ["nrLDPC_hip_offload_init", "nrLDPC_hip_offload_decoder", "nrLDPC_hip_offload_encoder"]
+T2_EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver"]
+_t2 = None
+
+
+def load_offload_library():
+    """dlopen libldpc_hip_t2.so the way load_LDPClib("_t2", &ldpc_interface_offload) does (nr_init.c:138-139,
+    nrLDPC_load.c:45-75) and run its LDPCinit.  Raises if the library is missing or no GPU is usable."""
+    global _t2
+    if _t2 is None:
+        load_library()
+        path = Path(os.environ.get("NRLDPC_HIP_T2_LIB", Path(LIB_PATH).parent / "libldpc_hip_t2.so"))
+        if not path.exists():
+            raise RuntimeError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+        L = C.CDLL(str(path))
+        for name in T2_EXPORTS:
+            getattr(L, name)
+        L.LDPCdecoder.restype = C.c_int32
+        L.LDPCdecoder.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.LDPCencoder.restype = C.c_int32
+        L.LDPCencoder.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if L.LDPCinit() != 0:
+            raise RuntimeError(f"offload LDPCinit failed: {last_error()}")
+        _t2 = L
+    return _t2
+
+
+def offload_decoder(BG, Z, R, llr, Qm, rv, F, setCombIn, ulsch_id=0, r=0, harq_pid=0, numMaxIter=8):
+    """One segment through the offload slot's LDPCdecoder (nrLDPC_decoder_offload.c:1036, caller nr_ulsch_decoding.c:225-268):
+    llr = the E received soft values as int8 in transmission order.  Returns (passes, decoded bytes uint8[ceil(K/8)])."""
+    L = load_offload_library()
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    p = t_nrLDPC_dec_params(BG=BG, Z=Z, R=R, F=F, Qm=Qm, rv=rv, numMaxIter=numMaxIter, E=llr.size, setCombIn=1 if setCombIn else 0)
+    K = (22 if BG == 1 else 10) * Z
+    out = np.zeros((K + 7) // 8 + 64, dtype=np.uint8)
+    n = L.LDPCdecoder(C.addressof(p), harq_pid, ulsch_id, r, llr.ctypes.data, out.ctypes.data, None, None)
+    if n < 0:
+        raise RuntimeError(f"offload LDPCdecoder failed: {last_error()}")
+    assert not out[(K + 7) // 8:].any()
+    return n, out[:(K + 7) // 8]
+
+
+def offload_encoder(BG, Zc, segment, F, E, Qm, rv, Kb=None):
+    """One segment through the offload slot's LDPCencoder (nrLDPC_decoder_offload.c:1094, caller nr_dlsch_coding.c:366-383):
+    segment = its K - F bits (uint8, MSB first).  Returns the E rate-matched, interleaved bits, one per byte."""
+    L = load_offload_library()
+    K = (22 if BG == 1 else 10) * Zc
+    seg = np.ascontiguousarray(np.asarray(segment, dtype=np.uint8)[:(K - F) // 8])
+    out = np.full(E + 64, 0xEE, dtype=np.uint8)
+    ip = (C.c_void_p * 1)(seg.ctypes.data)
+    op = (C.c_void_p * 1)(out.ctypes.data)
+    impp = encoder_implemparams_t(n_segments=1, macro_num=0, Kr=K, Kb=(22 if BG == 1 else 10) if Kb is None else Kb, Zc=Zc, BG=BG,
+                                  K=K, F=F, Qm=Qm, E=E, rv=rv)
+    rc = L.LDPCencoder(C.addressof(ip), C.addressof(op), C.addressof(impp))
+    if rc != 0:
+        raise RuntimeError(f"offload LDPCencoder failed: {last_error()}")
+    assert (out[E:] == 0xEE).all()
+    return out[:E]
+
+
 def decode_batch_host(BG, Z, R, llr, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_crc=False, E=0,
                       crc_type=CRC24_B, out=None, kernel=0):
     """llr: int8[n_blocks, >= ncols*Z] host array. Returns (n_iter int32[n], out uint8[n, out_bytes])."""
