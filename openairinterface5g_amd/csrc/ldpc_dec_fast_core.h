@@ -234,6 +234,73 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
+/* The same check-node item with the "minimum of the OTHER edges" taken as min(prefix, suffix) instead of through the two
+ * smallest magnitudes: P_k = min(cap, M_0 .. M_k) on the way forward (cap = 127 biased: every output is capped for free),
+ * S = min(M_{k+1} ..) on the way back, o_k = min(P_{k-1}, S).  Per edge and 16-bit half that is four packed min/max
+ * (|d|, prefix, output, suffix) where the two-minima form needs five plus a subtract (|d|, max, min, min; min, sub) and six
+ * more per row -- and the packed ops are the slow ones (tools/ubench/valu_rate.hip).  The sign bytes of an edge are
+ * gathered once in the forward sweep (one v_perm, needed anyway) and kept instead of the two D1 words: five registers per
+ * edge (M, P per half + signs) instead of four; a workgroup of 16 waves has 128.  Bit-identical outputs: the minimum over
+ * the other edges is the same number whichever way it is found. */
+template <int D, bool EXT, bool P1 = false>
+LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0, int boff_a = 0)
+{
+  const int t = 4 * j + boff_r, ta = 4 * j + boff_a;
+  uint32_t m_lo[D], m_hi[D], p_lo[D], p_hi[D], s4[D];
+  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
+  ldpc_v2u pl = cap, ph = cap;
+  uint32_t sx4 = 0, parw = 0, extl = 0, exth = 0;
+  uint8_t *rrow = L.r + e0 * rstride + t;
+  uint8_t *rpad = rrow + (j == 0 ? Z : 0); /* lanes 0..3 are written twice: wrap-around copy behind the row */
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    const uint32_t info = L.etbl[e0 + k];
+    const uint32_t rw = P1 ? 0u : *reinterpret_cast<const uint32_t *>(rrow + k * rstride);
+    uint32_t dl, dh;
+    if (EXT && k == D - 1)
+      ldpc_fast_cn_edge<true, P1>(L, info, t, rw, true, dl, dh, parw, extl, exth);
+    else
+      ldpc_fast_cn_edge<false, P1>(L, info, ta, rw, true, dl, dh, parw, extl, exth);
+    const ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
+    const ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+    m_lo[k] = ldpc_u2u32(ml);
+    m_hi[k] = ldpc_u2u32(mh);
+    s4[k] = ldpc_perm(dh, dl, 0x07050301u); /* the bytes that carry bit 15 of the four D1 halves */
+    sx4 ^= s4[k];
+    if (k < D - 1) {
+      pl = ldpc_pminu(pl, ml);
+      ph = ldpc_pminu(ph, mh);
+      p_lo[k] = ldpc_u2u32(pl);
+      p_hi[k] = ldpc_u2u32(ph);
+    }
+  }
+  if ((D - 1) & 1)
+    sx4 ^= 0x80808080u;
+  ldpc_v2u sl = cap, sh = cap;
+#pragma unroll
+  for (int k = D - 1; k >= 0; k--) {
+    const ldpc_v2u pvl = k ? ldpc_as_v2u(p_lo[k - 1]) : cap, pvh = k ? ldpc_as_v2u(p_hi[k - 1]) : cap;
+    const ldpc_v2u ol = k == D - 1 ? pvl : ldpc_pminu(pvl, sl), oh = k == D - 1 ? pvh : ldpc_pminu(pvh, sh);
+    if (k > 0) {
+      sl = k == D - 1 ? ldpc_as_v2u(m_lo[k]) : ldpc_pminu(sl, ldpc_as_v2u(m_lo[k]));
+      sh = k == D - 1 ? ldpc_as_v2u(m_hi[k]) : ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
+    }
+    const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u); /* low bytes: the magnitudes 0..127 */
+    const uint32_t n4 = ((sx4 ^ s4[k]) >> 7) & 0x01010101u;
+    const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
+    *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
+    *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
+  }
+  uint32_t np = (parw >> 7) & 0x01010101u;
+  if (EXT) {
+    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
+    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
+  }
+  if (D & 1)
+    np ^= 0x01010101u;
+  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+}
+
 /* A degree-19 row item shared by TWO neighbouring lanes (lane parity = half): half 0 takes the row's edges 0..9, half 1
  * edges 10..18 -- ten edges in registers each (the one-lane version has to re-read LDS in its second sweep, MODE 2, or
  * spill), the partial minima / sign xor / parity word are swapped through a DPP move and merged, then every lane writes
@@ -244,12 +311,15 @@ __device__ __forceinline__ uint32_t ldpc_swap_pair(uint32_t v) { return (uint32_
 template <bool P1>
 __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int half)
 {
+  /* prefix / suffix form (ldpc_fast_cn_ps): a lane's prefix over ALL its edges is what its partner needs -- it starts the
+   * partner's suffix, so "the other lane's edges" cost nothing per edge */
   constexpr int N = 10;
   const int t = 4 * j;
   const int ebase = e0 + (half ? 10 : 0);
-  uint32_t d_lo[N], d_hi[N], g_lo[N], g_hi[N];
-  ldpc_v2u m1l = ldpc_splatu(0xffff), m2l = m1l, m1h = m1l, m2h = m1l;
-  uint32_t sxl = 0, sxh = 0, parw = 0, extl = 0, exth = 0;
+  uint32_t m_lo[N], m_hi[N], p_lo[N], p_hi[N], s4[N];
+  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
+  ldpc_v2u pl = cap, ph = cap;
+  uint32_t sx4 = 0, parw = 0, extl = 0, exth = 0;
   uint8_t *rrow = L.r + ebase * rstride + t;
   uint8_t *rpad = rrow + (j == 0 ? Z : 0);
 #pragma unroll
@@ -262,46 +332,36 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
     ldpc_fast_cn_edge<false, P1>(L, info, t, rw, true, dl, dh, pw, extl, exth);
     ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
     ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+    uint32_t sg = ldpc_perm(dh, dl, 0x07050301u);
     if (!live) {
       ml = mh = ldpc_splatu(0xffff);
-      dl = dh = 0u;
+      sg = 0u;
       pw = 0u;
     }
-    d_lo[k] = dl; d_hi[k] = dh;
-    g_lo[k] = ldpc_u2u32(ml); g_hi[k] = ldpc_u2u32(mh);
+    m_lo[k] = ldpc_u2u32(ml); m_hi[k] = ldpc_u2u32(mh);
+    s4[k] = sg;
+    sx4 ^= sg;
     parw ^= pw;
-    sxl ^= dl;
-    sxh ^= dh;
-    m2l = ldpc_pminu(m2l, ldpc_pmaxu(m1l, ml));
-    m1l = ldpc_pminu(m1l, ml);
-    m2h = ldpc_pminu(m2h, ldpc_pmaxu(m1h, mh));
-    m1h = ldpc_pminu(m1h, mh);
+    pl = ldpc_pminu(pl, ml);
+    ph = ldpc_pminu(ph, mh);
+    p_lo[k] = ldpc_u2u32(pl); p_hi[k] = ldpc_u2u32(ph);
   }
-  { /* merge with the partner lane */
-    const ldpc_v2u p1l = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m1l))), p2l = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m2l)));
-    const ldpc_v2u p1h = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m1h))), p2h = ldpc_as_v2u(ldpc_swap_pair(ldpc_u2u32(m2h)));
-    m2l = ldpc_pminu(ldpc_pmaxu(m1l, p1l), ldpc_pminu(m2l, p2l));
-    m1l = ldpc_pminu(m1l, p1l);
-    m2h = ldpc_pminu(ldpc_pmaxu(m1h, p1h), ldpc_pminu(m2h, p2h));
-    m1h = ldpc_pminu(m1h, p1h);
-    sxl ^= ldpc_swap_pair(sxl);
-    sxh ^= ldpc_swap_pair(sxh);
-    parw ^= ldpc_swap_pair(parw);
-  }
-  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
-  m1l = ldpc_pminu(m1l, cap); m2l = ldpc_pminu(m2l, cap);
-  m1h = ldpc_pminu(m1h, cap); m2h = ldpc_pminu(m2h, cap);
-  const uint32_t sl = (ldpc_u2u32(m1l) - 0x80008000u) + ldpc_u2u32(m2l), sh = (ldpc_u2u32(m1h) - 0x80008000u) + ldpc_u2u32(m2h);
-  /* (19 - 1 is even: no sign flip; a neutral slot xor-ed zeros into sx) */
-  const uint32_t sx4 = ldpc_perm(sxh, sxl, 0x07050301u);
+  /* the partner lane's minimum over all its edges starts this lane's suffix; signs and parity are merged */
+  ldpc_v2u sl = ldpc_as_v2u(ldpc_swap_pair(p_lo[N - 1])), sh = ldpc_as_v2u(ldpc_swap_pair(p_hi[N - 1]));
+  sx4 ^= ldpc_swap_pair(sx4);
+  parw ^= ldpc_swap_pair(parw);
+  /* (19 - 1 is even: no sign flip; a neutral slot xor-ed zeros into sx4) */
 #pragma unroll
-  for (int k = 0; k < N; k++) {
+  for (int k = N - 1; k >= 0; k--) {
     const bool live = k < N - 1 || !half;
-    const uint32_t dl = d_lo[k], dh = d_hi[k];
-    const ldpc_v2u ml = ldpc_as_v2u(g_lo[k]), mh = ldpc_as_v2u(g_hi[k]);
-    const uint32_t ol = sl - ldpc_u2u32(ldpc_pminu(ml, m2l)), oh = sh - ldpc_u2u32(ldpc_pminu(mh, m2h));
-    const uint32_t o4 = ldpc_perm(oh, ol, 0x06040200u);
-    const uint32_t n4 = ((sx4 ^ ldpc_perm(dh, dl, 0x07050301u)) >> 7) & 0x01010101u;
+    const ldpc_v2u pvl = k ? ldpc_as_v2u(p_lo[k - 1]) : cap, pvh = k ? ldpc_as_v2u(p_hi[k - 1]) : cap;
+    const ldpc_v2u ol = ldpc_pminu(pvl, sl), oh = ldpc_pminu(pvh, sh);
+    if (k > 0) {
+      sl = ldpc_pminu(sl, ldpc_as_v2u(m_lo[k]));
+      sh = ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
+    }
+    const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u);
+    const uint32_t n4 = ((sx4 ^ s4[k]) >> 7) & 0x01010101u;
     const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
     if (live) {
       *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
@@ -367,19 +427,19 @@ LDPC_HD uint32_t ldpc_fast_cn_dispatch(int deg, int ext, const ldpc_fast_lds &L,
   if (!ext) {
     switch (deg) {
       case 19: return ldpc_fast_cn<19, false, LDPC_F_MODE_D19, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-      case 10: return ldpc_fast_cn<10, false, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-      default: return ldpc_fast_cn<8, false, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+      case 10: return ldpc_fast_cn_ps<10, false, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+      default: return ldpc_fast_cn_ps<8, false, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
     }
   }
   switch (deg) {
-    case 3: return ldpc_fast_cn<3, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 4: return ldpc_fast_cn<4, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 5: return ldpc_fast_cn<5, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 6: return ldpc_fast_cn<6, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 7: return ldpc_fast_cn<7, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 8: return ldpc_fast_cn<8, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    case 9: return ldpc_fast_cn<9, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
-    default: return ldpc_fast_cn<10, true, 0, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 3: return ldpc_fast_cn_ps<3, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 4: return ldpc_fast_cn_ps<4, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 5: return ldpc_fast_cn_ps<5, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 6: return ldpc_fast_cn_ps<6, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 7: return ldpc_fast_cn_ps<7, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 8: return ldpc_fast_cn_ps<8, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    case 9: return ldpc_fast_cn_ps<9, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
+    default: return ldpc_fast_cn_ps<10, true, P1>(L, e0, j, Z, rstride, boff_r, boff_a);
   }
 }
 
