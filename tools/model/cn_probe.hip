@@ -21,7 +21,10 @@ __device__ __forceinline__ ldpc_fast_lds probe_lds(uint8_t *fsm, const probe_arg
   {                                                                                                  \
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];                                   \
     const ldpc_fast_lds L = probe_lds(fsm, a);                                                       \
-    a.out[threadIdx.x] = ldpc_fast_cn<D, EXT != 0, MODE>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride); \
+    if (MODE == 0) /* the library's dispatch: prefix/suffix body for everything whose registers fit */                        \
+      a.out[threadIdx.x] = ldpc_fast_cn_ps<D, EXT != 0>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride);         \
+    else                                                                                             \
+      a.out[threadIdx.x] = ldpc_fast_cn<D, EXT != 0, MODE>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride); \
   }
 CN_PROBE(19, 0, 2) CN_PROBE(10, 0, 0) CN_PROBE(8, 0, 0)
 /* a degree-19 row item shared by two lanes (ldpc_fast_cn19_pair): one lane's instructions */
