@@ -274,7 +274,12 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
       p_hi[k] = ldpc_u2u32(ph);
     }
   }
-  if ((D - 1) & 1)
+  /* Signs.  The byte of s4 that stands for a lane is the high byte of 0x8000 + d, d in [-255, 255]: 0x80 (d >= 0) or 0x7f
+   * (d < 0), nothing else.  The xor over the OTHER edges is therefore 0x80 / 0x7f (odd count) or 0x00 / 0xff (even count:
+   * xor 0x80 in) per byte -- 0x7f = "an odd number of them is negative".  With x that byte, the biased output byte
+   * 128 + o (x = 0x80) or 128 - o = (o ^ 0x7f) + 1 (x = 0x7f) is (o ^ x) + (x & 1): four plain 32-bit ops per edge for
+   * four lanes, no carry between the bytes (the largest value is 0x80 + 0x7f resp. 0x7f + 1). */
+  if (!((D - 1) & 1))
     sx4 ^= 0x80808080u;
   ldpc_v2u sl = cap, sh = cap;
 #pragma unroll
@@ -286,8 +291,8 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
       sh = k == D - 1 ? ldpc_as_v2u(m_hi[k]) : ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
     }
     const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u); /* low bytes: the magnitudes 0..127 */
-    const uint32_t n4 = ((sx4 ^ s4[k]) >> 7) & 0x01010101u;
-    const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
+    const uint32_t x4 = sx4 ^ s4[k];
+    const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
     *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
     *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
   }
@@ -350,7 +355,7 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
   ldpc_v2u sl = ldpc_as_v2u(ldpc_swap_pair(p_lo[N - 1])), sh = ldpc_as_v2u(ldpc_swap_pair(p_hi[N - 1]));
   sx4 ^= ldpc_swap_pair(sx4);
   parw ^= ldpc_swap_pair(parw);
-  /* (19 - 1 is even: no sign flip; a neutral slot xor-ed zeros into sx4) */
+  sx4 ^= 0x80808080u; /* 19 - 1 others: an even count (see ldpc_fast_cn_ps; a neutral slot xor-ed zeros into sx4) */
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
     const bool live = k < N - 1 || !half;
@@ -361,8 +366,8 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
       sh = ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
     }
     const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u);
-    const uint32_t n4 = ((sx4 ^ s4[k]) >> 7) & 0x01010101u;
-    const uint32_t w = (o4 ^ (0x80808080u - n4)) + n4;
+    const uint32_t x4 = sx4 ^ s4[k];
+    const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
     if (live) {
       *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
       *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
