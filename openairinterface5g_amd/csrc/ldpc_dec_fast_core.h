@@ -57,6 +57,23 @@ LDPC_HD uint32_t ldpc_u2u32(ldpc_v2u x) { return __builtin_bit_cast(uint32_t, x)
 LDPC_HD ldpc_v2u ldpc_splatu(unsigned v) { return (ldpc_v2u){(unsigned short)v, (unsigned short)v}; }
 LDPC_HD ldpc_v2u ldpc_pminu(ldpc_v2u a, ldpc_v2u b) { return __builtin_elementwise_min(a, b); }
 LDPC_HD ldpc_v2u ldpc_pmaxu(ldpc_v2u a, ldpc_v2u b) { return __builtin_elementwise_max(a, b); }
+/* Minimum of three packed magnitude KEYS in one instruction.  A key is 0x8000 + m (m <= 0x3bff): as an f16 that is the
+ * negative number whose magnitude grows with m, so the f16 MAXIMUM of keys is the key with the smallest m -- and gfx950
+ * has a packed three-input f16 maximum that issues at the rate of v_pk_min_u16 (tools/ubench/pk_max3_f16.hip: every triple
+ * of keys incl. the denormal range 0x8000 .. 0x80ff, the cap and the neutral element checked against the integer minimum;
+ * f16 denormals are not flushed in HIP kernels).  LDPC_KEY_NEUTRAL = -65504, the largest finite magnitude. */
+#define LDPC_KEY_NEUTRAL 0xfbffu
+LDPC_HD ldpc_v2u ldpc_pmin3_keys(ldpc_v2u a, ldpc_v2u b, ldpc_v2u c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)),
+      "v"(__builtin_bit_cast(uint32_t, c)));
+  return __builtin_bit_cast(ldpc_v2u, r);
+#else
+  return __builtin_elementwise_min(__builtin_elementwise_min(a, b), c);
+#endif
+}
 LDPC_HD uint32_t ldpc_as_u32(ldpc_v2i x) { return __builtin_bit_cast(uint32_t, x); }
 LDPC_HD ldpc_v2i ldpc_splat(int v) { return (ldpc_v2i){(short)v, (short)v}; }
 LDPC_HD ldpc_v2i ldpc_pmin(ldpc_v2i a, ldpc_v2i b) { return __builtin_elementwise_min(a, b); }
@@ -234,21 +251,23 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
-/* The same check-node item with the "minimum of the OTHER edges" taken as min(prefix, suffix) instead of through the two
- * smallest magnitudes: P_k = min(cap, M_0 .. M_k) on the way forward (cap = 127 biased: every output is capped for free),
- * S = min(M_{k+1} ..) on the way back, o_k = min(P_{k-1}, S).  Per edge and 16-bit half that is four packed min/max
- * (|d|, prefix, output, suffix) where the two-minima form needs five plus a subtract (|d|, max, min, min; min, sub) and six
- * more per row -- and the packed ops are the slow ones (tools/ubench/valu_rate.hip).  The sign bytes of an edge are
- * gathered once in the forward sweep (one v_perm, needed anyway) and kept instead of the two D1 words: five registers per
- * edge (M, P per half + signs) instead of four; a workgroup of 16 waves has 128.  Bit-identical outputs: the minimum over
- * the other edges is the same number whichever way it is found. */
+/* The same check-node item with the "minimum of the OTHER edges" taken from prefixes and suffixes instead of through the
+ * two smallest magnitudes, with three-input minima (ldpc_pmin3_keys).  Edges are taken in pairs (2i, 2i+1):
+ *   forward   P_i = min(P_{i-1}, M_2i, M_2i+1), P_{-1} = cap (= 127 biased: every output is capped for free)
+ *   backward  S_i = min(S_{i+1}, M_2i, M_2i+1)
+ *   o_2i = min(P_{i-1}, M_2i+1, S_{i+1}),  o_2i+1 = min(P_{i-1}, M_2i, S_{i+1})
+ * i.e. per pair of edges and 16-bit half FOUR packed ops (prefix, suffix, two outputs) + two for the magnitudes, where
+ * the two-minima form needs five plus a subtract per EDGE and six more per row -- and the packed ops are the slow ones
+ * (tools/ubench/valu_rate.hip).  The sign bytes of an edge are gathered once in the forward sweep (one v_perm, needed
+ * anyway) and kept instead of the two D1 words.  Registers per edge: M per half + signs, P per half and pair.
+ * Bit-identical outputs: the minimum over the other edges is the same number whichever way it is found. */
 template <int D, bool EXT, bool P1 = false>
 LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int boff_r = 0, int boff_a = 0)
 {
   const int t = 4 * j + boff_r, ta = 4 * j + boff_a;
-  uint32_t m_lo[D], m_hi[D], p_lo[D], p_hi[D], s4[D];
+  constexpr int NP = D / 2; /* whole pairs; an odd D leaves edge D - 1 on its own */
+  uint32_t m_lo[D], m_hi[D], p_lo[NP], p_hi[NP], s4[D];
   const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
-  ldpc_v2u pl = cap, ph = cap;
   uint32_t sx4 = 0, parw = 0, extl = 0, exth = 0;
   uint8_t *rrow = L.r + e0 * rstride + t;
   uint8_t *rpad = rrow + (j == 0 ? Z : 0); /* lanes 0..3 are written twice: wrap-around copy behind the row */
@@ -267,11 +286,10 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
     m_hi[k] = ldpc_u2u32(mh);
     s4[k] = ldpc_perm(dh, dl, 0x07050301u); /* the bytes that carry bit 15 of the four D1 halves */
     sx4 ^= s4[k];
-    if (k < D - 1) {
-      pl = ldpc_pminu(pl, ml);
-      ph = ldpc_pminu(ph, mh);
-      p_lo[k] = ldpc_u2u32(pl);
-      p_hi[k] = ldpc_u2u32(ph);
+    if ((k & 1) && k < D - 1) { /* P of pair k / 2: wanted by the pairs (and the single edge) behind it */
+      const int i = k / 2;
+      p_lo[i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_lo[i - 1]) : cap, ldpc_as_v2u(m_lo[k - 1]), ml));
+      p_hi[i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_hi[i - 1]) : cap, ldpc_as_v2u(m_hi[k - 1]), mh));
     }
   }
   /* Signs.  The byte of s4 that stands for a lane is the high byte of 0x8000 + d, d in [-255, 255]: 0x80 (d >= 0) or 0x7f
@@ -281,20 +299,31 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
    * four lanes, no carry between the bytes (the largest value is 0x80 + 0x7f resp. 0x7f + 1). */
   if (!((D - 1) & 1))
     sx4 ^= 0x80808080u;
-  ldpc_v2u sl = cap, sh = cap;
-#pragma unroll
-  for (int k = D - 1; k >= 0; k--) {
-    const ldpc_v2u pvl = k ? ldpc_as_v2u(p_lo[k - 1]) : cap, pvh = k ? ldpc_as_v2u(p_hi[k - 1]) : cap;
-    const ldpc_v2u ol = k == D - 1 ? pvl : ldpc_pminu(pvl, sl), oh = k == D - 1 ? pvh : ldpc_pminu(pvh, sh);
-    if (k > 0) {
-      sl = k == D - 1 ? ldpc_as_v2u(m_lo[k]) : ldpc_pminu(sl, ldpc_as_v2u(m_lo[k]));
-      sh = k == D - 1 ? ldpc_as_v2u(m_hi[k]) : ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
-    }
+  auto put = [&](int k, ldpc_v2u ol, ldpc_v2u oh) {
     const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u); /* low bytes: the magnitudes 0..127 */
     const uint32_t x4 = sx4 ^ s4[k];
     const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
     *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
     *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
+  };
+  ldpc_v2u sl = cap, sh = cap; /* suffix behind the pair in hand (set before its first use) */
+  if (D & 1) {                 /* the single last edge: everything before it */
+    put(D - 1, ldpc_as_v2u(p_lo[NP - 1]), ldpc_as_v2u(p_hi[NP - 1]));
+    sl = ldpc_as_v2u(m_lo[D - 1]);
+    sh = ldpc_as_v2u(m_hi[D - 1]);
+  }
+#pragma unroll
+  for (int i = NP - 1; i >= 0; i--) {
+    const int k0 = 2 * i, k1 = 2 * i + 1;
+    const ldpc_v2u pvl = i ? ldpc_as_v2u(p_lo[i - 1]) : cap, pvh = i ? ldpc_as_v2u(p_hi[i - 1]) : cap;
+    const ldpc_v2u a0l = ldpc_as_v2u(m_lo[k0]), a0h = ldpc_as_v2u(m_hi[k0]), a1l = ldpc_as_v2u(m_lo[k1]), a1h = ldpc_as_v2u(m_hi[k1]);
+    const bool last = !(D & 1) && i == NP - 1; /* nothing behind this pair */
+    put(k0, last ? ldpc_pminu(pvl, a1l) : ldpc_pmin3_keys(pvl, a1l, sl), last ? ldpc_pminu(pvh, a1h) : ldpc_pmin3_keys(pvh, a1h, sh));
+    put(k1, last ? ldpc_pminu(pvl, a0l) : ldpc_pmin3_keys(pvl, a0l, sl), last ? ldpc_pminu(pvh, a0h) : ldpc_pmin3_keys(pvh, a0h, sh));
+    if (i > 0) {
+      sl = last ? ldpc_pminu(a0l, a1l) : ldpc_pmin3_keys(sl, a0l, a1l);
+      sh = last ? ldpc_pminu(a0h, a1h) : ldpc_pmin3_keys(sh, a0h, a1h);
+    }
   }
   uint32_t np = (parw >> 7) & 0x01010101u;
   if (EXT) {
@@ -316,14 +345,13 @@ __device__ __forceinline__ uint32_t ldpc_swap_pair(uint32_t v) { return (uint32_
 template <bool P1>
 __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, int e0, int j, int Z, int rstride, int half)
 {
-  /* prefix / suffix form (ldpc_fast_cn_ps): a lane's prefix over ALL its edges is what its partner needs -- it starts the
-   * partner's suffix, so "the other lane's edges" cost nothing per edge */
-  constexpr int N = 10;
+  /* the pair network of ldpc_fast_cn_ps over this lane's ten slots; the partner lane's minimum over ALL its edges is the
+   * suffix behind this lane's last pair, so "the other lane's edges" cost nothing per edge */
+  constexpr int N = 10, NP = N / 2;
   const int t = 4 * j;
   const int ebase = e0 + (half ? 10 : 0);
-  uint32_t m_lo[N], m_hi[N], p_lo[N], p_hi[N], s4[N];
+  uint32_t m_lo[N], m_hi[N], p_lo[NP], p_hi[NP], s4[N];
   const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
-  ldpc_v2u pl = cap, ph = cap;
   uint32_t sx4 = 0, parw = 0, extl = 0, exth = 0;
   uint8_t *rrow = L.r + ebase * rstride + t;
   uint8_t *rpad = rrow + (j == 0 ? Z : 0);
@@ -339,7 +367,7 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
     ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
     uint32_t sg = ldpc_perm(dh, dl, 0x07050301u);
     if (!live) {
-      ml = mh = ldpc_splatu(0xffff);
+      ml = mh = ldpc_splatu(LDPC_KEY_NEUTRAL);
       sg = 0u;
       pw = 0u;
     }
@@ -347,30 +375,36 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
     s4[k] = sg;
     sx4 ^= sg;
     parw ^= pw;
-    pl = ldpc_pminu(pl, ml);
-    ph = ldpc_pminu(ph, mh);
-    p_lo[k] = ldpc_u2u32(pl); p_hi[k] = ldpc_u2u32(ph);
+    if (k & 1) {
+      const int i = k / 2;
+      p_lo[i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_lo[i - 1]) : cap, ldpc_as_v2u(m_lo[k - 1]), ml));
+      p_hi[i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_hi[i - 1]) : cap, ldpc_as_v2u(m_hi[k - 1]), mh));
+    }
   }
   /* the partner lane's minimum over all its edges starts this lane's suffix; signs and parity are merged */
-  ldpc_v2u sl = ldpc_as_v2u(ldpc_swap_pair(p_lo[N - 1])), sh = ldpc_as_v2u(ldpc_swap_pair(p_hi[N - 1]));
+  ldpc_v2u sl = ldpc_as_v2u(ldpc_swap_pair(p_lo[NP - 1])), sh = ldpc_as_v2u(ldpc_swap_pair(p_hi[NP - 1]));
   sx4 ^= ldpc_swap_pair(sx4);
   parw ^= ldpc_swap_pair(parw);
   sx4 ^= 0x80808080u; /* 19 - 1 others: an even count (see ldpc_fast_cn_ps; a neutral slot xor-ed zeros into sx4) */
 #pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const bool live = k < N - 1 || !half;
-    const ldpc_v2u pvl = k ? ldpc_as_v2u(p_lo[k - 1]) : cap, pvh = k ? ldpc_as_v2u(p_hi[k - 1]) : cap;
-    const ldpc_v2u ol = ldpc_pminu(pvl, sl), oh = ldpc_pminu(pvh, sh);
-    if (k > 0) {
-      sl = ldpc_pminu(sl, ldpc_as_v2u(m_lo[k]));
-      sh = ldpc_pminu(sh, ldpc_as_v2u(m_hi[k]));
+  for (int i = NP - 1; i >= 0; i--) {
+    const ldpc_v2u pvl = i ? ldpc_as_v2u(p_lo[i - 1]) : cap, pvh = i ? ldpc_as_v2u(p_hi[i - 1]) : cap;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int k = 2 * i + q, ko = 2 * i + 1 - q;
+      const bool live = k < N - 1 || !half;
+      const ldpc_v2u ol = ldpc_pmin3_keys(pvl, ldpc_as_v2u(m_lo[ko]), sl), oh = ldpc_pmin3_keys(pvh, ldpc_as_v2u(m_hi[ko]), sh);
+      const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u);
+      const uint32_t x4 = sx4 ^ s4[k];
+      const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
+      if (live) {
+        *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
+        *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
+      }
     }
-    const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u);
-    const uint32_t x4 = sx4 ^ s4[k];
-    const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
-    if (live) {
-      *reinterpret_cast<uint32_t *>(rrow + k * rstride) = w;
-      *reinterpret_cast<uint32_t *>(rpad + k * rstride) = w;
+    if (i > 0) {
+      sl = ldpc_pmin3_keys(sl, ldpc_as_v2u(m_lo[2 * i]), ldpc_as_v2u(m_lo[2 * i + 1]));
+      sh = ldpc_pmin3_keys(sh, ldpc_as_v2u(m_hi[2 * i]), ldpc_as_v2u(m_hi[2 * i + 1]));
     }
   }
   uint32_t np = (parw >> 7) & 0x01010101u;
