@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-2 evidence in one GPU call: bench line, rocprofv3 kernel statistics, PMC passes (own runs, --kernel-trace only),
-# chain kernels, per-segment ABI, host path, link / HBM / BAR micro-benchmarks.  Everything lands in gpurun_out/r02/final.
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r02/final; mkdir -p $O; export TMPDIR=/tmp
+# Round evidence in one GPU call (tools/gpu_profiles.sh [round tag, default r03]): bench line, rocprofv3 kernel statistics, PMC passes (own runs, --kernel-trace only),
+# chain kernels, per-segment ABI, host path, link / HBM / BAR micro-benchmarks.  Everything lands in gpurun_out/<tag>/final.
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${1:-r03}/final; mkdir -p $O; export TMPDIR=/tmp
 L=$GRAFT_REPO_ROOT/openairinterface5g_amd/lib/libldpc_hip.so
 rocminfo | grep -E 'Marketing Name|Compute Unit|gfx' | head -6 > $O/rocminfo.txt 2>&1; nproc >> $O/rocminfo.txt; cat /sys/fs/cgroup/cpu.max >> $O/rocminfo.txt 2>&1
 echo "== bench"; timeout 900 python bench.py --steps 50 > $O/fast_bench.json 2> $O/fast_bench.err; echo rc=$?
@@ -31,10 +31,29 @@ for k, v in sorted(acc.items()):
         print("$c", k, "n=%d mean=%.1f KiB max=%.1f" % (len(v), sum(v) / len(v), max(v)))
 PY
 done | tee $O/chain_pmc.txt
+echo "== chain: retransmission (HARQ round 1: only the received positions of the soft buffers are rewritten)"
+timeout 300 python tools/slot_chain.py 20 0.18 retx | tee $O/slot_chain_retx.txt
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_chain_retx" -- python "$GRAFT_REPO_ROOT/tools/slot_chain.py" 5 0.18 retx > /dev/null 2>&1
+cd "$GRAFT_REPO_ROOT"; python - <<PY | tee -a $O/chain_pmc.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("$O/pmc_chain_retx/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"].split("(")[0][:60]].append(float(row["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    if "dematch" in k:
+        print("WRITE_SIZE (rounds 0 and 1 alternate)", k, "n=%d mean=%.1f KiB min=%.1f max=%.1f" % (len(v), sum(v) / len(v), min(v), max(v)))
+PY
+echo "== mixed batch of small transport blocks"; timeout 300 python tools/small_tbs.py 64 50 0.35 2>&1 | tee $O/small_tbs.txt; timeout 300 python tools/small_tbs.py 256 30 0.35 2>&1 | tee -a $O/small_tbs.txt
+echo "== offload slot"; timeout 120 python tools/offload_latency.py 2>&1 | tee $O/offload_latency.txt
+echo "== sims"; timeout 300 python tests/ulschsim_hip.py -R 106 -m 9 -s 13 -n 100 2>&1 | tail -4 | tee $O/ulschsim.txt; timeout 300 python tests/dlschsim_hip.py -R 106 -m 9 -s 13 -n 100 2>&1 | tail -4 | tee $O/dlschsim.txt
+echo "== bench --gpus 1 under torch.distributed (RCCL path)"; BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 20 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err; tail -c 600 $O/bench_dist1.json
+echo "== per-call breakdown"; timeout 120 python tools/srv_breakdown.py 3000 2>&1 | tail -1 | tee $O/srv_breakdown.txt; timeout 120 python tools/srv_breakdown.py 3000 1 384 13 -12 2>&1 | tail -1 | tee -a $O/srv_breakdown.txt
 echo "== abi"
 run() { echo "$1 T=$2 case=${4:-mix}: $(env $1 timeout 60 ./tests/abi_threads.bin $L $2 ${3:-400} $4 2>&1 | tail -1 | cut -c1-330)"; }
 { run X=1 1 3000 1; run X=1 1 2000 0; run NRLDPC_HIP_SRV_BAR=0 1 3000 1; run NRLDPC_HIP_SERVER=0 1 1000 1
   for T in 1 4 16 32 64; do run X=1 $T 1000; done
+  for W in yield sleep; do for T in 1 32; do run NRLDPC_HIP_SRV_WAIT=$W $T 1000; done; done
   for T in 1 16 32; do run NRLDPC_HIP_SERVER=0 $T 300; done; } | tee $O/abi_threads.txt
 timeout 300 python tests/ldpctest_hip.py -l 8448 -s 10 -n 200 > $O/ldpctest_hip_8448.txt 2>&1; tail -3 $O/ldpctest_hip_8448.txt
 timeout 120 python tools/enc_call_latency.py 2000 2>&1 | grep segment | sed "s/^/server: /" > $O/enc_call_latency.txt; NRLDPC_HIP_ENC_SERVER=0 timeout 120 python tools/enc_call_latency.py 1000 2>&1 | grep segment | sed "s/^/launch per call: /" >> $O/enc_call_latency.txt; cat $O/enc_call_latency.txt
