@@ -12,7 +12,7 @@ def maxval(sub, counter):
             if "ldpc_dec" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
     return max(vals)   # the fixed-work launches (9 passes) are the largest
-model = Path("profiles/r02/valu_issue_model.json")
+model = sorted(Path("profiles").glob("r0*/valu_issue_model.json"))[-1]  # the newest round's
 model_avg_ns = json.loads(model.read_text())["avg_ns_per_valu_wave_inst"] if model.exists() else None
 fetch_kib, write_kib = maxval("pmc_fetch", "FETCH_SIZE"), maxval("pmc_write", "WRITE_SIZE")
 valu = maxval("pmc_sq1", "SQ_INSTS_VALU")
@@ -23,7 +23,7 @@ out = {"ldpc_dec_bg1_z384_r13_b1024_bytes_per_launch": int((2 * fetch_kib + writ
        "valu_wave_insts_per_launch": int(valu),
        # mean issue time per VALU wave-instruction per SIMD: opcode histogram of the kernel's bodies (disassembly) x the
        # per-opcode issue times of profiles/r01/valu_rate_ubench.txt, weighted by the code's task structure
-       # (tools/valu_issue_model.py -> profiles/r02/valu_issue_model.json); not a hand-entered figure any more
+       # (tools/valu_issue_model.py -> profiles/rNN/valu_issue_model.json); not a hand-entered figure any more
        "valu_avg_ns_per_wave_inst_per_simd": model_avg_ns,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes on bench.py (1024 x BG1 Zc=384 R13, 9 passes)"}
 Path("profiles").mkdir(exist_ok=True)

@@ -32,6 +32,7 @@ UBENCH_ROW = {
     "v_pk_add_u16": "pk_add_u16", "v_pk_add_i16": "pk_add_u16", "v_pk_sub_i16": "pk_sub_i16", "v_pk_sub_u16": "pk_sub_i16",
     "v_pk_ashrrev_i16": "pk_ashr_i16", "v_pk_lshlrev_b16": "pk_lshl_b16", "v_pk_lshrrev_b16": "pk_lshl_b16",
     "v_pk_mul_lo_u16": "pk_mul_lo", "v_pk_mad_i16": "pk_mad_i16", "v_pk_mad_u16": "pk_mad_i16",
+    "v_pk_maximum3_f16": "pk_min_i16", "v_pk_max_f16": "pk_min_i16",   # measured at the packed-min rate (tools/ubench/pk_max3_f16.hip)
     "v_perm_b32": "perm_b32", "v_alignbyte_b32": "alignbyte", "v_alignbit_b32": "alignbit",
     "v_min_u32": "min_u32", "v_max_u32": "min_u32", "v_min_i32": "min_i32", "v_max_i32": "max_i32",
     "v_min3_u32": "min3_u32", "v_med3_i32": "med3_i32", "v_med3_u32": "med3_i32",
