@@ -87,9 +87,11 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   if (offload_begin(c, s) != 0)
     return -1;
   /* device scratch: [decoder input | decoded bits]; staging: [jobs | E int16 in] and [pass count | bits] back */
-  const size_t o_l = 0, o_c = align_up((size_t)hc.num_llr, 16), scratch_top = o_c + align_up((size_t)out_bytes_of(hc, 0), 16);
-  const size_t o_seg = 0, o_dec = align_up(sizeof(tb_rx_seg_job), 16), o_iter = o_dec + align_up(sizeof(ldpc_dec_job), 16),
-               jobs_bytes = o_iter + 16, o_in = jobs_bytes, up_bytes = o_in + (size_t)E * 2;
+  /* (the pass count sits right in front of the decoded bits: one copy brings both back) */
+  const size_t o_l = 0, o_iter = align_up((size_t)hc.num_llr, 16), o_c = o_iter + 16,
+               scratch_top = o_c + align_up((size_t)out_bytes_of(hc, 0), 16);
+  const size_t o_seg = 0, o_dec = align_up(sizeof(tb_rx_seg_job), 16), jobs_bytes = o_dec + align_up(sizeof(ldpc_dec_job), 16),
+               o_in = jobs_bytes, up_bytes = o_in + (size_t)E * 2;
   const size_t kbytes = (K + 7) / 8;
   if (c.scratch.ensure(scratch_top) != 0 || c.jobs_h.ensure(up_bytes) != 0 || c.jobs_d.ensure(up_bytes) != 0 ||
       c.small_h.ensure(16 + kbytes) != 0)
@@ -109,7 +111,6 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   dj.iter_idx = 0; dj.abort_idx = -1;
   memcpy(c.jobs_h.p + o_seg, &j, sizeof(j));
   memcpy(c.jobs_h.p + o_dec, &dj, sizeof(dj));
-  memset(c.jobs_h.p + o_iter, 0, 16);
   int16_t *in16 = reinterpret_cast<int16_t *>(c.jobs_h.p + o_in);
   for (uint32_t i = 0; i < E; i++)
     in16[i] = p_llr[i];
@@ -121,7 +122,7 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   memset(&da, 0, sizeof(da));
   da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);
   da.out = reinterpret_cast<int8_t *>(c.scratch.p);
-  da.n_iter = reinterpret_cast<int32_t *>(c.jobs_d.p + o_iter);
+  da.n_iter = reinterpret_cast<int32_t *>(c.scratch.p + o_iter);
   da.out_mode = 0;
   da.use_crc = 0;
   da.jobs = reinterpret_cast<const ldpc_dec_job *>(c.jobs_d.p + o_dec);
@@ -129,8 +130,7 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
     HIP_TRY(ldpc_launch_dec_fast_jobs(da, ce->host_lat.f_n_threads, ce->host_lat.f_lds_total, 1, s));
   else
     HIP_TRY(ldpc_launch_dec_generic_jobs(da, hc.n_threads, hc.lds_total, 1, s));
-  HIP_TRY(hipMemcpyAsync(c.small_h.p, c.jobs_d.p + o_iter, 16, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(c.small_h.p + 16, c.scratch.p + o_c, kbytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(c.small_h.p, c.scratch.p + o_iter, 16 + kbytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   c.pending = false;
   memcpy(p_out, c.small_h.p + 16, kbytes);

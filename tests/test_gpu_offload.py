@@ -103,3 +103,40 @@ def test_offload_slot_rejects_bad_parameters(hip):
         hip.ldpc.offload_decoder(2, 64, 15, np.zeros(601, np.int8), 2, 0, 0, False)     # E not a multiple of Qm
     with pytest.raises(RuntimeError):
         hip.ldpc.offload_encoder(2, 64, np.zeros(80, np.uint8), 4, 600, 2, 0)            # K - F not whole bytes
+
+
+def test_offload_slot_serves_threads_side_by_side(hip):
+    """The T2 library serialises its callers with a global mutex (offload.c:1044, 1097); this one does not need to: four
+    threads, each with its own ULSCH (= its own soft buffers), two HARQ rounds each, results equal to the CPU chain's."""
+    import threading
+    BG, Z, F, Qm, E = 1, 96, 16, 4, 3000
+    K = 22 * Z
+    ncols = {13: 68, 23: 35, 89: 27}
+    cases = []
+    for t in range(4):
+        rng = np.random.default_rng(900 + t)
+        _, info = _segment(rng, BG, Z, F)
+        w = np.zeros(66 * 384, np.int16)
+        llrLen, rounds = 0, []
+        for rnd, rv in enumerate((0, 2)):
+            f = _oracle_tx(BG, Z, info, F, E, Qm, rv)
+            y = np.clip(np.round((1 - 2 * f.astype(np.float64)) * 6 + 5.5 * rng.standard_normal(E)), -128, 127).astype(np.int8)
+            R, llrLen = O.get_R(rv, E, BG, Z, llrLen, rnd)
+            rc, w = O.rate_match_rx(0, BG, Z, w, O.deinterleave(E, Qm, y.astype(np.int16)), 1, rv, 1 if rnd == 0 else 0, E, F, K - F - 2 * Z)
+            it_ref, out_ref = O.decode(BG, Z, R, O.llr_prepack(w, BG, Z, K, F, ncols[R]), max_iter=8)
+            rounds.append((rv, R, y, it_ref, out_ref[:(K + 7) // 8].copy()))
+        cases.append(rounds)
+    bad = []
+
+    def worker(t):
+        for rep in range(20):
+            for rnd, (rv, R, y, it_ref, out_ref) in enumerate(cases[t]):
+                it, out = hip.ldpc.offload_decoder(BG, Z, R, y, Qm, rv, F, setCombIn=rnd > 0, ulsch_id=40 + t, r=t, numMaxIter=8)
+                if it != it_ref or not np.array_equal(out, out_ref):
+                    bad.append((t, rep, rnd, it, it_ref))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad[:5]
