@@ -35,14 +35,16 @@ OffloadHarq &offload_harq()
   return h[cur_dev_index()];
 }
 
-int16_t *offload_soft_buffer(uint8_t ulsch_id, uint8_t r)
+/* `s`: the calling thread's stream.  The zero fill of a new ULSCH's buffers runs there and is waited for under the lock (no
+ * null-stream call: that would wait for every blocking stream of the process, the resident servers' included) */
+int16_t *offload_soft_buffer(uint8_t ulsch_id, uint8_t r, hipStream_t s)
 {
   OffloadHarq &h = offload_harq();
   std::lock_guard<std::mutex> lk(h.mu);
   if (!h.buf[ulsch_id]) {
     void *p = nullptr;
     const size_t bytes = (size_t)OFFLOAD_MAX_SEG * OFFLOAD_HARQ_STRIDE * sizeof(int16_t);
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
       set_error("offload: soft buffer allocation failed");
       return nullptr;
     }
@@ -79,12 +81,12 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   nr_hip_rm_t rm;
   if (nr_hip_rate_match_geometry(0, p->BG, Z, 1, p->F, K, p->rv, E, &rm) != 0) /* n_cb = N: no LBRM on this slot (offload.c:1049) */
     return set_error("offload decoder: invalid rate-matching parameters");
-  int16_t *w = offload_soft_buffer(ulsch_id, r);
-  if (!w)
-    return -1;
   TbCtx &c = tls_tb;
   hipStream_t s;
   if (offload_begin(c, s) != 0)
+    return -1;
+  int16_t *w = offload_soft_buffer(ulsch_id, r, s);
+  if (!w)
     return -1;
   /* device scratch: [decoder input | decoded bits]; staging: [jobs | E int16 in] and [pass count | bits] back */
   /* (the pass count sits right in front of the decoded bits: one copy brings both back) */
