@@ -485,6 +485,44 @@ def test_encode_then_decode_round_trip_rv_and_lbrm(hip):
     assert not ack[1] and itm[1] == 9 and ack[0]
 
 
+def test_largest_transport_block(hip):
+    """The largest NR transport block (38.214: 1 277 992 bits = 152 segments of BG1 Zc = 384, 256QAM, 4 layers) next to
+    the smallest (24 bits) in one call: coded bits, payloads, ACKs, pass counts and soft buffers against the oracle chain,
+    first transmission at rv 0 and a retransmission at rv 3."""
+    rng = np.random.default_rng(1277992)
+    big = dict(A=1277992, G=8 * 4 * 48000, BG=1, Qm=8, Nl=4, rv=0, tbslbrm=0)
+    tiny = dict(A=24, G=2 * 40, BG=2, Qm=2, Nl=1, rv=0, tbslbrm=0)
+    s = O.segmentation(None, O.len_with_crc(1, big["A"]), 1)
+    assert s["C"] == 152 and s["Z"] == 384
+    tbs = [tiny, big]
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    stride = hip.ldpc.HARQ_STRIDE
+    segs = [1, 152]
+    harq_gpu = np.zeros((sum(segs), stride), np.int16)
+    harq_ref = [[np.zeros(stride, np.int16) for _ in range(c)] for c in segs]
+    llrlen = [0, 0]
+    for rnd, rv in enumerate((0, 3)):
+        cur = [dict(t, rv=rv) for t in tbs]
+        coded = hip.ldpc.dlsch_encode_host(cur, pays)
+        for t, p, f in zip(cur, pays, coded):
+            assert np.array_equal(f, O.dlsch_encode(t, p)), (t["A"], rv)
+        llrs = [np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + 5.0 * rng.standard_normal(f.size)), -200, 200).astype(np.int16)
+                for f in coded]
+        rx = [dict(t, round=rnd, llrLen=llrlen[i]) for i, t in enumerate(cur)]
+        out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq_gpu, numMaxIter=8)
+        off = 0
+        for i, t in enumerate(cur):
+            p_ref, ack_ref, its, state = O.ulsch_decode(dict(t), llrs[i], harq_ref[i], 8, rnd, llrlen[i], vec=True)
+            assert bool(ack[i]) == ack_ref and itm[i] == min(max(its), 9) and rx[i]["llrLen"] == state, (t["A"], rnd, its[:4], int(itm[i]))
+            if ack_ref:
+                assert np.array_equal(out[i], p_ref) and np.array_equal(p_ref, pays[i])
+            for r in range(segs[i]):
+                assert np.array_equal(harq_gpu[off + r], harq_ref[i][r]), (t["A"], rnd, r)
+            off += segs[i]
+            llrlen[i] = state
+    assert ack[1]  # the retransmission brings the big block home
+
+
 def test_invalid_parameters(hip):
     with pytest.raises(RuntimeError):
         hip.ldpc.dlsch_encode_host([dict(A=1001, G=4000, BG=1, Qm=2, Nl=1)], [np.zeros(200, np.uint8)])     # A % 8
