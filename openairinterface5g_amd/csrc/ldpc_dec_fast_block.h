@@ -169,7 +169,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   /* ---- passes ------------------------------------------------------------------------------------------ */
   const int max_pass = io.max_pass();
   int n_iter = max_pass;
-  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tickets = code->f_n_bn_tickets;
   int cn_ticket = 0;
 #ifdef LDPC_TIMING
   /* diagnostic build (tools/task_timing.sh): block 0 logs, for pass 2, every task of every wave into its (oversized)
@@ -267,19 +267,37 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       break;
     }
 #ifndef LDPC_ABLATE_BN
-    for (int ticket = bn_ticket; ticket * bn_group < n_bn_tasks; ticket = ldpc_draw(bnq, lane)) {
-      for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
-        LDPC_TLOG_BEGIN();
-        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
-        const int maxdeg = code->f_bn_task[task][2];
-        if (item < end) {
-          const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
+    for (int ticket = bn_ticket; ticket < n_bn_tickets; ticket = ldpc_draw(bnq, lane)) {
+      const int task = code->f_bn_ticket[ticket][0], cnt = code->f_bn_ticket[ticket][1];
+      LDPC_TLOG_BEGIN();
+      const int item0 = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+      const int maxdeg = code->f_bn_task[task][2];
+      if (cnt == 1) {
+        if (item0 < end) {
+          const int sc = (int)ldpc_umulhi((uint32_t)item0, zq_magic), j = item0 - sc * zq;
           const uint32_t colrec = coltbl[sc];
           const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
           ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
         }
-        LDPC_TLOG_END(1, maxdeg);
+      } else {
+        /* short columns: one item of each of the ticket's tasks per thread, walked together (the tasks' item ranges follow
+         * each other, 64 apart) */
+        uint32_t rec[LDPC_F_BN_GROUP], lw[LDPC_F_BN_GROUP];
+        int jj[LDPC_F_BN_GROUP];
+        bool live[LDPC_F_BN_GROUP];
+#pragma unroll
+        for (int g = 0; g < LDPC_F_BN_GROUP; g++) {
+          const int item = item0 + 64 * g;
+          live[g] = g < cnt && item < end;
+          const int it = live[g] ? item : end - 1; /* filler: the last item, a short column's */
+          const int sc = (int)ldpc_umulhi((uint32_t)it, zq_magic);
+          jj[g] = it - sc * zq;
+          rec[g] = coltbl[sc];
+          lw[g] = src32[(int)(rec[g] & 0xffu) * zq + jj[g]];
+        }
+        ldpc_fast_bn_multi<LDPC_F_BN_GROUP>(L, rec, jj, lw, live, maxdeg, Z, astride);
       }
+      LDPC_TLOG_END(1, maxdeg);
     }
 #endif
     cn_ticket = ldpc_draw(&flags[8 + ((p + 1) & 1)], lane);

@@ -567,6 +567,48 @@ LDPC_HD void ldpc_fast_bn(const ldpc_fast_lds &L, uint32_t colrec, int maxdeg, i
   ldpc_fast_bn_finish(L, (int)(colrec & 0xffu), (int)((colrec >> 8) & 0xffu), j, Z, astride, llr_word, acc_e, acc_o, boff_a);
 }
 
+/* G bit-node items of one thread, all of short columns (ldpc_graph.h f_bn_ticket), walked edge by edge TOGETHER: G table
+ * entries, then G windows in flight per step instead of one chain after the other.  md = the ticket's loop bound (every
+ * short column's list is padded at least that far); live[g] = 0: slot g is a filler (some valid item, result dropped). */
+template <int G>
+LDPC_HD void ldpc_fast_bn_multi(const ldpc_fast_lds &L, const uint32_t (&rec)[G], const int (&jj)[G], const uint32_t (&lw)[G],
+                                const bool (&live)[G], int md, int Z, int astride)
+{
+  uint32_t ae[G], ao[G];
+  const uint2 *tbl[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    ae[g] = ao[g] = 0u;
+    tbl[g] = reinterpret_cast<const uint2 *>(L.ctbl) + (int)(rec[g] >> 16);
+  }
+  for (int k = 0; k < md; k++) {
+    uint2 ce[G];
+    uint32_t lo[G], hi[G], ph[G];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      ce[g] = tbl[g][k];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const uint32_t q = 4u * (uint32_t)jj[g] + ce[g].x;
+      const uint32_t p = q < q - (uint32_t)Z ? q : q - (uint32_t)Z;
+      const uint32_t a = ce[g].y + p;
+      lo[g] = ldpc_lds_ld32(L.base, a);
+      hi[g] = ldpc_lds_ld32(L.base, a + 4u);
+      ph[g] = q;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const uint32_t w = ldpc_alignbyte(hi[g], lo[g], ph[g]);
+      ae[g] += w & 0x00ff00ffu;
+      ao[g] += (w >> 8) & 0x00ff00ffu;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++)
+    if (live[g])
+      ldpc_fast_bn_finish(L, (int)(rec[g] & 0xffu), (int)((rec[g] >> 8) & 0xffu), jj[g], Z, astride, lw[g], ae[g], ao[g], 0);
+}
+
 /* hard decision of code bit `b` (< ncore*Z) from the biased APP store */
 LDPC_HD int ldpc_fast_hd(const ldpc_fast_lds &L, int b, int Z, uint32_t zmagic, int astride)
 {

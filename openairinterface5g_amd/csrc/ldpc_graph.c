@@ -114,10 +114,23 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
   /* adjacency lists in sorted-column order, padded (see ldpc_graph.h); the row offsets are filled in below once the
    * LDS layout is known */
   const int span = (63 + zq - 1) / zq; /* how many earlier columns can share a 64-item task with a column */
+  int bn_short = LDPC_F_BN_SHORT, short_max = 0; /* degree of the largest short column (ldpc_graph.h f_bn_ticket) */
+  {
+    const char *e = getenv("NRLDPC_HIP_BN_SHORT"); /* tuning knob: 0 = every bit-node task is a ticket of its own */
+    if (e)
+      bn_short = atoi(e);
+    if (mb > 1 || d->f_sub == 4)
+      bn_short = 0; /* (the several-blocks kernels keep f_bn_group) */
+    for (int i = 0; i < d->ncore; i++)
+      if (cols[i].key <= bn_short && cols[i].key > short_max)
+        short_max = cols[i].key;
+  }
   int n = 0;
   for (int i = 0; i < d->ncore; i++) {
     const int c = cols[i].id;
-    const int padded = cols[i - span > 0 ? i - span : 0].key;
+    int padded = cols[i - span > 0 ? i - span : 0].key;
+    if (cols[i].key <= bn_short && padded < short_max)
+      padded = short_max;
     if (n + padded > LDPC_F_MAX_CTBL)
       return;
     d->f_coltbl[i] = (uint32_t)c | ((uint32_t)cols[i].key << 8) | ((uint32_t)n << 16);
@@ -216,6 +229,27 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
     if (m > 4) m = 4;
     if (m > nb / (2 * waves)) m = nb / (2 * waves);
     d->f_bn_group = m < 1 ? 1 : m;
+  }
+  /* tickets: long tasks alone, short ones grouped so that every wave gets about one group */
+  {
+    int n_short = 0;
+    for (int i = 0; i < nb; i++)
+      n_short += d->f_bn_task[i][2] <= bn_short;
+    int g = waves > 0 ? (n_short + waves - 1) / waves : 1;
+    if (g > LDPC_F_BN_GROUP) g = LDPC_F_BN_GROUP;
+    if (g < 1) g = 1;
+    const char *e = getenv("NRLDPC_HIP_BN_GROUP");
+    if (e && atoi(e) >= 1 && atoi(e) <= LDPC_F_BN_GROUP)
+      g = atoi(e);
+    int nk = 0;
+    for (int i = 0; i < nb;) {
+      const int cnt = d->f_bn_task[i][2] <= bn_short ? (nb - i < g ? nb - i : g) : 1;
+      d->f_bn_ticket[nk][0] = i;
+      d->f_bn_ticket[nk][1] = cnt;
+      nk++;
+      i += cnt;
+    }
+    d->f_n_bn_tickets = nk;
   }
   /* the kernel's waves draw tasks 0, 1, 2, ... from a queue: task ids must already be in descending cost order
    * (rows and columns are sorted by degree, so they are) */

@@ -23,6 +23,8 @@
 #define LDPC_F_DEFAULT_WAVES 16 /* waves per workgroup the fast kernel uses for large codes */
 #define LDPC_F_MAX_CN_TASKS 96
 #define LDPC_F_MAX_BN_TASKS 48
+#define LDPC_F_BN_SHORT 6 /* columns up to this degree count as short */
+#define LDPC_F_BN_GROUP 5 /* short tasks per ticket at most */
 #define LDPC_F_MAX_CTBL 800 /* <= 26 columns x degree 30 when every list is padded to the maximum */
 
 typedef struct ldpc_code_desc {
@@ -92,6 +94,13 @@ typedef struct ldpc_code_desc {
   int32_t f_cn_task[LDPC_F_MAX_CN_TASKS][6];
   /* BN task: {first item, end item (all columns), loop bound = degree of the first item's column} */
   int32_t f_bn_task[LDPC_F_MAX_BN_TASKS][3];
+  /* Bit-node queue tickets (one-block kernels): {first task, tasks}.  A task of high-degree columns is a ticket of its own;
+   * tasks of columns with at most LDPC_F_BN_SHORT edges -- where the fetch chain in front of a task (ticket, task record,
+   * column record, table entry, window) outweighs the few edges -- come up to LDPC_F_BN_GROUP to a ticket, and a thread
+   * walks one item of each of them edge by edge together (ldpc_fast_bn_multi): that many chains in flight instead of one.
+   * The lists of ALL short columns are padded to the degree of the largest short column, so the walk needs no per-item bound. */
+  int32_t f_bn_ticket[LDPC_F_MAX_BN_TASKS][2];
+  int32_t f_n_bn_tickets;
   /* tables the kernel copies into LDS (read per lane): */
   uint32_t f_rowtbl[LDPC_MAX_ROWS + 2];  /* per sorted row: first edge (9 bits) | degree << 9 | has extension column << 14 | pc_lo << 16 */
   uint32_t f_etbl[LDPC_MAX_EDGES + 4];   /* per edge: LDS byte offset of the neighbour's data: core column: f_lds_app + col*astride + shift;

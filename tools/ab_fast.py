@@ -14,7 +14,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-CODES = [(1, 384, 13), (1, 384, 23), (1, 192, 13), (2, 208, 15), (2, 384, 15)]
+CODES = [(1, 384, 13), (1, 384, 23), (1, 384, 89), (1, 192, 13), (2, 208, 15), (2, 384, 15), (2, 384, 23)]
 
 
 def child():
