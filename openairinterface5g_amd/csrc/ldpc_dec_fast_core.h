@@ -550,11 +550,22 @@ LDPC_HD void ldpc_fast_bn_finish(const ldpc_fast_lds &L, int c, int deg, int j, 
   const uint32_t lw = llr_word ^ 0x80808080u;
   acc_e += lw & 0x00ff00ffu;
   acc_o += (lw >> 8) & 0x00ff00ffu;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LDPC_NO_SAT_PK)
+  /* biased APP byte = clamp(app, -128, 127) + 128 = clamp(sum - deg * 128, 0, 255): v_sat_pk_u8_i16 clamps both 16-bit
+   * halves to 0 .. 255 and packs them into two bytes -- one subtract, one pack per register, one v_perm to interleave */
+  const ldpc_v2i bias = ldpc_splat(deg * 128);
+  uint32_t se, so;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(se) : "v"(ldpc_as_u32(ldpc_as_v2i(acc_e) - bias)));
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(so) : "v"(ldpc_as_u32(ldpc_as_v2i(acc_o) - bias)));
+  /* bytes: lane0 = se.b0, lane1 = so.b0, lane2 = se.b1, lane3 = so.b1 */
+  const uint32_t w = ldpc_perm(so, se, 0x05010400u);
+#else
   const ldpc_v2i bias = ldpc_splat((deg + 1) * 128), lo = ldpc_splat(-128), hi = ldpc_splat(127), b128 = ldpc_splat(128);
   const ldpc_v2i ve = ldpc_pmin(ldpc_pmax(ldpc_as_v2i(acc_e) - bias, lo), hi) + b128;
   const ldpc_v2i vo = ldpc_pmin(ldpc_pmax(ldpc_as_v2i(acc_o) - bias, lo), hi) + b128;
   /* bytes: lane0 = ve.lo, lane1 = vo.lo, lane2 = ve.hi, lane3 = vo.hi */
   const uint32_t w = ldpc_perm(ldpc_as_u32(vo), ldpc_as_u32(ve), 0x06020400u);
+#endif
   uint32_t *dst = reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a);
   dst[0] = w;
   *reinterpret_cast<uint32_t *>(L.app + c * astride + u + boff_a + Z) = w;
@@ -574,11 +585,14 @@ template <int G>
 LDPC_HD void ldpc_fast_bn_multi(const ldpc_fast_lds &L, const uint32_t (&rec)[G], const int (&jj)[G], const uint32_t (&lw)[G],
                                 const bool (&live)[G], int md, int Z, int astride)
 {
-  uint32_t ae[G], ao[G];
+  /* sums: ae = bytes 0 and 2 of the windows (mask, add), at = the windows >> 8 whole (shift, add) = S1 + 2^8 S2 + 2^16 S3 with
+   * S_i the sum of byte i over the edges (< 2^13: no overflow); the high half of ae is S2, so the odd lanes' packed sums
+   * S1 + 2^16 S3 = at - (S2 << 8), once per item: four ops per edge instead of five (this path is bound by VALU issue) */
+  uint32_t ae[G], at[G];
   const uint2 *tbl[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    ae[g] = ao[g] = 0u;
+    ae[g] = at[g] = 0u;
     tbl[g] = reinterpret_cast<const uint2 *>(L.ctbl) + (int)(rec[g] >> 16);
   }
   for (int k = 0; k < md; k++) {
@@ -600,13 +614,14 @@ LDPC_HD void ldpc_fast_bn_multi(const ldpc_fast_lds &L, const uint32_t (&rec)[G]
     for (int g = 0; g < G; g++) {
       const uint32_t w = ldpc_alignbyte(hi[g], lo[g], ph[g]);
       ae[g] += w & 0x00ff00ffu;
-      ao[g] += (w >> 8) & 0x00ff00ffu;
+      at[g] += w >> 8;
     }
   }
 #pragma unroll
   for (int g = 0; g < G; g++)
     if (live[g])
-      ldpc_fast_bn_finish(L, (int)(rec[g] & 0xffu), (int)((rec[g] >> 8) & 0xffu), jj[g], Z, astride, lw[g], ae[g], ao[g], 0);
+      ldpc_fast_bn_finish(L, (int)(rec[g] & 0xffu), (int)((rec[g] >> 8) & 0xffu), jj[g], Z, astride, lw[g], ae[g],
+                          at[g] - ((ae[g] >> 16) << 8), 0);
 }
 
 /* hard decision of code bit `b` (< ncore*Z) from the biased APP store */
