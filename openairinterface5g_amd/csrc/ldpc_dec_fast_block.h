@@ -46,6 +46,7 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             tag) is that store (it must leave the caches by itself)
  *   bool tables_resident()    the code's tables are still in this workgroup's LDS from the previous block (resident
  *                             server, same code as last time): the prologue does not copy them again
+ *   static bool bn_tickets    bit-node queue by tickets (f_bn_ticket: short tasks grouped) or by tasks (f_bn_group)
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
  *                             check-node phase when the block has converged); same results, same pass counts */
@@ -169,7 +170,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   /* ---- passes ------------------------------------------------------------------------------------------ */
   const int max_pass = io.max_pass();
   int n_iter = max_pass;
-  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tickets = code->f_n_bn_tickets;
+  const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tickets = code->f_n_bn_tickets, n_bn_tasks = code->f_n_bn_tasks,
+            bn_group = code->f_bn_group;
   int cn_ticket = 0;
 #ifdef LDPC_TIMING
   /* diagnostic build (tools/task_timing.sh): block 0 logs, for pass 2, every task of every wave into its (oversized)
@@ -267,6 +269,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       break;
     }
 #ifndef LDPC_ABLATE_BN
+    if constexpr (IO::bn_tickets) {
     for (int ticket = bn_ticket; ticket < n_bn_tickets; ticket = ldpc_draw(bnq, lane)) {
       const int task = code->f_bn_ticket[ticket][0], cnt = code->f_bn_ticket[ticket][1];
       LDPC_TLOG_BEGIN();
@@ -298,6 +301,22 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         ldpc_fast_bn_multi<LDPC_F_BN_GROUP>(L, rec, jj, lw, live, maxdeg, Z, astride);
       }
       LDPC_TLOG_END(1, maxdeg);
+    }
+    } else {
+    for (int ticket = bn_ticket; ticket * bn_group < n_bn_tasks; ticket = ldpc_draw(bnq, lane)) {
+      for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
+        LDPC_TLOG_BEGIN();
+        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+        const int maxdeg = code->f_bn_task[task][2];
+        if (item < end) {
+          const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
+          const uint32_t colrec = coltbl[sc];
+          const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
+          ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+        }
+        LDPC_TLOG_END(1, maxdeg);
+      }
+    }
     }
 #endif
     cn_ticket = ldpc_draw(&flags[8 + ((p + 1) & 1)], lane);
