@@ -84,6 +84,23 @@ def test_introspection_without_gpu(built):
     assert b"gfx950" in L.nrLDPC_hip_version()
 
 
+def test_every_code_with_zc_multiple_of_four_keeps_its_fast_descriptor(built):
+    """The fast kernel's descriptor builder gives up silently (-> generic kernel) when a table does not fit; no (BG, Zc, R)
+    with Zc % 4 == 0, Zc >= 8 may do that (column lists are padded for the interleaved bit-node walk, ldpc_graph.h)."""
+    import openairinterface5g_amd as pkg
+    sizes = [a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384]
+    assert len(sizes) == 51
+    n = 0
+    for BG, rates in ((1, (13, 23, 89)), (2, (15, 13, 23))):
+        for Z in sizes:
+            for R in rates:
+                info = pkg.ldpc.code_info(BG, Z, R)
+                if Z % 4 == 0 and Z >= 8:
+                    n += 1
+                    assert info["kernel"] == "fast", (BG, Z, R, info)
+    assert n == 210
+
+
 def test_struct_layouts_match_the_c_header(built, tmp_path):
     """ctypes mirrors (used by every Python-side test) vs the compiler's view of include/nrLDPC_hip.h."""
     import openairinterface5g_amd as pkg
