@@ -81,6 +81,20 @@ for regime, snr in (("fixed_work", -12.0), ("operating_point", 1.0)):
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_replay_ms"] = dtg * 1e3
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_coded_gbps"] = bits / dtg / 1e9
 
+# ---- the decoder's rate modes (nr_get_R_ldpc_decoder picks them from the code rate): BG1 Zc=384, 1024 blocks per launch ----
+for (BG, Z, R, label) in ((1, 384, 13, "r13"), (1, 384, 23, "r23"), (1, 384, 89, "r89"), (2, 384, 15, "bg2_r15"), (2, 384, 13, "bg2_r13"),
+                          (2, 384, 23, "bg2_r23")):
+    entry = {}
+    for regime, snr in (("fixed_work", -12.0), ("operating_point", {13: 1.0, 15: 1.0, 23: 4.5, 89: 7.5}[R] if BG == 1 else {15: 0.0, 13: 1.5, 23: 5.0}[R])):
+        _, llr = noisy_llr(BG, Z, R, 1024, snr, 11 * R + BG)
+        out = torch.zeros((1024, m.out_bytes(BG, Z, R)), dtype=torch.uint8, device="cuda")
+        it = torch.zeros(1024, dtype=torch.int32, device="cuda")
+        dt = timeit(lambda: pkg.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8), 50)
+        ntx = (m.NCOLS[(BG, R)] - 2) * Z
+        entry[regime] = {"ms": dt * 1e3, "received_gbps": 1024 * ntx / dt / 1e9, "mean_passes": float(it.float().mean().item()),
+                         "bler": float((it > 8).float().mean().item()), "snr_db": snr}
+    res[f"rate_mode_bg{BG}_z384_{label}"] = entry
+progress('rate modes done')
 progress('config3 done')
 # ---- config 2 through HOST buffers (PCIe-inclusive): pinned staging inside the library, 1024 blocks per call ---------
 _, llr_c2 = noisy_llr(1, 384, 13, 1024, 1.0, 5)
