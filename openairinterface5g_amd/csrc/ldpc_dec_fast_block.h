@@ -46,6 +46,7 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             tag) is that store (it must leave the caches by itself)
  *   bool tables_resident()    the code's tables are still in this workgroup's LDS from the previous block (resident
  *                             server, same code as last time): the prologue does not copy them again
+ *   static bool syndrome      false: the launch stops on the CRC only, the parity of the hard decisions is not computed
  *   static bool bn_tickets    bit-node queue by tickets (f_bn_ticket: short tasks grouped) or by tasks (f_bn_group)
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
@@ -232,7 +233,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
           m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
                      : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-        syn |= m & mask;
+        if constexpr (IO::syndrome)
+          syn |= m & mask;
+        else
+          (void)m, (void)mask;
       }
       LDPC_TLOG_END(0, deg);
     }
@@ -241,9 +245,11 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     {
       /* flags[p & 1] = how many lanes saw an unsatisfied check of the previous pass (0 = none: the stop criterion; the
        * count itself only steers the eager check below) */
-      const unsigned long long bad_lanes = __ballot(syn != 0);
-      if (bad_lanes && lane == 0)
-        atomicAdd(&flags[p & 1], (int)__popcll(bad_lanes));
+      if constexpr (IO::syndrome) {
+        const unsigned long long bad_lanes = __ballot(syn != 0);
+        if (bad_lanes && lane == 0)
+          atomicAdd(&flags[p & 1], (int)__popcll(bad_lanes));
+      }
     }
     if (tid == 0) {
       flags[2] = 0;

@@ -15,7 +15,10 @@
 
 /* a block of a batch launch: addressed by strides (homogeneous batch) or by its job record; everything is read from
  * the kernel arguments / the job record where it is needed (scalar loads), see ldpc_dec_fast_block.h */
-template <bool JOBS> struct ldpc_batch_io {
+/* CRC = the launch is known to stop on the CRC (the transport-block chain's job launches): the parity of the hard decisions,
+ * which only the parity-check stop looks at, is then not computed at all -- an XOR per edge and a dozen ops per item of the
+ * check-node bodies fall away as dead code */
+template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
   const ldpc_dec_args &a;
   ldpc_job_ptr_t job; /* nullptr without JOBS: known at compile time, so the selects below fold away */
   __device__ __forceinline__ const uint32_t *src32() const
@@ -24,7 +27,8 @@ template <bool JOBS> struct ldpc_batch_io {
   }
   __device__ __forceinline__ int8_t *out() const { return a.out + (job ? (size_t)job->out_off : (size_t)blockIdx.x * a.out_stride); }
   __device__ __forceinline__ int max_pass() const { return (job ? job->num_max_iter : a.num_max_iter) + 1; }
-  __device__ __forceinline__ int use_crc() const { return a.use_crc; }
+  __device__ __forceinline__ int use_crc() const { return CRC ? 1 : a.use_crc; }
+  static constexpr bool syndrome = !CRC;
   __device__ __forceinline__ int crcE() const { return job ? job->E : a.E; }
   __device__ __forceinline__ const uint32_t *crc_pow() const { return job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow; }
   __device__ __forceinline__ int out_mode() const { return a.out_mode; }
@@ -54,7 +58,7 @@ template <bool JOBS> struct ldpc_batch_io {
  * waves per CU: the throughput shapes put k workgroups of w <= 16 / k waves on a CU and count on all 16 wave slots
  * (a variant compiled for <= 768 threads may take 129+ VGPRs and silently drop the CU to 12 waves: measured 180 -> 262 us
  * on the 1664-segment slot). */
-template <bool JOBS>
+template <bool JOBS, bool CRC = false>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
    * so everything derived from them stays in SGPRs */
   const ldpc_job_ptr_t job = JOBS ? (ldpc_job_ptr_t)a.jobs + blockIdx.x : (ldpc_job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
-  const ldpc_batch_io<JOBS> io{a, job};
+  const ldpc_batch_io<JOBS, CRC> io{a, job};
   const int n_iter = ldpc_dec_fast_block(fsm, code, io);
   if (threadIdx.x == 0)
     a.n_iter[job ? (uint32_t)job->iter_idx : blockIdx.x] = n_iter;
@@ -159,12 +163,13 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[7] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+  const void *k[8] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4>)};
-  for (int i = 0; i < 7; i++) {
+  for (int i = 0; i < 8; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -227,6 +232,9 @@ hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int 
 {
   if (n_blocks == 0)
     return hipSuccess;
-  hipLaunchKernelGGL((ldpc_dec_fast_kernel<true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+  if (a.use_crc) /* (the chain's launches) */
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, false>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   return hipGetLastError();
 }

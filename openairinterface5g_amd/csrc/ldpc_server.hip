@@ -101,6 +101,7 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   /* one block per CU with as many waves as tasks: grouping short bit-node tasks buys nothing here, and the plain loop is
    * 3 % faster on the large codes (profiles/r03/README.md) */
   static constexpr bool bn_tickets = false;
+  static constexpr bool syndrome = true;
   __device__ __forceinline__ bool tables_resident() const { return resident_; }
   __device__ __forceinline__ uint32_t out_tag() const { return tag_; }
   __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { srv_st16_sys(p, x, y, z, t); }
