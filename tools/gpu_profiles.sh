@@ -50,6 +50,7 @@ echo "== sims"; timeout 300 python tests/ulschsim_hip.py -R 106 -m 9 -s 13 -n 10
 echo "== bench --gpus 1 under torch.distributed (RCCL path)"; BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 20 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err; tail -c 600 $O/bench_dist1.json
 echo "== per-call breakdown"; timeout 120 python tools/srv_breakdown.py 3000 2>&1 | tail -1 | tee $O/srv_breakdown.txt; timeout 120 python tools/srv_breakdown.py 3000 1 384 13 -12 2>&1 | tail -1 | tee -a $O/srv_breakdown.txt
 echo "== abi"
+gcc -O2 -I include tests/abi_threads.c -o tests/abi_threads.bin -ldl -lpthread   # (binaries are not tracked)
 run() { echo "$1 T=$2 case=${4:-mix}: $(env $1 timeout 60 ./tests/abi_threads.bin $L $2 ${3:-400} $4 2>&1 | tail -1 | cut -c1-330)"; }
 { run X=1 1 3000 1; run X=1 1 2000 0; run NRLDPC_HIP_SRV_BAR=0 1 3000 1; run NRLDPC_HIP_SERVER=0 1 1000 1
   for T in 1 4 16 32 64; do run X=1 $T 1000; done
