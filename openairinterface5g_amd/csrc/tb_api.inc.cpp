@@ -670,7 +670,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     ack = c.io_small.p + (size_t)ntb * 4;
   }
   HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, pl.rx_lds_elems, llr, harq,
-                               reinterpret_cast<int8_t *>(c.scratch.p), s));
+                               reinterpret_cast<int8_t *>(c.scratch.p), s, n_seg <= (size_t)G().n_cus));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));
   da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);

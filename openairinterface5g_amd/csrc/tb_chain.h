@@ -83,7 +83,7 @@ __host__ __device__ static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t 
   return ((span < Ncb ? span : Ncb) + 8u + 7u) & ~7u; /* + 8: the span starts up to 7 slots into its first aligned word */
 }
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
-                                int8_t *scratch, hipStream_t s);
+                                int8_t *scratch, hipStream_t s, int wide = 0);
 /* reassembly per segment (payload copy + partial TB CRC into acc[tb], zero on entry and on exit), then per-TB verdict */
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,

@@ -594,7 +594,7 @@ __device__ __forceinline__ void tb_rx_scatter_laps(const int16_t *__restrict__ f
   }
 }
 
-__global__ void __launch_bounds__(TB_THREADS) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
+__global__ void __launch_bounds__(1024) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
                                                                    int16_t *harq, int8_t *scratch)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t e_lds[];
@@ -786,11 +786,14 @@ hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejo
   return hipGetLastError();
 }
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
-                                int8_t *scratch, hipStream_t s)
+                                int8_t *scratch, hipStream_t s, int wide)
 {
   if (n == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(tb_rx_dematch_kernel, dim3(n), dim3(TB_THREADS), (size_t)lds_elems * sizeof(int16_t), s, jobs, llr, harq, scratch);
+  /* wide: a launch that gives every segment a CU of its own (one transport block: 13 -> 5 us) takes 1024 threads per
+   * workgroup -- a segment's time is then the latency of its strided loops, not the GPU's throughput */
+  hipLaunchKernelGGL(tb_rx_dematch_kernel, dim3(n), dim3(wide ? 1024 : TB_THREADS), (size_t)lds_elems * sizeof(int16_t), s, jobs, llr, harq,
+                     scratch);
   return hipGetLastError();
 }
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,

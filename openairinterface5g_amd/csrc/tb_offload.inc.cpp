@@ -119,7 +119,7 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   if (tb_upload_jobs(c, c.jobs_d.p, up_bytes, s) != 0)
     return -1;
   HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(c.jobs_d.p + o_seg), 1, tb_rx_lds_elems(E, rm.Fin, rm.Ncb),
-                               reinterpret_cast<const int16_t *>(c.jobs_d.p + o_in), w, reinterpret_cast<int8_t *>(c.scratch.p), s));
+                               reinterpret_cast<const int16_t *>(c.jobs_d.p + o_in), w, reinterpret_cast<int8_t *>(c.scratch.p), s, 1));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));
   da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);
