@@ -163,13 +163,13 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[8] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>),
+  const void *k[9] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1>),
                       reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4>)};
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < 9; i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -183,7 +183,10 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     return hipSuccess;
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
-  hipLaunchKernelGGL((ldpc_dec_fast_kernel<false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  if (a.use_crc) /* CRC stop: the instantiation without the parity of the hard decisions */
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  else
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 
