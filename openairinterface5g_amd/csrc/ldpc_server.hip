@@ -66,7 +66,9 @@ template <typename T> __device__ __forceinline__ T *srv_sgpr(T *p)
   return reinterpret_cast<T *>(((uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)LDPC_UNIFORM((uint32_t)v));
 }
 
-struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_dec_fast_block.h) */
+/* CRC = the request stops on the CRC (what the reference's per-segment callers ask for, nr_ulsch_decoding.c:219): the block
+ * body is instantiated without the parity of the hard decisions (ldpc_dec_fast_block.h `syndrome`) */
+template <bool CRC> struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_dec_fast_block.h) */
   const srv_req *rq;
   const uint8_t *host_llr;  /* the slot's input area in host memory: read once, by the prologue */
   const uint8_t *staged;    /* device copy of the core columns, written by the prologue, re-read every pass */
@@ -81,7 +83,7 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   __device__ __forceinline__ uint32_t *stage_core() const { return reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(staged)); }
   __device__ __forceinline__ int8_t *out() const { return reinterpret_cast<int8_t *>(hout); }
   __device__ __forceinline__ int max_pass() const { return LDPC_UNIFORM((int)rq->max_pass); }
-  __device__ __forceinline__ int use_crc() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 16) & 0xffu)); }
+  __device__ __forceinline__ int use_crc() const { return CRC ? 1 : 0; }
   __device__ __forceinline__ int crcE() const { return LDPC_UNIFORM((int)rq->crcE); }
   __device__ __forceinline__ const uint32_t *crc_pow() const { return a->crc_pow_tbl[LDPC_UNIFORM(rq->kind_mode >> 24) & 3u]; }
   __device__ __forceinline__ int out_mode() const { return LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu)); }
@@ -101,7 +103,7 @@ struct srv_fast_io { /* the request header sits in LDS: read where needed (ldpc_
   /* one block per CU with as many waves as tasks: grouping short bit-node tasks buys nothing here, and the plain loop is
    * 3 % faster on the large codes (profiles/r03/README.md) */
   static constexpr bool bn_tickets = false;
-  static constexpr bool syndrome = true;
+  static constexpr bool syndrome = !CRC;
   __device__ __forceinline__ bool tables_resident() const { return resident_; }
   __device__ __forceinline__ uint32_t out_tag() const { return tag_; }
   __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { srv_st16_sys(p, x, y, z, t); }
@@ -202,8 +204,14 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
       const uint8_t *staged = srv_sgpr(a->staging + (size_t)blockIdx.x * SRV_IN_STRIDE);
       /* bc[20], bc[21]: the code whose tables this workgroup's LDS holds (0: none) */
       const bool resident = bc[20] == LDPC_UNIFORM(rq->code_lo) && bc[21] == LDPC_UNIFORM(rq->code_hi);
-      const srv_fast_io io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d, srv_sgpr(a->abort_w + 16u * SRV_SLOT())};
-      n_iter = ldpc_dec_fast_block(fsm, code, io);
+      const uint32_t *abw = srv_sgpr(a->abort_w + 16u * SRV_SLOT());
+      if (LDPC_UNIFORM((int)((rq->kind_mode >> 16) & 0xffu))) {
+        const srv_fast_io<true> io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d, abw};
+        n_iter = ldpc_dec_fast_block(fsm, code, io);
+      } else {
+        const srv_fast_io<false> io{rq, host_in, staged, hout, a, bc + 24, tid_l, resident, d, abw};
+        n_iter = ldpc_dec_fast_block(fsm, code, io);
+      }
       if (threadIdx.x == 0) {
         bc[20] = rq->code_lo;
         bc[21] = rq->code_hi;

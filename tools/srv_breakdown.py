@@ -3,7 +3,7 @@
 N calls from one thread; the library's own stamps (nrLDPC_hip_server_stats) split the host call into
 GPU doorbell-seen -> LLRs staged in LDS, staged -> decoded + result written, and what is left on the host side.
 
-  python tools/srv_breakdown.py [calls] [BG Z R snr_dB]
+  python tools/srv_breakdown.py [calls] [BG Z R snr_dB [crc]]      crc: CRC stop mode (the check fails on random bits: all passes run)
 """
 import sys
 import time
@@ -29,7 +29,8 @@ coded = O.encode(BG, Z, info)
 llr = np.zeros(m.num_llr(BG, Z, R) + 64, np.int8)
 l = O.awgn_llr(rng, coded, Z, snr)
 llr[:min(l.size, m.num_llr(BG, Z, R))] = l[:m.num_llr(BG, Z, R)]
-p = pkg.make_dec_params(BG, Z, R, 8)
+crc = len(sys.argv) > 6 and sys.argv[6] == "crc"
+p = pkg.make_dec_params(BG, Z, R, 8, check_crc=crc, E=K if crc else 0)
 out = np.zeros(m.out_bytes(BG, Z, R) + 64, np.uint8)
 call, keep = m.raw_decoder_call(p)
 for _ in range(200):
@@ -42,6 +43,6 @@ t = (time.perf_counter() - t0) / n
 s1 = m.server_stats()
 d = {k: (s1[k] - s0[k]) for k in s1}
 c = max(d["calls"], 1)
-print({"code": (BG, Z, R), "passes": it, "calls": d["calls"], "us_per_call_python": round(t * 1e6, 2),
+print({"code": (BG, Z, R), "crc_mode": crc, "passes": it, "calls": d["calls"], "us_per_call_python": round(t * 1e6, 2),
        "host_call_us": round(d["host_call_ns"] / c / 1e3, 2), "host_wait_us": round(d["host_wait_ns"] / c / 1e3, 2),
        "gpu_stage_us": round(d["gpu_stage_ns"] / c / 1e3, 2), "gpu_decode_us": round(d["gpu_decode_ns"] / c / 1e3, 2)})
