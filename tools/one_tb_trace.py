@@ -1,3 +1,5 @@
+"""One transport block (26 segments) through the UL-SCH and DL-SCH calls, 30 times, every call awaited: the workload for a
+rocprofv3 --kernel-trace of the single-block latency (tools/gpu_one_tb_trace.sh)."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import torch
@@ -17,5 +19,7 @@ llr = ((1.0 - 2.0 * coded.float()) * 10 + 1.8 * torch.randn(coded.numel(), devic
 harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
 pay_out = torch.zeros_like(payload); ack = torch.zeros(1, dtype=torch.uint8, device="cuda"); itm = torch.zeros(1, dtype=torch.int32, device="cuda")
 dec = m.PreparedTbBatch(tbs, pay_out, llr, harq, ack, itm)
+enc = m.PreparedTbBatch(tbs, payload, coded)
 for _ in range(30):
     dec.decode(); torch.cuda.synchronize()
+    enc.encode(); torch.cuda.synchronize()
