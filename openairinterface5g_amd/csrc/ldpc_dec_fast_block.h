@@ -222,16 +222,26 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         const int rig = (int)ldpc_umulhi((uint32_t)gi, zq_magic), j = gi - rig * zq;
         const uint32_t rowrec = rowtbl[srow0 + rig];
         const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j; /* lanes t+i < pc_lo are checked */
-        /* pass 1: the messages are all 0 and are not read (nor initialised by the prologue) */
-        uint32_t m;
+        /* pass 1: the messages are all 0 and are not read (nor initialised by the prologue); what its check-node phase
+         * returns -- the parity of the CHANNEL's hard decisions -- is looked at by nobody (stops are decided from pass 3
+         * on, the eager check from pass 2 on), so it is not accumulated and the bodies drop it as dead code */
+        uint32_t m = 0;
         (void)half;
+        if (p == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (pair)
-          m = p == 1 ? ldpc_fast_cn19_pair<true>(L, e0, j, Z, rstride, half) : ldpc_fast_cn19_pair<false>(L, e0, j, Z, rstride, half);
-        else
+          if (pair)
+            (void)ldpc_fast_cn19_pair<true>(L, e0, j, Z, rstride, half);
+          else
 #endif
-          m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
-                     : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
+            (void)ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride);
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (pair)
+            m = ldpc_fast_cn19_pair<false>(L, e0, j, Z, rstride, half);
+          else
+#endif
+            m = ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
+        }
         const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
         if constexpr (IO::syndrome)
           syn |= m & mask;
