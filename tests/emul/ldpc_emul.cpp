@@ -249,15 +249,34 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
       n_iter = p - 1;
       break;
     }
-    for (int task = 0; task < code->f_n_bn_tasks; task++) {
+    /* the kernel's bit-node queue: tickets (ldpc_graph.h f_bn_ticket) -- a long task on its own, short ones several to a
+     * ticket and walked together, one item of each per thread (ldpc_fast_bn_multi) */
+    for (int ticket = 0; ticket < code->f_n_bn_tickets; ticket++) {
+      const int task = code->f_bn_ticket[ticket][0], cnt = code->f_bn_ticket[ticket][1];
       for (int lane = 0; lane < 64; lane++) {
-        const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
+        const int item0 = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
         const int maxdeg = code->f_bn_task[task][2];
-        if (item < end) {
-          const int sc = (int)ldpc_umulhi((uint32_t)item, zq_magic), j = item - sc * zq;
-          const uint32_t colrec = coltbl[sc];
-          const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
-          ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+        if (cnt == 1) {
+          if (item0 < end) {
+            const int sc = (int)ldpc_umulhi((uint32_t)item0, zq_magic), j = item0 - sc * zq;
+            const uint32_t colrec = coltbl[sc];
+            const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
+            ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+          }
+        } else {
+          uint32_t rec[LDPC_F_BN_GROUP], lw[LDPC_F_BN_GROUP];
+          int jj[LDPC_F_BN_GROUP];
+          bool live[LDPC_F_BN_GROUP];
+          for (int g = 0; g < LDPC_F_BN_GROUP; g++) {
+            const int item = item0 + 64 * g;
+            live[g] = g < cnt && item < end;
+            const int it = live[g] ? item : end - 1;
+            const int sc = (int)ldpc_umulhi((uint32_t)it, zq_magic);
+            jj[g] = it - sc * zq;
+            rec[g] = coltbl[sc];
+            lw[g] = src32[(int)(rec[g] & 0xffu) * zq + jj[g]];
+          }
+          ldpc_fast_bn_multi<LDPC_F_BN_GROUP>(L, rec, jj, lw, live, maxdeg, Z, astride);
         }
       }
     }
