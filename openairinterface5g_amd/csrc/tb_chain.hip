@@ -594,7 +594,7 @@ __device__ __forceinline__ void tb_rx_scatter_laps(const int16_t *__restrict__ f
   }
 }
 
-__global__ void __launch_bounds__(1024) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
                                                                    int16_t *harq, int8_t *scratch)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t e_lds[];
