@@ -141,6 +141,18 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
  * =================================================================================================== */
 #define NRLDPC_HIP_MEM_HOST 0   /* pointers are host memory: staged through pinned buffers, call is synchronous */
 #define NRLDPC_HIP_MEM_DEVICE 1 /* pointers are device memory on the library's GPU: call only enqueues on `stream` */
+/* nrLDPC_hip_ulsch_decode only, OR-ed into `mem`: where the HARQ soft buffers d[r] live, independently of the other buffers.
+ * The reference keeps them per HARQ process for the life of the process (NR_TRANSPORT/nr_ulsch_decoding.c:168,
+ * harq_process->d[r]) while the LLRs of a slot arrive in host memory (nr_ulsch_decoding(..., short *ulsch_llr, ...), :320):
+ * with NRLDPC_HIP_MEM_HOST | NRLDPC_HIP_MEM_HARQ_DEVICE or ..._HARQ_LIBRARY a call moves the slot's LLRs over the link once
+ * and nothing else -- the soft buffers never leave the GPU. */
+#define NRLDPC_HIP_MEM_HARQ_DEVICE 2  /* b->harq is device memory (hipMalloc) on the library's GPU whatever bit 0 says */
+#define NRLDPC_HIP_MEM_HARQ_LIBRARY 4 /* b->harq is ignored: the library keeps the soft buffers in GPU memory of its own, one
+                                       * set of C x harq_stride int16 per transport block, found by tb[i].harq_off used as an
+                                       * opaque 64-bit id chosen by the caller (e.g. ulsch_id << 8 | harq_pid -- the way the T2
+                                       * card is addressed, nrLDPC_decoder_offload.c:546-547).  Allocated on first use, kept until
+                                       * nrLDPC_hip_harq_release(); with several GPUs the buffers live on the GPU that decodes
+                                       * the block (and follow it if a later round is given to another one). */
 
 typedef struct nrLDPC_hip_dec_batch {
   t_nrLDPC_dec_params params; /* shared by every block of the batch (homogeneous batch = one launch) */
@@ -206,15 +218,31 @@ typedef struct nrLDPC_hip_tb_batch {
   nrLDPC_hip_tb_t *tb;     /* host array [n_tb] (llrLen is updated by the decode call) */
   uint8_t *payload;        /* encode: in, decode: out */
   void *coded;             /* encode: uint8_t* out; decode: const int16_t* in */
-  int16_t *harq;           /* decode: soft buffers (device memory when mem = DEVICE) */
+  int16_t *harq;           /* decode: soft buffers (device memory when mem = DEVICE or mem & HARQ_DEVICE; unused with HARQ_LIBRARY) */
   uint32_t harq_stride;    /* int16 per code block, >= 66*384 */
   uint8_t *ack;            /* decode out [n_tb]: 1 = every segment decoded and the TB CRC holds */
   int32_t *iter_max;       /* decode out [n_tb]: largest per-segment pass count */
-  int32_t mem;             /* NRLDPC_HIP_MEM_*: payload / coded / harq / ack / iter_max alike */
+  int32_t mem;             /* NRLDPC_HIP_MEM_HOST or _DEVICE: payload / coded / harq / ack / iter_max alike; decode: optionally
+                            * | NRLDPC_HIP_MEM_HARQ_DEVICE or | NRLDPC_HIP_MEM_HARQ_LIBRARY for the soft buffers.  HOST: `coded`
+                            * in page-locked memory (nrLDPC_hip_host_alloc / nrLDPC_hip_host_register / hipHostMalloc) is read by
+                            * the GPU in place -- the segments' workgroups pull their LLRs over the link while others decode --,
+                            * pageable memory goes through a staged copy first */
   void *stream;            /* DEVICE mem: enqueue only (except the small per-call job upload) */
 } nrLDPC_hip_tb_batch_t;
 int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b);
 int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b);
+/* Soft buffers kept by the library (NRLDPC_HIP_MEM_HARQ_LIBRARY).  release: forget one transport block's buffers (its HARQ
+ * process ended) / all of them; read: copy int16 values [first, first + n) of a block's C x harq_stride soft values to host
+ * memory (diagnostics and tests; waits for the GPU).  0, or -1 (unknown id, range outside the buffers). */
+int32_t nrLDPC_hip_harq_release(uint64_t id);
+int32_t nrLDPC_hip_harq_release_all(void);
+int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t n);
+/* Page-locked host memory for callers that do not link the HIP runtime themselves (a C gNB): LLR arrays placed here are
+ * read by the GPU in place.  alloc returns NULL on failure; register / unregister pin an existing allocation (0 / -1). */
+void *nrLDPC_hip_host_alloc(uint64_t bytes);
+void nrLDPC_hip_host_free(void *p);
+int32_t nrLDPC_hip_host_register(void *p, uint64_t bytes);
+int32_t nrLDPC_hip_host_unregister(void *p);
 /* ---------------------------------------------------------------------------------------------------
  * The reference's OFFLOAD plugin slot (`ldpc_interface_offload`, loaded with the suffix "_t2": nr_init.c:138-139).  Same
  * signatures as LDPCdecoder / LDPCencoder, the semantics of nrLDPC_decoder/nrLDPC_decoder_offload.c:1036-1140: one

@@ -181,6 +181,7 @@ int ensure_ready_locked()
       return set_error("NRLDPC_HIP_DEVICE(S) out of range");
   HIP_TRY(ldpc_kernels_init());
   HIP_TRY(ldpc_fast_kernel_init());
+  HIP_TRY(tb_rx_fused_init());
   for (int i = 0; i < n; i++)
     if (device_init_locked(g.dev[i], list[i]) != 0)
       return -1;
@@ -531,10 +532,24 @@ void meter_stop(time_stats_t *ts)
 }
 } // namespace
 
+namespace {
+/* LDPCinit's body, also behind the offload slot's init (tb_offload.inc.cpp): internal, so that neither entry point depends
+ * on which LDPCinit the dynamic linker binds */
+int32_t lib_init()
+{
+  if (ensure_ready() != 0)
+    return -1;
+  /* the resident servers' mailboxes and buffers (tens of milliseconds of allocations) are set up here, not inside the
+   * first LDPCdecoder / LDPCencoder call; the kernels themselves start with the first call and leave when idle */
+  (void)srv_ready(srv);
+  return 0;
+}
+} // namespace
+
 extern "C" {
 
 const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
-const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.3 (gfx950)"; }
+const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.4 (gfx950)"; }
 
 /* Optional hook of the reference's module loader (common/utils/load_module_shlib.c:174-185: "<modname>_checkbuildver",
  * modname = "ldpc" whatever the version suffix of the file name, nrLDPC_load.c:48,62): called right after
@@ -545,7 +560,7 @@ const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.3 (gfx950)"; }
  * tests/test_abi.py -- an executable of another revision may have moved them). */
 int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
 {
-  static char version[] = "libldpc_hip 0.3 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
+  static char version[] = "libldpc_hip 0.4 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
   if (shlib_buildversion)
     *shlib_buildversion = version;
   const char *need = getenv("NRLDPC_HIP_REQUIRE_BUILD");
@@ -616,15 +631,7 @@ int32_t nrLDPC_hip_server_stats(int64_t out[8])
   return 0;
 }
 
-int32_t LDPCinit(void)
-{
-  if (ensure_ready() != 0)
-    return -1;
-  /* the resident servers' mailboxes and buffers (tens of milliseconds of allocations) are set up here, not inside the
-   * first LDPCdecoder / LDPCencoder call; the kernels themselves start with the first call and leave when idle */
-  (void)srv_ready(srv);
-  return 0;
-}
+int32_t LDPCinit(void) { return lib_init(); }
 
 int32_t LDPCshutdown(void)
 {

@@ -48,6 +48,10 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             server, same code as last time): the prologue does not copy them again
  *   static bool syndrome      false: the launch stops on the CRC only, the parity of the hard decisions is not computed
  *   static bool bn_tickets    bit-node queue by tickets (f_bn_ticket: short tasks grouped) or by tasks (f_bn_group)
+ *   static bool tb_epilogue   the caller may end a block with the transport-block chain's epilogue (tb_rx_fused.hip):
+ *   bool tb_fused()           ... and does so for this block: instead of an output row, io.tb_finish(n_iter, bits_word,
+ *                             flags) delivers the segment's payload bytes, its share of the TB CRC and -- from the last
+ *                             segment of a transport block to finish -- the block's verdict
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
  *                             check-node phase when the block has converged); same results, same pass counts */
@@ -196,6 +200,11 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
     const uint32_t ab_word = (io.has_abort() && tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
+    /* likewise the transport block's flag (a load that leaves the caches: its latency would otherwise sit between the
+     * check-node phase and the barrier, once per pass) */
+    int tb_ab = 0;
+    if (io.has_abort() && tid == 0 && p >= 2 && io.tb_abort())
+      tb_ab = __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int *cnq = &flags[8 + (p & 1)], *bnq = &flags[10 + (p & 1)]; /* this pass' task queues */
     (void)cnq;
 #ifdef LDPC_ABLATE_CN
@@ -266,7 +275,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       flags[8 + ((p + 1) & 1)] = 0; /* the next pass' queues: last drawn from before the previous pass' barriers, */
       flags[10 + ((p + 1) & 1)] = 0; /* first drawn from behind the barrier below */
       /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
-      if (io.tb_abort() && p >= 2 && __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      if (tb_ab)
         flags[3] = 1;
       if (p >= 2 && io.abort_is(ab_word))
         flags[3] = 1;
@@ -410,30 +419,36 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   if (blockIdx.x == 0)
     return n_iter; /* (its output row holds the log) */
 #endif
-  if ((!io.use_crc() || n_iter >= 3) && n_iter <= max_pass) {
-    /* output dword w: packed bits 32w .. 32w+31 MSB first (bnProc.h:1353-1380), resp. bits 4w .. 4w+3 one per byte */
-    auto bits_word = [&](int w) -> uint32_t {
-      uint32_t word = 0;
+  /* output dword w: packed bits 32w .. 32w+31 MSB first (bnProc.h:1353-1380), resp. bits 4w .. 4w+3 one per byte */
+  auto bits_word = [&](int w) -> uint32_t {
+    uint32_t word = 0;
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
-        if (b < ncz) {
-          const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
-          const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
-          const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
-          word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
-        }
+    for (int q = 0; q < 8; q++) {
+      const int b = 32 * w + 4 * q; /* Z % 4 == 0: the four bits lie in one column */
+      if (b < ncz) {
+        const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+        const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+        const uint32_t nib = (((nb >> 7) & 1u) << 3) | (((nb >> 15) & 1u) << 2) | (((nb >> 23) & 1u) << 1) | (nb >> 31);
+        word |= nib << (8 * (q >> 1) + ((q & 1) ? 0 : 4));
       }
-      return word;
-    };
-    auto bytes_word = [&](int w) -> uint32_t {
-      const int b = 4 * w;
-      if (b >= ncz)
-        return 0u;
-      const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
-      const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
-      return (nb >> 7) & 0x01010101u;
-    };
+    }
+    return word;
+  };
+  auto bytes_word = [&](int w) -> uint32_t {
+    const int b = 4 * w;
+    if (b >= ncz)
+      return 0u;
+    const int c = (int)ldpc_umulhi((uint32_t)b, z_magic), u = b - c * Z;
+    const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u);
+    return (nb >> 7) & 0x01010101u;
+  };
+  if constexpr (IO::tb_epilogue) {
+    if (io.tb_fused()) {
+      io.tb_finish(n_iter, bits_word, flags);
+      return n_iter;
+    }
+  }
+  if ((!io.use_crc() || n_iter >= 3) && n_iter <= max_pass) {
     const uint32_t tag = io.out_tag();
     const int nwords = io.out_mode() == 0 ? (num_llr + 31) >> 5 : num_llr >> 2;
     if (tag) {

@@ -42,6 +42,7 @@ template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
    * stops saves the next pass' check-node phase; one that does not converge never gets close and pays nothing) */
   __device__ __forceinline__ bool eager_check() const { return !JOBS; }
   static constexpr bool bn_tickets = true; /* short bit-node tasks come several to a ticket (ldpc_graph.h f_bn_ticket) */
+  static constexpr bool tb_epilogue = false; /* (the chain's fused segment kernel has an IO of its own: tb_rx_fused.hip) */
   __device__ __forceinline__ bool tables_resident() const { return false; }
   __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
   __device__ __forceinline__ uint32_t abort_load() const { return 0u; }

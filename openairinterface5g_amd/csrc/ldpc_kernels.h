@@ -19,7 +19,8 @@ struct ldpc_dec_job {
   int32_t crc_type;             /* CRC mode: index into ldpc_dec_args.crc_pow_tbl */
   int32_t iter_idx;             /* where in ldpc_dec_args.n_iter this block reports */
   int32_t abort_idx;            /* index into ldpc_dec_args.tb_abort of the block's transport block, -1: none */
-  int32_t pad;
+  int32_t seg_idx;              /* fused segment kernel (tb_rx_fused.hip): index of the segment's tb_rx_seg_job -- the workgroup
+                                   de-matches the segment first and ends with the chain's epilogue; -1: a plain decoder job */
 };
 /* several jobs of ONE small code, the same iteration cap and the same CRC in one workgroup (ldpc_dec_fast_mblock.h): the
  * transport-block chain groups a batch's small segments this way; the jobs of a group are consecutive in the job array */

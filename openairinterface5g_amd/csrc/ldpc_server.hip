@@ -103,6 +103,7 @@ template <bool CRC> struct srv_fast_io { /* the request header sits in LDS: read
   /* one block per CU with as many waves as tasks: grouping short bit-node tasks buys nothing here, and the plain loop is
    * 3 % faster on the large codes (profiles/r03/README.md) */
   static constexpr bool bn_tickets = false;
+  static constexpr bool tb_epilogue = false;
   static constexpr bool syndrome = !CRC;
   __device__ __forceinline__ bool tables_resident() const { return resident_; }
   __device__ __forceinline__ uint32_t out_tag() const { return tag_; }

@@ -51,12 +51,6 @@ struct TbPlan {
   size_t ext[6] = {0, 0, 0, 0, 0, 0}; /* [lo, hi) of the payload, coded and harq ranges the blocks touch */
   uint32_t rx_lds_elems = 8; /* LDS the de-matching kernel needs per workgroup (int16 slots) */
   bool out_dense = true; /* the blocks' outputs tile their range: one copy back; else one per block (nothing between them is touched) */
-  /* decode, host buffers: the blocks' soft buffers tile [ext[4], ext[5]) -- one copy each way; otherwise (gaps between
-   * them, a sharded batch whose offsets are not monotonic, another thread's blocks in between) one copy per block each
-   * way, so that a call never writes back soft values it does not own.  (First transmissions are uploaded
-   * too: the kernel clears Ncb values per segment, what lies behind them in the caller's array must come back unchanged.) */
-  bool harq_dense = true;
-  std::vector<size_t> harq_span; /* per block: {first int16, int16 count} */
   size_t off[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int threads[4] = {64, 64, 64, 64}, lds[4] = {0, 0, 0, 0};
   size_t n_fast = 0, n_gen = 0; /* encode */
@@ -64,33 +58,73 @@ struct TbPlan {
    * its jobs, so a batch that mixes code sizes is cut into launches by how many workgroups of a job's shape a CU holds
    * (1, 2, 4, 8, 16+): a Zc = 8 segment does not occupy the LDS of a Zc = 384 one.  kind 0: fast kernel, 1: generic
    * kernel, 2 / 3: several small segments per workgroup (f_sub = 1 / 4; grp_off = their ldpc_dec_mgroup array) */
-  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; };
+  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; };
   std::vector<DecLaunch> dec;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
-  /* the descriptors tb[0 .. n_tb) of a call (one device's share of the batch) */
-  bool matches(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, uint32_t salt) const
+  /* decode: segments / transport blocks that go through the separate de-matching, reassembly and verdict kernels (the others
+   * are served from LLRs to payload by the fused segment kernel, tb_rx_fused.hip); legacy_off = their copy of the segment jobs */
+  size_t n_legacy_seg = 0, n_legacy_tb = 0, legacy_off = 0;
+  bool any_fused = false;
+  /* decode, host-resident soft buffers: runs of rows of the caller's array (first int16, rows, int16 per row that the kernels
+   * look at, uploaded before the call?) -- a first transmission is cleared on the device and never uploaded; what lies behind
+   * a row's Ncb values in the caller's array is never touched */
+  struct HarqRun { size_t first; uint32_t rows, width; bool upload; };
+  std::vector<HarqRun> harq_runs;
+  uint64_t stamp = 0; /* LRU */
+  /* the descriptors tb[0 .. n_tb) of a call (one device's share of the batch); salt = whatever else the plan depends on */
+  bool matches(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, const uint64_t salt[3]) const
   {
     const size_t n = (size_t)n_tb * sizeof(nrLDPC_hip_tb_t);
-    return valid && key.size() == n + 8 && memcmp(key.data(), &n_tb, 4) == 0 && memcmp(key.data() + 4, &salt, 4) == 0 &&
-           memcmp(key.data() + 8, tb, n) == 0;
+    return valid && key.size() == n + 32 && memcmp(key.data(), &n_tb, 4) == 0 && memcmp(key.data() + 8, salt, 24) == 0 &&
+           memcmp(key.data() + 32, tb, n) == 0;
   }
-  void remember(const void *tb_bytes, uint32_t n_tb, uint32_t salt)
+  void remember(const void *tb_bytes, uint32_t n_tb, const uint64_t salt[3])
   {
     const size_t n = (size_t)n_tb * sizeof(nrLDPC_hip_tb_t);
-    key.resize(n + 8);
+    key.assign(n + 32, 0);
     memcpy(key.data(), &n_tb, 4);
-    memcpy(key.data() + 4, &salt, 4);
-    memcpy(key.data() + 8, tb_bytes, n);
+    memcpy(key.data() + 8, salt, 24);
+    memcpy(key.data() + 32, tb_bytes, n);
     valid = true;
   }
 };
 
+/* A thread's plans of one direction: a handful, least recently used one replaced -- a caller that alternates between a few
+ * allocations (parallel.ShardedUlsch sends a slot as three chunks per rank; a scheduler's DL / UL patterns) finds each of
+ * them again instead of rebuilding the one plan every call. */
+#define TB_PLAN_SLOTS 8
+struct TbPlanCache {
+  TbPlan slot[TB_PLAN_SLOTS];
+  uint64_t clock = 0;
+  TbPlan *find(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, const uint64_t salt[3])
+  {
+    for (TbPlan &p : slot)
+      if (p.matches(tb, n_tb, salt)) {
+        p.stamp = ++clock;
+        return &p;
+      }
+    return nullptr;
+  }
+  TbPlan &victim() /* an unused slot, else the least recently used one; the caller rebuilds it */
+  {
+    TbPlan *v = &slot[0];
+    for (TbPlan &p : slot) {
+      if (!p.valid) { v = &p; break; }
+      if (p.stamp < v->stamp) v = &p;
+    }
+    v->valid = false;
+    v->stamp = ++clock;
+    return *v;
+  }
+};
+
 struct TbCtx {
-  TbPlan tx, rx;
-  DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small;
+  TbPlanCache tx, rx;
+  DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small, trace_d;
   PinBuf jobs_h, small_h;
   hipStream_t own = nullptr, last = nullptr;
   hipEvent_t uploaded = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr; /* device-resident batches cut over several GPUs (tb_run_sharded) */
   bool pending = false;
   void drain() /* nothing of this thread's stays in flight (error paths, thread exit) */
   {
@@ -113,14 +147,15 @@ struct Arena { /* bump allocator over the scratch buffer, 16-byte granules */
 };
 
 /* on the current device (UseDevice) */
-int tb_begin(const nrLDPC_hip_tb_batch_t *b, hipStream_t &s)
+/* staged: the part works on copies of the caller's buffers, on this thread's own stream; else in place on s_direct */
+int tb_begin(hipStream_t &s, hipStream_t s_direct, bool staged)
 {
   TbCtx &c = tls_tb;
   if (!c.own) {
     HIP_TRY(hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c.uploaded, hipEventDisableTiming));
   }
-  s = b->mem == NRLDPC_HIP_MEM_DEVICE ? static_cast<hipStream_t>(b->stream) : c.own;
+  s = staged ? c.own : s_direct;
   if (c.last && c.last != s) { /* scratch is reused: calls on different streams are serialised */
     HIP_TRY(hipStreamSynchronize(c.last));
   }
@@ -158,6 +193,14 @@ bool tb_classes_enabled()
 int tb_multi_mode()
 {
   const char *e = getenv("NRLDPC_HIP_TB_MULTI");
+  return e ? atoi(e) : 1;
+}
+
+/* NRLDPC_HIP_TB_FUSED=0: de-matching, decoding, reassembly and verdict as four launches (the round-3 path, kept as the
+ * cross-check); default: one fused segment kernel wherever the fast decoder serves the segment (tb_rx_fused.hip) */
+int tb_fused_mode()
+{
+  const char *e = getenv("NRLDPC_HIP_TB_FUSED");
   return e ? atoi(e) : 1;
 }
 
@@ -226,21 +269,23 @@ struct TbExtent {
 };
 
 /* ---- TX: transport blocks [tb0, tb0+ntb) of b on the current device -------------------------------------------------
- * host buffers: the device works on copies of exactly the byte ranges its blocks touch (job offsets stay the caller's:
- * the device pointers are biased by the range start); enqueue only, tb_tx_finish() copies back and waits */
-int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
+ * staged (host buffers, or another GPU's memory -- a device-resident batch cut over several GPUs): the device works on copies
+ * of exactly the byte ranges its blocks touch (job offsets stay the caller's: the device pointers are biased by the range
+ * start); enqueue only, tb_tx_finish() waits for the copies back to the host */
+int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bool staged, hipStream_t s_direct)
 {
   hipStream_t s;
-  if (tb_begin(b, s) != 0)
+  if (tb_begin(s, s_direct, staged) != 0)
     return -1;
   if (ntb == 0)
     return 0;
   const nrLDPC_hip_tb_t *tbs = b->tb + tb0;
   TbCtx &c = tls_tb;
-  TbPlan &pl = c.tx;
   const bool fused = ldpc_enc_is_packed() != 0;
-  if (!pl.matches(tbs, ntb, fused ? 1u : 0u)) {
-    pl.valid = false;
+  const uint64_t salt[3] = {fused ? 1u : 0u, 0, 0};
+  TbPlan *hit = c.tx.find(tbs, ntb, salt);
+  TbPlan &pl = hit ? *hit : c.tx.victim();
+  if (!hit) {
     std::vector<tb_tx_tb_job> tbj(ntb);
     std::vector<tb_tx_seg_job> sj;
     std::vector<ldpc_enc_job> ej;
@@ -329,7 +374,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     pl.out_dense = ex.cod_sum == ex.cod_hi - ex.cod_lo;
     pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_enc; pl.off[3] = o_chk; pl.off[4] = o_acc;
     pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
-    pl.remember(tbs, ntb, fused ? 1u : 0u);
+    pl.remember(tbs, ntb, salt);
   }
   if (c.scratch.ensure(pl.scratch_top + 16) != 0) /* (+16: the fused kernel reads whole dwords around a segment's bytes) */
     return -1;
@@ -338,11 +383,11 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   const int enc_threads = pl.threads[0], enc_lds = pl.lds[0];
   const uint8_t *payload = b->payload;
   uint8_t *coded = static_cast<uint8_t *>(b->coded);
-  if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
+  if (staged) {
     const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
     if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload + pay_lo, pay_n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload + pay_lo, pay_n, hipMemcpyDefault, s));
     payload = c.io_payload.p - pay_lo;
     coded = c.io_coded.p - cod_lo;
   }
@@ -368,13 +413,13 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     HIP_TRY(ldpc_launch_enc_jobs(ea, enc_threads, enc_lds, (uint32_t)n_seg, s));
     HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
   }
-  if (b->mem != NRLDPC_HIP_MEM_DEVICE) {
+  if (staged) {
     uint8_t *hc = static_cast<uint8_t *>(b->coded);
     if (pl.out_dense) {
-      HIP_TRY(hipMemcpyAsync(hc + pl.ext[2], c.io_coded.p, pl.ext[3] - pl.ext[2], hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(hc + pl.ext[2], c.io_coded.p, pl.ext[3] - pl.ext[2], hipMemcpyDefault, s));
     } else {
       for (uint32_t i = 0; i < ntb; i++)
-        HIP_TRY(hipMemcpyAsync(hc + tbs[i].coded_off, c.io_coded.p + (tbs[i].coded_off - pl.ext[2]), tbs[i].G, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hc + tbs[i].coded_off, c.io_coded.p + (tbs[i].coded_off - pl.ext[2]), tbs[i].G, hipMemcpyDefault, s));
     }
   }
   return 0;
@@ -382,36 +427,121 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
 
 int tb_tx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t ntb)
 {
-  if (b->mem == NRLDPC_HIP_MEM_DEVICE || ntb == 0)
+  if ((b->mem & NRLDPC_HIP_MEM_DEVICE) || ntb == 0)
     return 0;
   HIP_TRY(hipStreamSynchronize(tls_tb.own));
   return 0;
 }
 
-/* ---- RX: transport blocks [tb0, tb0+ntb) of b on the current device ---------------------------------------------------- */
-int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
+/* ---- soft buffers kept by the library (NRLDPC_HIP_MEM_HARQ_LIBRARY) -------------------------------------------------------
+ * id -> {logical device, device pointer, int16 count}.  Buffers that are released go to a per-device pool and are handed out
+ * again (hipFree would wait for every stream of the device, the resident server kernels' included).  `gen` changes whenever
+ * an id's address does: the plans that hold absolute addresses are keyed on it. */
+struct HarqEntry { int dev; int16_t *p; size_t n; };
+struct HarqTable {
+  std::mutex mu;
+  std::map<uint64_t, HarqEntry> m;
+  std::vector<HarqEntry> pool;
+  std::atomic<uint64_t> gen{1};
+} harq_tbl;
+
+/* the soft buffers of block `id` on the current device, n int16; `fresh`: the call clears them before use (first
+ * transmission).  A block that arrives with round > 0 and no history combines with zeros; one whose buffers live on another
+ * GPU (the partition moved it) takes its history along.  Stream-ordered on s. */
+int16_t *harq_lookup(uint64_t id, size_t n, bool fresh, hipStream_t s)
+{
+  const int di = cur_dev_index();
+  std::lock_guard<std::mutex> lk(harq_tbl.mu);
+  auto it = harq_tbl.m.find(id);
+  if (it != harq_tbl.m.end() && it->second.dev == di && it->second.n >= n)
+    return it->second.p;
+  HarqEntry e{di, nullptr, n};
+  for (size_t k = 0; k < harq_tbl.pool.size(); k++)
+    if (harq_tbl.pool[k].dev == di && harq_tbl.pool[k].n >= n && harq_tbl.pool[k].n <= 2 * n) {
+      e = harq_tbl.pool[k];
+      harq_tbl.pool.erase(harq_tbl.pool.begin() + (long)k);
+      break;
+    }
+  if (!e.p && hipMalloc(reinterpret_cast<void **>(&e.p), n * sizeof(int16_t)) != hipSuccess) {
+    set_error("soft buffer allocation");
+    return nullptr;
+  }
+  hipError_t err = hipSuccess;
+  if (it != harq_tbl.m.end()) {
+    if (!fresh) {
+      const size_t keep = std::min(n, it->second.n);
+      err = hipMemcpyAsync(e.p, it->second.p, keep * sizeof(int16_t), hipMemcpyDefault, s);
+      if (err == hipSuccess && keep < n)
+        err = hipMemsetAsync(e.p + keep, 0, (n - keep) * sizeof(int16_t), s);
+      if (err == hipSuccess)
+        err = hipStreamSynchronize(s); /* the old buffers go back to the pool below */
+    }
+    harq_tbl.pool.push_back(it->second);
+  } else if (!fresh) {
+    err = hipMemsetAsync(e.p, 0, n * sizeof(int16_t), s);
+  }
+  if (err != hipSuccess) {
+    harq_tbl.pool.push_back(e);
+    set_error("soft buffer set-up", err);
+    return nullptr;
+  }
+  harq_tbl.m[id] = e;
+  harq_tbl.gen.fetch_add(1);
+  return e.p;
+}
+
+/* ---- RX: transport blocks [tb0, tb0+ntb) of b on the current device ----------------------------------------------------
+ * staged = the caller's buffers are not this device's memory (host buffers; or, for a device-resident batch cut over
+ * several GPUs, the owning GPU's memory): the device works on copies of exactly the ranges its blocks touch.  Two things are
+ * never staged: LLRs in page-locked host memory (the segments' workgroups read them over the link in place) and soft
+ * buffers that already live here (NRLDPC_HIP_MEM_HARQ_DEVICE on this GPU, NRLDPC_HIP_MEM_HARQ_LIBRARY). */
+int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bool staged, hipStream_t s_direct)
 {
   hipStream_t s;
-  if (tb_begin(b, s) != 0)
+  if (tb_begin(s, s_direct, staged) != 0)
     return -1;
   if (ntb == 0)
     return 0;
   nrLDPC_hip_tb_t *tbs = b->tb + tb0;
   TbCtx &c = tls_tb;
-  TbPlan &pl = c.rx;
-  if (pl.matches(tbs, ntb, (uint32_t)b->harq_stride)) {
+  const bool harq_lib = (b->mem & NRLDPC_HIP_MEM_HARQ_LIBRARY) != 0;
+  /* soft buffers usable in place: the caller's device memory on THIS GPU */
+  bool harq_here = false;
+  if (!harq_lib && (!staged || (b->mem & (NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_DEVICE)))) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, b->harq) == hipSuccess && at.type == hipMemoryTypeDevice)
+      harq_here = at.device == G().id;
+    else
+      (void)hipGetLastError();
+    if (!staged && !harq_here)
+      return set_error("soft buffers must be memory of the GPU that holds the LLRs");
+    /* test hook: logical devices that alias one GPU (the GPU box has one) treat the owner's soft buffers as a peer's */
+    static const bool stage_env = [] { const char *e = getenv("NRLDPC_HIP_TEST_STAGE_HARQ"); return e && atoi(e) != 0; }();
+    if (staged && stage_env)
+      harq_here = false;
+    if ((b->mem & NRLDPC_HIP_MEM_HARQ_DEVICE) && !(b->mem & NRLDPC_HIP_MEM_DEVICE) && !harq_here && g.n_shard == 1)
+      return set_error("NRLDPC_HIP_MEM_HARQ_DEVICE: harq is not device memory of the library's GPU");
+  }
+  const bool harq_staged = !harq_lib && !harq_here;
+  const int fused_mode = tb_fused_mode();
+  uint64_t salt[3] = {(uint64_t)b->harq_stride | ((uint64_t)(harq_lib ? 2 : (harq_staged ? 1 : 0)) << 32),
+                            (uint64_t)(fused_mode & 0xff) | ((uint64_t)(tb_multi_mode() & 0xff) << 8) | ((uint64_t)tb_classes_enabled() << 16),
+                            harq_lib ? harq_tbl.gen.load() : 0};
+  TbPlan *hit = c.rx.find(tbs, ntb, salt);
+  if (hit) {
     for (uint32_t i = 0; i < ntb; i++) /* nr_get_R_ldpc_decoder's state leaves the call as it did the first time */
-      tbs[i].llrLen = pl.llr_len[i];
-  } else {
-    pl.valid = false;
+      tbs[i].llrLen = hit->llr_len[i];
+  }
+  TbPlan &pl = hit ? *hit : c.rx.victim();
+  if (!hit) {
     std::vector<uint8_t> key_tb((const uint8_t *)tbs, (const uint8_t *)tbs + (size_t)ntb * sizeof(nrLDPC_hip_tb_t));
     std::vector<tb_rx_tb_job> tbj(ntb);
-    std::vector<tb_rx_seg_job> sj;
+    std::vector<tb_rx_seg_job> sj, sj_legacy;
     struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; };
     std::vector<ShapedJob> single; /* segments that get a workgroup of their own */
     Arena ar;
     TbExtent ex;
-    std::vector<size_t> harq_span;
+    std::vector<TbPlan::HarqRun> runs;
     uint32_t rx_lds_elems = 8;
     /* decoder workgroup shape (ldpc_graph.h): a batch that does not even give every CU one segment wants the latency shape */
     uint32_t n_seg_total = 0;
@@ -425,11 +555,11 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     const int multi_mode = tb_multi_mode();
     const bool multi_ok = multi_mode != 0 && n_seg_total >= 2u * (uint32_t)G().n_cus;
     const bool classes = tb_classes_enabled() && !lat_shape;
-    auto add_single = [&](const CodeEntry *ce, const ldpc_dec_job &dj) {
+    auto add_single = [&](const CodeEntry *ce, const ldpc_dec_job &dj, uint32_t fused_lds) {
       const ldpc_code_desc_t &hc = ce->host, &shape = lat_shape ? ce->host_lat : ce->host;
       const double cost = (double)hc.num_llr * dj.num_max_iter;
       if (hc.f_ok)
-        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, shape.f_lds_total, cost});
+        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, std::max(shape.f_lds_total, (int)fused_lds), cost});
       else
         single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost});
     };
@@ -438,6 +568,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     std::vector<ldpc_dec_job> mjobs[2];
     std::vector<ldpc_dec_mgroup> mgrp[2];
     int m_threads[2] = {64, 64}, m_lds[2] = {0, 0};
+    size_t n_legacy_tb = 0;
+    bool any_fused = false;
     for (uint32_t i = 0; i < ntb; i++) {
       nrLDPC_hip_tb_t &t = tbs[i];
       if (tb_validate(t) != 0)
@@ -450,12 +582,26 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       const CodeEntry *full = get_code(t.BG, (int)sg.Zc, t.BG == 1 ? 13 : 15);
       if (!full)
         return -1;
+      /* the block's soft buffers: the caller's array (offset in int16), or the library's (absolute address / 2: the kernels
+       * then get a null base) */
+      uint64_t harq_base = t.harq_off;
+      if (harq_lib) {
+        const int16_t *hp = harq_lookup(t.harq_off, (size_t)sg.C * b->harq_stride, t.round == 0, s);
+        if (!hp)
+          return -1;
+        harq_base = (uint64_t)(reinterpret_cast<uintptr_t>(hp) / sizeof(int16_t));
+      }
+      /* every segment of the block through the fused segment kernel?  (the fast decoder serves the code, and the block's
+       * segments are not candidates for shared workgroups) */
+      bool fused_tb = fused_mode != 0 && full->host.f_ok && !(multi_ok && full->dev_multi);
       const uint32_t cstride = (uint32_t)align_up(out_bytes_of(full->host, 0), 16);
       tb_rx_tb_job &tj = tbj[i];
       memset(&tj, 0, sizeof(tj));
       tj.payload_off = t.payload_off;
-      tj.b_off = ar.take(B / 8 + 4);
-      tj.c_off0 = ar.take((size_t)cstride * sg.C);
+      if (!fused_tb) {
+        tj.b_off = ar.take(B / 8 + 4);
+        tj.c_off0 = ar.take((size_t)cstride * sg.C);
+      }
       tj.c_stride = cstride;
       tj.seg0 = (uint32_t)sj.size();
       tj.C = sg.C;
@@ -464,13 +610,14 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       tj.crc_type = (uint32_t)nr_hip_crc_type(1, (int)t.A);
       tj.num_max_iter = t.numMaxIter;
       tj.seg_bytes = sg.K / 8 - sg.F / 8 - (sg.C > 1 ? 3 : 0); /* phy_procedures_nr_gNB.c:287 */
+      tj.fused = fused_tb ? 1u : 0u;
+      any_fused |= fused_tb;
+      n_legacy_tb += fused_tb ? 0 : 1;
       ex.add(ex.pay_lo, ex.pay_hi, (size_t)t.payload_off, (size_t)t.payload_off + t.A / 8);
       ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
-      ex.add(ex.harq_lo, ex.harq_hi, (size_t)t.harq_off, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
+      if (!harq_lib)
+        ex.add(ex.harq_lo, ex.harq_hi, (size_t)t.harq_off, (size_t)t.harq_off + (size_t)sg.C * b->harq_stride);
       ex.pay_sum += t.A / 8;
-      ex.harq_sum += (size_t)sg.C * b->harq_stride;
-      harq_span.push_back((size_t)t.harq_off);
-      harq_span.push_back((size_t)sg.C * b->harq_stride);
       uint32_t r_offset = 0;
       int llrLen = t.llrLen;
       for (uint32_t r = 0; r < sg.C; r++) {
@@ -487,14 +634,26 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         tb_rx_seg_job j;
         memset(&j, 0, sizeof(j));
         j.llr_off = t.coded_off + r_offset;
-        j.harq_off = t.harq_off + (uint64_t)r * b->harq_stride;
+        j.harq_off = harq_base + (uint64_t)r * b->harq_stride;
         j.l_off = ar.take(hc.num_llr);
         j.E = E; j.Qm = t.Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
         j.clear = t.round == 0; /* harq_to_be_cleared -> d_to_be_cleared[r] (nr_ulsch_decoding.c:418-422) */
         j.K = sg.K; j.F = sg.F; j.Z = sg.Zc; j.num_llr = (uint32_t)hc.num_llr;
         j.c_off = tj.c_off0 + (uint64_t)r * cstride;
-        rx_lds_elems = std::max(rx_lds_elems, tb_rx_lds_elems(E, rm.Fin, rm.Ncb));
+        const uint32_t lds_elems = tb_rx_lds_elems(E, rm.Fin, rm.Ncb);
+        if (!fused_tb)
+          rx_lds_elems = std::max(rx_lds_elems, lds_elems);
         j.tb = i; j.r = r; j.iter_idx = (uint32_t)sj.size();
+        if (harq_staged) { /* rows of the caller's array that travel: what the kernels look at of this segment's row */
+          const uint32_t np = (uint32_t)hc.num_llr > 2 * sg.Zc ? (uint32_t)hc.num_llr - 2 * sg.Zc : 0u;
+          const uint32_t width = std::min<uint32_t>(std::max(rm.Ncb, np), b->harq_stride);
+          const size_t first = (size_t)t.harq_off + (size_t)r * b->harq_stride;
+          if (!runs.empty() && runs.back().width == width && runs.back().upload == (t.round != 0) &&
+              runs.back().first + (size_t)runs.back().rows * b->harq_stride == first)
+            runs.back().rows++;
+          else
+            runs.push_back(TbPlan::HarqRun{first, 1u, width, t.round != 0});
+        }
         ldpc_dec_job dj;
         dj.code = (hc.f_ok && lat_shape) ? ce->dev_lat : ce->dev;
         dj.llr_off = j.l_off;
@@ -504,14 +663,18 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
         dj.iter_idx = (int32_t)sj.size();
         dj.abort_idx = tb_abort_enabled() ? (int32_t)i : -1;
-        dj.pad = 0;
+        dj.seg_idx = fused_tb ? (int32_t)sj.size() : -1;
         if (dj.E > hc.kb_full * hc.Z || (dj.E & 7))
           return set_error("CRC length outside the code block");
-        if (multi_ok && ce->dev_multi) /* candidates for a shared workgroup; sorted into groups below */
+        if (fused_tb && !hc.f_ok)
+          return set_error("internal: fused block with a segment outside the fast decoder");
+        if (!fused_tb && multi_ok && ce->dev_multi) /* candidates for a shared workgroup; sorted into groups below */
           cands.push_back(MultiCand{ce, dj});
         else
-          add_single(ce, dj);
+          add_single(ce, dj, fused_tb ? lds_elems * (uint32_t)sizeof(int16_t) : 0u);
         sj.push_back(j);
+        if (!fused_tb)
+          sj_legacy.push_back(j);
         r_offset += E;
       }
       t.llrLen = llrLen;
@@ -520,7 +683,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
      * f_mb * f_sub segments each; smaller groups go back to one workgroup per segment */
     if (multi_mode != 2 && cands.size() < (size_t)TB_MULTI_MIN_PER_CU * (size_t)G().n_cus) { /* they all fit side by side as they are */
       for (const MultiCand &q : cands)
-        add_single(q.ce, q.dj);
+        add_single(q.ce, q.dj, 0u);
       cands.clear();
     }
     std::stable_sort(cands.begin(), cands.end(), [](const MultiCand &x, const MultiCand &y) {
@@ -554,7 +717,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         m_lds[cls] = std::max(m_lds[cls], hm.f_lds_total);
       } else {
         for (size_t q = i0; q < i1; q++)
-          add_single(ce, cands[q].dj);
+          add_single(ce, cands[q].dj, 0u);
       }
       i0 = i1;
     }
@@ -574,22 +737,25 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     for (size_t q = 0; q < single.size(); q++) {
       single_jobs[q] = single[q].dj;
       if (q == 0 || wg_class(single[q]) != wg_class(single[q - 1]) || single[q].kind != single[q - 1].kind)
-        dec.push_back(TbPlan::DecLaunch{single[q].kind, q * sizeof(ldpc_dec_job), 0, 0, 64, 0});
+        dec.push_back(TbPlan::DecLaunch{single[q].kind, q * sizeof(ldpc_dec_job), 0, 0, 64, 0, false});
       TbPlan::DecLaunch &dl = dec.back();
       dl.n++;
       dl.threads = std::max(dl.threads, single[q].threads);
       dl.lds = std::max(dl.lds, single[q].lds);
+      dl.fused |= single[q].dj.seg_idx >= 0;
     }
     const size_t n_seg = sj.size();
     const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
-                 o_single = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
+                 o_leg = o_seg + align_up(n_seg * sizeof(tb_rx_seg_job), 16),
+                 o_single = o_leg + align_up(sj_legacy.size() * sizeof(tb_rx_seg_job), 16),
                  o_mj0 = o_single + align_up(single_jobs.size() * sizeof(ldpc_dec_job), 16),
                  o_mg0 = o_mj0 + align_up(mjobs[0].size() * sizeof(ldpc_dec_job), 16),
                  o_mj1 = o_mg0 + align_up(mgrp[0].size() * sizeof(ldpc_dec_mgroup), 16),
                  o_mg1 = o_mj1 + align_up(mjobs[1].size() * sizeof(ldpc_dec_job), 16),
-                 o_acc = o_mg1 + align_up(mgrp[1].size() * sizeof(ldpc_dec_mgroup), 16), /* CRC accumulators, then the per-TB
-                                                                                            abort flags: uploaded as zeros */
-                 jobs_bytes = o_acc + align_up((size_t)ntb * 2 * sizeof(uint32_t), 16),
+                 o_acc = o_mg1 + align_up(mgrp[1].size() * sizeof(ldpc_dec_mgroup), 16), /* per TB: CRC accumulators, abort
+                                                                                            flags, finished-segment counters:
+                                                                                            uploaded as zeros, left zero */
+                 jobs_bytes = o_acc + align_up((size_t)ntb * 3 * sizeof(uint32_t), 16),
                  o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
     if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
         pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
@@ -597,6 +763,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
     memcpy(c.jobs_h.p + o_tb, tbj.data(), tbj.size() * sizeof(tb_rx_tb_job));
     memcpy(c.jobs_h.p + o_seg, sj.data(), n_seg * sizeof(tb_rx_seg_job));
+    memcpy(c.jobs_h.p + o_leg, sj_legacy.data(), sj_legacy.size() * sizeof(tb_rx_seg_job));
     memcpy(c.jobs_h.p + o_single, single_jobs.data(), single_jobs.size() * sizeof(ldpc_dec_job));
     memcpy(c.jobs_h.p + o_mj0, mjobs[0].data(), mjobs[0].size() * sizeof(ldpc_dec_job));
     memcpy(c.jobs_h.p + o_mg0, mgrp[0].data(), mgrp[0].size() * sizeof(ldpc_dec_mgroup));
@@ -611,6 +778,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
         dec[k - 1].n += dec[k].n;
         dec[k - 1].threads = std::max(dec[k - 1].threads, dec[k].threads);
         dec[k - 1].lds = std::max(dec[k - 1].lds, dec[k].lds);
+        dec[k - 1].fused |= dec[k].fused;
         dec.erase(dec.begin() + (long)k);
       } else {
         k++;
@@ -619,22 +787,25 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     for (TbPlan::DecLaunch &dl : dec)
       dl.jobs_off += o_single;
     if (!mgrp[0].empty())
-      dec.push_back(TbPlan::DecLaunch{2, o_mj0, o_mg0, (uint32_t)mgrp[0].size(), m_threads[0], m_lds[0]});
+      dec.push_back(TbPlan::DecLaunch{2, o_mj0, o_mg0, (uint32_t)mgrp[0].size(), m_threads[0], m_lds[0], false});
     if (!mgrp[1].empty())
-      dec.push_back(TbPlan::DecLaunch{3, o_mj1, o_mg1, (uint32_t)mgrp[1].size(), m_threads[1], m_lds[1]});
+      dec.push_back(TbPlan::DecLaunch{3, o_mj1, o_mg1, (uint32_t)mgrp[1].size(), m_threads[1], m_lds[1], false});
     pl.dec.swap(dec);
     pl.n_seg = n_seg; pl.scratch_top = ar.top;
-    pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi; pl.ext[4] = ex.harq_lo; pl.ext[5] = ex.harq_hi;
+    pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi;
+    pl.ext[4] = harq_lib ? 0 : ex.harq_lo; pl.ext[5] = harq_lib ? 0 : ex.harq_hi;
     pl.out_dense = ex.pay_sum == ex.pay_hi - ex.pay_lo;
-    pl.harq_dense = ex.harq_sum == ex.harq_hi - ex.harq_lo;
-    pl.harq_span.swap(harq_span);
+    pl.harq_runs.swap(runs);
     pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[4] = o_iter; pl.off[5] = o_acc;
+    pl.legacy_off = o_leg; pl.n_legacy_seg = sj_legacy.size(); pl.n_legacy_tb = n_legacy_tb; pl.any_fused = any_fused;
     pl.rx_lds_elems = rx_lds_elems;
     pl.llr_len.resize(ntb);
     for (uint32_t i = 0; i < ntb; i++)
       pl.llr_len[i] = tbs[i].llrLen;
-    /* the key is the descriptor array as it ARRIVED (llrLen is updated by the loop above) */
-    pl.remember(key_tb.data(), ntb, (uint32_t)b->harq_stride);
+    /* the key is the descriptor array as it ARRIVED (llrLen is updated by the loop above); the library's soft buffers as
+     * they are now, after this build's allocations */
+    salt[2] = harq_lib ? harq_tbl.gen.load() : 0;
+    pl.remember(key_tb.data(), ntb, salt);
   }
   if (c.scratch.ensure(pl.scratch_top) != 0)
     return -1;
@@ -643,34 +814,51 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   int32_t *d_iter = reinterpret_cast<int32_t *>(pl.jobs_d.p + o_iter);
   uint8_t *payload = b->payload;
   const int16_t *llr = static_cast<const int16_t *>(b->coded);
-  int16_t *harq = b->harq;
+  int16_t *harq = harq_lib ? nullptr : b->harq;
   uint8_t *ack = b->ack + tb0;
   int32_t *iter_max = b->iter_max + tb0;
-  const bool host = b->mem != NRLDPC_HIP_MEM_DEVICE;
-  if (host) {
-    const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2],
-                 harq_lo = pl.ext[4], harq_n = pl.ext[5] - pl.ext[4];
-    if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n * 2) != 0 || c.io_harq.ensure(harq_n * 2) != 0 ||
-        c.io_small.ensure((size_t)ntb * 8 + 64) != 0 || c.small_h.ensure((size_t)ntb * 8 + 64) != 0)
+  const size_t stride2 = (size_t)b->harq_stride * sizeof(int16_t);
+  if (staged) {
+    const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
+    if (c.io_payload.ensure(pay_n) != 0 || c.io_small.ensure((size_t)ntb * 8 + 64) != 0 || c.small_h.ensure((size_t)ntb * 8 + 64) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyHostToDevice, s));
-    {
-      if (pl.harq_dense) {
-        HIP_TRY(hipMemcpyAsync(c.io_harq.p, b->harq + harq_lo, harq_n * 2, hipMemcpyHostToDevice, s));
-      } else {
-        for (uint32_t i = 0; i < ntb; i++)
-            HIP_TRY(hipMemcpyAsync(c.io_harq.p + (pl.harq_span[2 * i] - harq_lo) * 2, b->harq + pl.harq_span[2 * i], pl.harq_span[2 * i + 1] * 2,
-                                   hipMemcpyHostToDevice, s));
-      }
+    /* LLRs in page-locked host memory are read in place (the device address of the caller's array); anything else is copied */
+    const int16_t *pulled = nullptr;
+    static const int pull_env = [] { const char *e = getenv("NRLDPC_HIP_TB_PULL"); return e ? atoi(e) : 1; }();
+    if (pull_env && !(b->mem & NRLDPC_HIP_MEM_DEVICE) && host_ptr_is_pinned(b->coded)) {
+      void *dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, b->coded, 0) == hipSuccess)
+        pulled = static_cast<const int16_t *>(dp);
+      else
+        (void)hipGetLastError();
+    }
+    if (pulled) {
+      llr = pulled;
+    } else {
+      if (c.io_coded.ensure(cod_n * 2) != 0)
+        return -1;
+      HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyDefault, s));
+      llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
+    }
+    if (harq_staged) {
+      const size_t harq_lo = pl.ext[4], harq_n = pl.ext[5] - pl.ext[4];
+      if (c.io_harq.ensure(harq_n * 2) != 0)
+        return -1;
+      for (const TbPlan::HarqRun &r : pl.harq_runs)
+        if (r.upload)
+          HIP_TRY(hipMemcpy2DAsync(c.io_harq.p + (r.first - harq_lo) * 2, stride2, b->harq + r.first, stride2, (size_t)r.width * 2, r.rows,
+                                   hipMemcpyDefault, s));
+      harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     }
     payload = c.io_payload.p - pay_lo;
-    llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
-    harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
     ack = c.io_small.p + (size_t)ntb * 4;
   }
-  HIP_TRY(tb_launch_rx_dematch(reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, pl.rx_lds_elems, llr, harq,
-                               reinterpret_cast<int8_t *>(c.scratch.p), s, n_seg <= (size_t)G().n_cus));
+  const tb_rx_seg_job *d_seg = reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg);
+  const tb_rx_seg_job *d_leg = reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + pl.legacy_off);
+  const tb_rx_tb_job *d_tb = reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb);
+  HIP_TRY(tb_launch_rx_dematch(d_leg, (uint32_t)pl.n_legacy_seg, pl.rx_lds_elems, llr, harq, reinterpret_cast<int8_t *>(c.scratch.p), s,
+                               n_seg <= (size_t)G().n_cus));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));
   da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);
@@ -681,46 +869,82 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   for (int k = 0; k < 4; k++)
     da.crc_pow_tbl[k] = G().crc_pow[k];
   da.crc_pow_tbl[NR_HIP_CRC24_A] = G().crc_pow_24a_long;
-  int *d_abort = reinterpret_cast<int *>(pl.jobs_d.p + o_acc) + ntb; /* zero on entry, left zero by the verdict kernel */
+  uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
+  int *d_abort = reinterpret_cast<int *>(d_acc) + ntb; /* zero on entry, left zero by the verdict */
   da.tb_abort = d_abort;
+  tb_rx_fused_args fx;
+  fx.segs = d_seg; fx.tbs = d_tb; fx.llr = llr; fx.harq = harq; fx.payload = payload; fx.ack = ack; fx.iter_max = iter_max;
+  fx.acc = d_acc; fx.done = d_abort + ntb; fx.pow24a = G().crc_pow_24a_long;
+  fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
+  fx.trace = nullptr;
   for (size_t k = 0; k < pl.dec.size(); k++) {
     const TbPlan::DecLaunch &dl = pl.dec[k];
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + dl.jobs_off);
     da.mgroups = reinterpret_cast<const ldpc_dec_mgroup *>(pl.jobs_d.p + dl.grp_off);
-    if (dl.kind == 0)
+    if (dl.kind == 0 && dl.fused) {
+      /* more than one workgroup per CU in the first round: staggered start (tb_chain.h).  NRLDPC_HIP_TB_STAGGER_US = the
+       * offset between the two workgroups of a CU (k workgroups: 2 / k of it each), 0 = off */
+      static const int stagger_us = [] { const char *e = getenv("NRLDPC_HIP_TB_STAGGER_US"); return e ? atoi(e) : 8; }();
+      const int per_cu = std::min(16 / std::max(dl.threads / 64, 1), (160 * 1024) / std::max(dl.lds, 1024));
+      fx.stagger_ticks = 0;
+      if (stagger_us > 0 && per_cu >= 2 && dl.n > (uint32_t)G().n_cus) {
+        fx.stagger_ticks = (uint32_t)(stagger_us * 100 * 2 / per_cu);
+        fx.stagger_cus = (uint32_t)G().n_cus;
+        fx.stagger_slots = (uint32_t)per_cu;
+      }
+      static const char *trace_file = getenv("NRLDPC_HIP_TB_TRACE"); /* diagnostics: per-workgroup clocks of this launch */
+      if (trace_file && c.trace_d.ensure((size_t)dl.n * 64) == 0) {
+        HIP_TRY(hipMemsetAsync(c.trace_d.p, 0, (size_t)dl.n * 64, s));
+        fx.trace = reinterpret_cast<unsigned long long *>(c.trace_d.p);
+      }
+      HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
+      if (fx.trace) {
+        std::vector<unsigned long long> h((size_t)dl.n * 8);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(h.data(), c.trace_d.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(trace_file, "wb")) {
+          fwrite(h.data(), 8, h.size(), f);
+          fclose(f);
+        }
+        fx.trace = nullptr;
+      }
+    }
+    else if (dl.kind == 0)
       HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s));
     else if (dl.kind == 1)
       HIP_TRY(ldpc_launch_dec_generic_jobs(da, dl.threads, dl.lds, dl.n, s));
     else
       HIP_TRY(ldpc_launch_dec_fast_multi_jobs(da, dl.kind == 3 ? 4 : 1, dl.threads, dl.lds, dl.n, s));
   }
-  uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
-  HIP_TRY(tb_launch_rx_assemble(reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb), ntb,
-                                reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg), (uint32_t)n_seg, d_iter,
-                                c.scratch.p, payload, ack, iter_max, d_acc, d_abort, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
-  if (host) {
+  if (pl.n_legacy_tb)
+    HIP_TRY(tb_launch_rx_assemble(d_tb, ntb, d_leg, (uint32_t)pl.n_legacy_seg, d_iter, c.scratch.p, payload, ack, iter_max, d_acc, d_abort,
+                                  G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
+  if (staged) {
+    const bool to_host = !(b->mem & NRLDPC_HIP_MEM_DEVICE);
     if (pl.out_dense) {
-      HIP_TRY(hipMemcpyAsync(b->payload + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(b->payload + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDefault, s));
     } else {
       for (uint32_t i = 0; i < ntb; i++)
         HIP_TRY(hipMemcpyAsync(b->payload + tbs[i].payload_off, c.io_payload.p + (tbs[i].payload_off - pl.ext[0]), tbs[i].A / 8,
-                               hipMemcpyDeviceToHost, s));
+                               hipMemcpyDefault, s));
     }
-    if (pl.harq_dense) {
-      HIP_TRY(hipMemcpyAsync(b->harq + pl.ext[4], c.io_harq.p, (pl.ext[5] - pl.ext[4]) * 2, hipMemcpyDeviceToHost, s));
-    } else {
-      for (uint32_t i = 0; i < ntb; i++)
-        HIP_TRY(hipMemcpyAsync(b->harq + pl.harq_span[2 * i], c.io_harq.p + (pl.harq_span[2 * i] - pl.ext[4]) * 2, pl.harq_span[2 * i + 1] * 2,
-                               hipMemcpyDeviceToHost, s));
+    if (harq_staged)
+      for (const TbPlan::HarqRun &r : pl.harq_runs)
+        HIP_TRY(hipMemcpy2DAsync(b->harq + r.first, stride2, c.io_harq.p + (r.first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, r.rows,
+                                 hipMemcpyDefault, s));
+    if (to_host) {
+      HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)ntb * 5, hipMemcpyDeviceToHost, s));
+    } else { /* a peer GPU's share of a device-resident batch: the verdicts go to the owner's arrays */
+      HIP_TRY(hipMemcpyAsync(b->iter_max + tb0, c.io_small.p, (size_t)ntb * 4, hipMemcpyDefault, s));
+      HIP_TRY(hipMemcpyAsync(b->ack + tb0, c.io_small.p + (size_t)ntb * 4, ntb, hipMemcpyDefault, s));
     }
-    HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)ntb * 5, hipMemcpyDeviceToHost, s));
   }
   return 0;
 }
 
 int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
 {
-  if (b->mem == NRLDPC_HIP_MEM_DEVICE || ntb == 0)
+  if ((b->mem & NRLDPC_HIP_MEM_DEVICE) || ntb == 0)
     return 0;
   TbCtx &c = tls_tb;
   HIP_TRY(hipStreamSynchronize(c.own));
@@ -755,15 +979,70 @@ void tb_partition(const nrLDPC_hip_tb_batch_t *b, int parts, uint32_t *cut)
   cut[parts] = b->n_tb;
 }
 
-/* run enqueue on every part, then finish on every part (so that the devices work concurrently) */
+/* Run a batch over the library's GPUs.  enq(tb0, n, staged, stream) / fin(tb0, n) work on the current device.
+ *   host buffers: contiguous whole-TB ranges, one per sharding device, every device fed over its own link; enqueue on all of
+ *     them, then finish in order (so that they work concurrently);
+ *   device buffers: the GPU that owns them takes its range in place on the caller's stream; with NRLDPC_HIP_DEVICES listing
+ *     peers the other ranges are copied GPU to GPU (xGMI) into the peers' staging buffers, worked on there and the results
+ *     copied back -- ordered behind what the caller's stream held on entry, and the caller's stream waits for them on exit, so
+ *     the call stays "enqueue only" (whole transport blocks per GPU, one exchange step each way, no all-reduce). */
 template <typename Enq, typename Fin> int tb_run_sharded(const nrLDPC_hip_tb_batch_t *b, Enq enq, Fin fin)
 {
-  if (b->mem == NRLDPC_HIP_MEM_DEVICE) {
+  if (b->mem & NRLDPC_HIP_MEM_DEVICE) {
     Device *d = device_of_pointer(b->coded);
     if (!d)
       return -1;
-    UseDevice use(*d);
-    return enq(0u, b->n_tb) != 0 ? -1 : fin(0u, b->n_tb);
+    hipStream_t cs = static_cast<hipStream_t>(b->stream);
+    int owner = -1;
+    for (int k = 0; k < g.n_shard; k++)
+      if (&g.dev[k] == d)
+        owner = k;
+    const int parts = (owner >= 0 && b->n_tb >= 2u * (uint32_t)g.n_shard) ? g.n_shard : 1;
+    if (parts == 1) {
+      UseDevice use(*d);
+      return enq(0u, b->n_tb, false, cs) != 0 ? -1 : fin(0u, b->n_tb);
+    }
+    uint32_t cut[NRLDPC_HIP_MAX_DEVICES + 1];
+    tb_partition(b, parts, cut);
+    int rc = 0;
+    hipEvent_t ev_in = nullptr;
+    {
+      UseDevice use(*d);
+      TbCtx &c = tls_tb;
+      if (!c.ev_in && hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming) != hipSuccess)
+        return set_error("event");
+      ev_in = c.ev_in;
+      HIP_TRY(hipEventRecord(ev_in, cs)); /* what the caller's stream has produced so far: the peers read it */
+    }
+    hipEvent_t ev_out[NRLDPC_HIP_MAX_DEVICES];
+    int n_out = 0;
+    for (int k = 0; k < parts && rc == 0; k++) {
+      const uint32_t n = cut[k + 1] - cut[k];
+      if (n == 0)
+        continue;
+      UseDevice use(g.dev[k]);
+      if (k == owner) {
+        rc = enq(cut[k], n, false, cs);
+        continue;
+      }
+      TbCtx &c = tls_tb;
+      hipStream_t s;
+      if (tb_begin(s, nullptr, true) != 0) { rc = -1; break; }
+      if (!c.ev_out && hipEventCreateWithFlags(&c.ev_out, hipEventDisableTiming) != hipSuccess) { rc = set_error("event"); break; }
+      if (hipStreamWaitEvent(s, ev_in, 0) != hipSuccess) { rc = set_error("hipStreamWaitEvent"); break; }
+      rc = enq(cut[k], n, true, nullptr);
+      if (rc == 0 && hipEventRecord(c.ev_out, s) != hipSuccess)
+        rc = set_error("hipEventRecord");
+      if (rc == 0)
+        ev_out[n_out++] = c.ev_out;
+    }
+    {
+      UseDevice use(*d);
+      for (int q = 0; q < n_out; q++)
+        if (hipStreamWaitEvent(cs, ev_out[q], 0) != hipSuccess)
+          rc = set_error("hipStreamWaitEvent");
+    }
+    return rc;
   }
   if (ensure_ready() != 0)
     return -1;
@@ -773,7 +1052,7 @@ template <typename Enq, typename Fin> int tb_run_sharded(const nrLDPC_hip_tb_bat
   int rc = 0;
   for (int k = 0; k < parts && rc == 0; k++) {
     UseDevice use(g.dev[k]);
-    rc = enq(cut[k], cut[k + 1] - cut[k]);
+    rc = enq(cut[k], cut[k + 1] - cut[k], true, nullptr);
   }
   for (int k = 0; k < parts; k++) { /* also after an error: nothing stays in flight */
     UseDevice use(g.dev[k]);
@@ -793,22 +1072,99 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b)
 {
   if (!b || !b->tb || !b->payload || !b->coded)
     return set_error("null argument");
+  if (b->mem & ~NRLDPC_HIP_MEM_DEVICE)
+    return set_error("encode: mem must be NRLDPC_HIP_MEM_HOST or NRLDPC_HIP_MEM_DEVICE");
   if (b->n_tb == 0)
     return ensure_ready();
   return tb_run_sharded(
-      b, [&](uint32_t tb0, uint32_t n) { return tb_tx_enqueue(b, tb0, n); }, [&](uint32_t, uint32_t n) { return tb_tx_finish(b, n); });
+      b, [&](uint32_t tb0, uint32_t n, bool staged, hipStream_t s) { return tb_tx_enqueue(b, tb0, n, staged, s); },
+      [&](uint32_t, uint32_t n) { return tb_tx_finish(b, n); });
 }
 
 int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
 {
   if (!b || !b->tb || !b->payload || !b->coded)
     return set_error("null argument");
-  if (!b->harq || !b->ack || !b->iter_max || b->harq_stride < 66 * 384)
+  const bool harq_lib = (b->mem & NRLDPC_HIP_MEM_HARQ_LIBRARY) != 0;
+  if ((b->mem & ~(NRLDPC_HIP_MEM_DEVICE | NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_HARQ_LIBRARY)) ||
+      (harq_lib && (b->mem & NRLDPC_HIP_MEM_HARQ_DEVICE)))
+    return set_error("decode: invalid mem flags");
+  if ((!b->harq && !harq_lib) || !b->ack || !b->iter_max || b->harq_stride < 66 * 384)
     return set_error("decode needs harq (stride >= 66*384), ack and iter_max buffers");
   if (b->n_tb == 0)
     return ensure_ready();
   return tb_run_sharded(
-      b, [&](uint32_t tb0, uint32_t n) { return tb_rx_enqueue(b, tb0, n); }, [&](uint32_t tb0, uint32_t n) { return tb_rx_finish(b, tb0, n); });
+      b, [&](uint32_t tb0, uint32_t n, bool staged, hipStream_t s) { return tb_rx_enqueue(b, tb0, n, staged, s); },
+      [&](uint32_t tb0, uint32_t n) { return tb_rx_finish(b, tb0, n); });
+}
+
+int32_t nrLDPC_hip_harq_release(uint64_t id)
+{
+  std::lock_guard<std::mutex> lk(harq_tbl.mu);
+  auto it = harq_tbl.m.find(id);
+  if (it == harq_tbl.m.end())
+    return set_error("unknown soft-buffer id");
+  harq_tbl.pool.push_back(it->second);
+  harq_tbl.m.erase(it);
+  harq_tbl.gen.fetch_add(1);
+  return 0;
+}
+
+int32_t nrLDPC_hip_harq_release_all(void)
+{
+  std::lock_guard<std::mutex> lk(harq_tbl.mu);
+  for (auto &kv : harq_tbl.m)
+    harq_tbl.pool.push_back(kv.second);
+  harq_tbl.m.clear();
+  harq_tbl.gen.fetch_add(1);
+  return 0;
+}
+
+int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t n)
+{
+  HarqEntry e;
+  {
+    std::lock_guard<std::mutex> lk(harq_tbl.mu);
+    auto it = harq_tbl.m.find(id);
+    if (it == harq_tbl.m.end())
+      return set_error("unknown soft-buffer id");
+    e = it->second;
+  }
+  if (!dst || first + n > e.n)
+    return set_error("range outside the soft buffers");
+  UseDevice use(g.dev[e.dev]);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dst, e.p + first, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void *nrLDPC_hip_host_alloc(uint64_t bytes)
+{
+  if (ensure_ready() != 0)
+    return nullptr;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc");
+    return nullptr;
+  }
+  return p;
+}
+void nrLDPC_hip_host_free(void *p)
+{
+  if (p)
+    (void)hipHostFree(p);
+}
+int32_t nrLDPC_hip_host_register(void *p, uint64_t bytes)
+{
+  if (ensure_ready() != 0)
+    return -1;
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return 0;
+}
+int32_t nrLDPC_hip_host_unregister(void *p)
+{
+  HIP_TRY(hipHostUnregister(p));
+  return 0;
 }
 
 } /* extern "C" */

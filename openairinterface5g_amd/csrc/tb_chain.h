@@ -8,58 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define TB_CRC24A_POW_LEN (1u << 21) /* x^j mod g for j < 2 Mi: covers any NR transport block */
-
-struct tb_tx_tb_job {      /* one per transport block */
-  uint64_t payload_off;    /* A/8 bytes in the payload buffer */
-  uint64_t b_off;          /* scratch: payload || TB CRC, B/8 bytes */
-  uint32_t A, B, crc_type; /* CRC24_A (0) or CRC16 (2) */
-  uint32_t pad;
-};
-struct tb_crc_chunk_job {  /* one per chunk of a transport block: the TB CRC is computed by many workgroups */
-  uint32_t tb;             /* index into the per-TB job array */
-  uint32_t first_byte;     /* byte range [first_byte, first_byte + chunk) of the TB; chunk = TB_CRC_CHUNK_SMALL when bit 31 is set */
-};
-/* bytes of a transport block per workgroup of the TB CRC kernel: 8 or 32 per thread.  The byte-table recurrence over a
- * thread's bytes is a chain of dependent look-ups (short pieces = short latency: one transport block 30.6 -> 26.9 us),
- * but every piece costs ~200 instructions and a power-table load to move to the end of the string (long pieces = less
- * work: a 64-block slot's CRC kernels take twice as long with the short ones) -- the plan picks by the call's size. */
-#define TB_CRC_CHUNK_SMALL 2048u
-#define TB_CRC_CHUNK 8192u
-struct tb_tx_seg_job {     /* one per code block */
-  uint64_t b_off;          /* the TB's b */
-  uint64_t c_off;          /* scratch: packed segment, K/8 bytes (encoder input) */
-  uint64_t d_off;          /* scratch: encoder output, one bit per byte */
-  uint64_t out_off;        /* coded output: TB offset + sum of the previous segments' E */
-  uint32_t r, C, Kprime, L, K; /* segment index, segments, bits incl. CB CRC, CB CRC length, K */
-  uint32_t E, Qm, Foffset, Fin, V, rank0;
-  uint32_t tb;             /* transport block (index of its CRC accumulator) */
-  /* fused kernel, segment that carries the TB CRC (the last one): crc_pos = byte of the segment where the CRC starts,
-   * crc_len = 3 (CRC24A) / 2 (CRC16); crc_len = 0: no TB CRC bytes in this segment */
-  uint32_t crc_pos, crc_len;
-  uint32_t pad;
-};
-struct tb_rx_seg_job {
-  uint64_t llr_off;        /* int16 units: TB offset + sum of the previous segments' E */
-  uint64_t harq_off;       /* int16 units: soft buffer d[r] of this segment */
-  uint64_t l_off;          /* scratch: decoder input, int8 */
-  uint32_t E, Qm, Ncb, Foffset, Fin, V, rank0, clear;
-  uint32_t K, F, Z, num_llr; /* num_llr = ncols(R)*Z bytes the decoder reads */
-  /* reassembly (tb_rx_assemble_kernel): */
-  uint64_t c_off;          /* scratch: this segment's decoded bits */
-  uint32_t tb, r;          /* transport block (index into the per-TB jobs) and segment number */
-  uint32_t iter_idx, pad;  /* where the decoder reported this segment's pass count */
-};
-struct tb_rx_tb_job {
-  uint64_t payload_off;    /* A/8 bytes out */
-  uint64_t b_off;          /* scratch: reassembled b (B/8 bytes) */
-  uint64_t c_off0;         /* scratch: first segment's decoded bits; segments are c_stride apart */
-  uint32_t c_stride;
-  uint32_t seg0, C;        /* index of the first segment in the n_iter array */
-  uint32_t A, B, crc_type, num_max_iter;
-  uint32_t seg_bytes;      /* payload bytes carried per segment = K/8 - F/8 - (C > 1 ? 3 : 0) */
-  uint32_t pad;
-};
+#include "tb_jobs.h"
 
 /* TB CRC attach in two steps: per-chunk partial CRCs XOR-ed into acc[tb], then the CRC bytes.  acc[] must be zero on
  * entry and is zero again on exit (uploaded as zeros with the plan; no memset per call) */
@@ -76,14 +25,38 @@ hipError_t tb_launch_tx_ratematch(const tb_tx_seg_job *jobs, uint32_t n, const u
 struct ldpc_enc_job;
 hipError_t tb_launch_tx_fused(const tb_tx_seg_job *jobs, const struct ldpc_enc_job *ejobs, uint32_t n, int n_threads, int lds_bytes,
                               const uint8_t *scratch, uint8_t *coded, const uint32_t *pow24b, uint32_t *acc, hipStream_t s);
-/* lds_elems = the largest tb_rx_lds_elems() over the jobs (int16 slots of LDS a workgroup needs) */
-__host__ __device__ static inline uint32_t tb_rx_lds_elems(uint32_t E, uint32_t Fin, uint32_t Ncb)
-{
-  const uint32_t span = E + Fin;
-  return ((span < Ncb ? span : Ncb) + 8u + 7u) & ~7u; /* + 8: the span starts up to 7 slots into its first aligned word */
-}
 hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t lds_elems, const int16_t *llr, int16_t *harq,
                                 int8_t *scratch, hipStream_t s, int wide = 0);
+/* Fused segment kernel (tb_rx_fused.hip): one workgroup takes a code segment from the received LLRs to its payload bytes --
+ * de-matching (tb_rx_core.h) as the prologue of the decoder's block body, and instead of an output row the segment's bytes
+ * of the payload, its share of the TB CRC and, from the last segment of a transport block to finish, the block's verdict.
+ * Jobs = ldpc_dec_job with seg_idx >= 0 (a job with seg_idx < 0 is decoded as by ldpc_launch_dec_fast_jobs).  acc[], done[]
+ * and the abort flags are zero on entry and on exit. */
+struct tb_rx_fused_args {
+  const tb_rx_seg_job *segs;
+  const tb_rx_tb_job *tbs;
+  const int16_t *llr;  /* device memory, or the device address of page-locked host memory (pulled over the link) */
+  int16_t *harq;
+  uint8_t *payload;
+  uint8_t *ack;
+  int32_t *iter_max;
+  uint32_t *acc;       /* per TB: XOR of the segments' partial TB CRC registers */
+  int *done;           /* per TB: segments finished */
+  const uint32_t *pow24a;
+  /* First-round stagger.  The workgroups that share a CU start together and would stay in step -- all of them in their
+   * memory-bound prologue (the CU's VALUs idle, HBM contended by every CU at once), then all of them decoding.  Workgroup
+   * b < stagger_cus * stagger_slots waits (b / stagger_cus) * stagger_ticks (10 ns each) before it starts, so that one
+   * workgroup's prologue runs under its neighbour's decoding; a workgroup that finishes is replaced at once, so the later
+   * rounds inherit the offset.  0 ticks: off. */
+  uint32_t stagger_ticks, stagger_cus, stagger_slots;
+  /* diagnostics (NRLDPC_HIP_TB_TRACE=<file>): per workgroup {HW_ID, XCC_ID, wall clock at start, after the prologue, after
+   * the last pass, at the end, pass count, 0} as 8 x uint64; NULL normally */
+  unsigned long long *trace;
+};
+struct ldpc_dec_args;
+hipError_t tb_launch_rx_fused(const struct ldpc_dec_args &a, const tb_rx_fused_args &x, int n_threads, int lds_bytes, uint32_t n_jobs,
+                              hipStream_t s);
+hipError_t tb_rx_fused_init(void);
 /* reassembly per segment (payload copy + partial TB CRC into acc[tb], zero on entry and on exit), then per-TB verdict */
 hipError_t tb_launch_rx_assemble(const tb_rx_tb_job *jobs, uint32_t n_tb, const tb_rx_seg_job *segs, uint32_t n_seg,
                                  const int32_t *n_iter, uint8_t *scratch, uint8_t *payload, uint8_t *ack, int32_t *iter_max,

@@ -14,6 +14,7 @@
 #include "tb_chain.h"
 #include "ldpc_kernels.h"
 #include "ldpc_enc_packed_core.h"
+#include "tb_rx_core.h"
 
 #define TB_THREADS 256
 
@@ -521,170 +522,16 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
  * nr_rate_matching_ldpc_rx (:507-603): w[pos(k)] += e[k] (int16, wrapping), pos = circular-buffer position of rank
  * (rank0 + k) mod V among the non-filler positions, after clearing w[0..Ncb) on the first round;
  * caller's pack (nr_ulsch_decoding.c:195-210): punctured columns 0, fillers +127, saturate to int8.
- *
- * One workgroup per code segment, the segment's received contributions transposed through LDS so that both sides move
- * whole cache lines:
- *   phase A  a thread per modulation symbol jj reads the symbol's Qm LLRs f[jj*Qm .. +Qm) in ONE load and drops each at
- *            its soft-buffer position in LDS (e_lds[pos(i*E/Qm + jj)]); one lap of the circular buffer at a time, so that
- *            every position receives at most one value per lap (plain read-modify-write, no atomics, no division);
- *   phase B  a thread per 8 consecutive soft-buffer positions: w (16-byte load / store) + the lap sums from LDS, then the
- *            saturated int8 decoder input (8-byte store) with the punctured zeros and +127 fillers.
- * HBM traffic = E int16 in, Ncb int16 in (unless first round) and out, num_llr int8 out: the compulsory bytes. */
-typedef uint32_t tb_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t tb_u32x2 __attribute__((ext_vector_type(2)));
-
-template <int QM> struct tb_sym; /* the Qm LLRs of one modulation symbol as one load (4-byte aligned source) */
-template <> struct tb_sym<2> { uint32_t w[1]; };
-template <> struct tb_sym<4> { uint32_t w[2]; };
-template <> struct tb_sym<6> { uint32_t w[3]; };
-template <> struct tb_sym<8> { uint32_t w[4]; };
-
-/* LDS slot of soft-buffer position p.  Positions are visited in circular order starting at p_base = pos(rank0); the slot
- * is the circular distance from p_align = p_base rounded down to a multiple of 8, so that 8 consecutive positions that
- * start at a multiple of 8 sit in one aligned 16-byte LDS word (as long as Ncb % 8 == 0 across the wrap).  A segment
- * touches min(Ncb, E + Fin) + 8 slots at most (tb_rx_lds_elems); the slots are zeroed first, so a slot that receives
- * nothing (filler positions, the tail of the last lap) simply contributes 0 -- no coverage logic on the way out. */
-__device__ __forceinline__ uint32_t tb_rx_slot(uint32_t p, uint32_t p_align, uint32_t Ncb) { return p >= p_align ? p - p_align : p + Ncb - p_align; }
-
-template <int QM>
-__device__ __forceinline__ void tb_rx_scatter_laps(const int16_t *__restrict__ f, int16_t *e_lds, uint32_t E, uint32_t V, uint32_t rank0,
-                                                    uint32_t Foffset, uint32_t Fin, uint32_t p_align, uint32_t Ncb)
-{
-  const uint32_t EQ = E / QM, nlaps = (E + V - 1) / V;
-  const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
-  for (uint32_t lap = 0; lap < nlaps; lap++) {
-    const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
-    for (uint32_t jj0 = threadIdx.x; jj0 < EQ; jj0 += 2 * blockDim.x) {
-      /* two symbols per step: both loads are in flight before either is consumed */
-      int16_t v[2][QM];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const uint32_t jj = jj0 + (uint32_t)u * blockDim.x;
-        if (jj < EQ) {
-          if (vec) {
-            const tb_sym<QM> sy = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
-#pragma unroll
-            for (int i = 0; i < QM; i++)
-              v[u][i] = (int16_t)(sy.w[i >> 1] >> (16 * (i & 1)));
-          } else {
-#pragma unroll
-            for (int i = 0; i < QM; i++)
-              v[u][i] = f[(size_t)jj * QM + i];
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const uint32_t jj = jj0 + (uint32_t)u * blockDim.x;
-        if (jj < EQ) {
-#pragma unroll
-          for (int i = 0; i < QM; i++) {
-            const uint32_t k = (uint32_t)i * EQ + jj;
-            if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
-              uint32_t r = rank0 + (k - k_lo);
-              r = r >= V ? r - V : r;
-              const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_align, Ncb);
-              e_lds[q] = lap == 0 ? v[u][i] : (int16_t)(e_lds[q] + v[u][i]);
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
+ * One workgroup per code segment; the per-thread phases live in tb_rx_core.h (shared with the fused segment kernel,
+ * tb_rx_fused.hip, where the same work is the prologue of the segment's decoder workgroup). */
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) tb_rx_dematch_kernel(const tb_rx_seg_job *jobs, const int16_t *llr,
                                                                    int16_t *harq, int8_t *scratch)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t e_lds[];
   typedef const tb_rx_seg_job LDPC_CONST_AS *job_ptr_t;
   const job_ptr_t j = (job_ptr_t)jobs + blockIdx.x; /* uniform address: the job stays in SGPRs */
-  const int16_t *__restrict__ f = llr + j->llr_off;
-  int16_t *__restrict__ w = harq + j->harq_off;
-  int8_t *__restrict__ l = scratch + j->l_off;
-  const uint32_t E = j->E, Ncb = j->Ncb, Foffset = j->Foffset, Fin = j->Fin, V = j->V, rank0 = j->rank0, clear = j->clear;
-  const uint32_t twoZ = 2 * j->Z, num_llr = j->num_llr, Klo = j->K - j->F, Khi = j->K;
-  const uint32_t np = num_llr > twoZ ? num_llr - twoZ : 0;          /* soft-buffer positions the decoder reads */
-  const uint32_t n = Ncb > np ? Ncb : np;
-  const uint32_t p_base = rank0 < Foffset ? rank0 : rank0 + Fin, p_align = p_base & ~7u;
-  const uint32_t span = tb_rx_lds_elems(E, Fin, Ncb);               /* slots in use, a multiple of 8 */
-  for (uint32_t i = threadIdx.x; i < span / 8; i += blockDim.x)
-    reinterpret_cast<tb_u32x4 *>(e_lds)[i] = (tb_u32x4){0u, 0u, 0u, 0u};
-  for (uint32_t i = threadIdx.x; i < twoZ && i < num_llr; i += blockDim.x)
-    l[i] = 0;                                                       /* punctured columns (nr_ulsch_decoding.c:198) */
-  __syncthreads();
-  switch (j->Qm) {
-    case 2: tb_rx_scatter_laps<2>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
-    case 4: tb_rx_scatter_laps<4>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
-    case 6: tb_rx_scatter_laps<6>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
-    default: tb_rx_scatter_laps<8>(f, e_lds, E, V, rank0, Foffset, Fin, p_align, Ncb); break;
-  }
-  /* what position p received in this call (all laps), 0 if nothing */
-  auto received = [&](uint32_t p) -> int16_t {
-    const uint32_t q = tb_rx_slot(p, p_align, Ncb);
-    return (p < Ncb && q < span) ? e_lds[q] : (int16_t)0;
-  };
-  auto pack = [&](uint32_t p, int16_t acc) -> int8_t {             /* nr_ulsch_decoding.c:200-210 */
-    const uint32_t i = p + twoZ;
-    const int v = (i >= Klo && i < Khi) ? 127 : (int)acc;
-    return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
-  };
-  /* 8 positions per thread and step, lanes side by side: one 16-byte load / store of w, one aligned 16-byte LDS read, one
-   * 8-byte store of the decoder input.  w[p] = (first round ? 0 : w[p]) + received (nr_rate_matching.c:554-603; beyond
-   * Ncb the reference's buffer is calloc'ed and never written: 0 on a first round); a position that received nothing
-   * keeps its value, so the store is skipped unless something changes. */
-  const bool vec = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((reinterpret_cast<uintptr_t>(l + twoZ) & 7) == 0);
-  const uint32_t n8 = vec ? (n & ~7u) : 0;
-  const uint32_t fill_lo = Klo > twoZ ? Klo - twoZ : 0, fill_hi = Khi > twoZ ? Khi - twoZ : 0; /* decoder-input fillers in p */
-  for (uint32_t p0 = 8 * threadIdx.x; p0 < n8; p0 += 8 * blockDim.x) {
-    union { tb_u32x4 q; int16_t h[8]; uint32_t u[4]; } old, e, acc;
-    old.q = clear ? (tb_u32x4){0u, 0u, 0u, 0u} : *reinterpret_cast<const tb_u32x4 *>(w + p0);
-    const uint32_t q0 = tb_rx_slot(p0, p_align, Ncb);
-    if (p0 + 8 <= Ncb && (p0 >= p_align || (Ncb & 7u) == 0)) {       /* the chunk is one aligned LDS word (or outside the span) */
-      e.q = q0 < span ? *reinterpret_cast<const tb_u32x4 *>(e_lds + q0) : (tb_u32x4){0u, 0u, 0u, 0u};
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; t++)
-        e.h[t] = received(p0 + t);
-    }
-    bool any = clear != 0;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {                                    /* int16 wrapping add, two lanes per op */
-      acc.u[t] = ((old.u[t] & 0x7fff7fffu) + (e.u[t] & 0x7fff7fffu)) ^ ((old.u[t] ^ e.u[t]) & 0x80008000u);
-      any |= e.u[t] != 0;
-    }
-    if (any)
-      *reinterpret_cast<tb_u32x4 *>(w + p0) = acc.q;
-    if (p0 < np) {
-      union { tb_u32x2 q; int8_t b[8]; } lo;
-      if (p0 + 8 <= fill_lo || p0 >= fill_hi) {
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-          const int v = acc.h[t];
-          lo.b[t] = (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-          lo.b[t] = pack(p0 + t, acc.h[t]);
-      }
-      if (p0 + 8 <= np)
-        *reinterpret_cast<tb_u32x2 *>(l + twoZ + p0) = lo.q;
-      else
-        for (int t = 0; t < 8; t++)
-          if (p0 + t < np)
-            l[twoZ + p0 + t] = lo.b[t];
-    }
-  }
-  for (uint32_t p = n8 + threadIdx.x; p < n; p += blockDim.x) {
-    const int16_t ev = received(p);
-    const int16_t acc = (int16_t)((clear ? 0 : w[p]) + ev);
-    if (clear || ev != 0)
-      w[p] = acc;
-    if (p < np)
-      l[p + twoZ] = pack(p, acc);
-  }
+  const tb_rx_geom g = tb_rx_geometry(j);
+  tb_rx_dematch_block(g, j->Qm, llr + j->llr_off, harq + j->harq_off, scratch + j->l_off, e_lds);
 }
 
 /* ---- RX 2: reassemble b from the decoded segments, TB CRC, payload out --------------------------------------------
@@ -733,6 +580,8 @@ __global__ void __launch_bounds__(TB_THREADS) tb_rx_verdict_kernel(const tb_rx_t
   if (i >= n_tb)
     return;
   const tb_rx_tb_job j = jobs[i];
+  if (j.fused) /* delivered by the block's last segment to finish (tb_rx_fused.hip) */
+    return;
   bool all_ok = true;
   int imax = 0;
   for (uint32_t r = 0; r < j.C; r++) {

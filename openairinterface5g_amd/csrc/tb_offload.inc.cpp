@@ -110,7 +110,7 @@ int offload_decode(const t_nrLDPC_dec_params *p, uint8_t ulsch_id, uint8_t r, co
   dj.code = hc.f_ok ? ce->dev_lat : ce->dev;
   dj.llr_off = o_l; dj.out_off = o_c;
   dj.num_max_iter = p->numMaxIter;
-  dj.iter_idx = 0; dj.abort_idx = -1;
+  dj.iter_idx = 0; dj.abort_idx = -1; dj.seg_idx = -1;
   memcpy(c.jobs_h.p + o_seg, &j, sizeof(j));
   memcpy(c.jobs_h.p + o_dec, &dj, sizeof(dj));
   int16_t *in16 = reinterpret_cast<int16_t *>(c.jobs_h.p + o_in);
@@ -202,7 +202,8 @@ int offload_encode(const uint8_t *in, uint8_t *out, const encoder_implemparams_t
 
 extern "C" {
 
-int32_t nrLDPC_hip_offload_init(void) { return LDPCinit(); }
+/* (not through the exported name: libldpc_hip_t2.so exports an LDPCinit of its own, and plugins are loaded RTLD_GLOBAL) */
+int32_t nrLDPC_hip_offload_init(void) { return lib_init(); }
 
 int32_t nrLDPC_hip_offload_decoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                                    int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab)

@@ -1,0 +1,246 @@
+/*
+ * tb_rx_fused.hip -- the UL-SCH chain's fused segment kernel for gfx950: one workgroup takes ONE code segment from the
+ * received LLRs to its payload bytes, the way the reference's per-segment job does on one CPU thread
+ * (openair1/PHY/NR_TRANSPORT/nr_ulsch_decoding.c:122-223 nr_processULSegment: nr_deinterleaving_ldpc ->
+ * nr_rate_matching_ldpc_rx -> int8 pack -> LDPCdecoder; SCHED_NR/phy_procedures_nr_gNB.c:271-300 nr_postDecode: copy of
+ * the segment's bytes into the transport block, and when the last segment has arrived the TB CRC and the verdict).
+ *
+ *   prologue  tb_rx_core.h: de-interleave + rate de-match + HARQ combine through an LDS image (it lies in the decoder's
+ *             message area, which the first pass does not read), soft buffer updated in HBM, int8 decoder input written
+ *             to the segment's scratch row (the decoder re-reads the core columns from it every pass, L2 resident).  The
+ *             LLRs may sit in page-locked HOST memory: the workgroup then pulls them over the link itself, and with the
+ *             launch's workgroups at different points of their lives the link, HBM and the CUs are busy together -- no
+ *             copy engine, no copy -> kernel edge.
+ *   body      ldpc_dec_fast_block (CRC stop, transport-block abort flag).
+ *   epilogue  instead of an output row: the segment's bytes of the payload (stores that leave the caches), its share of the
+ *             TB CRC register (linear: XOR-ed into a per-TB accumulator) and its pass count; a per-TB counter tells the
+ *             last segment to finish that it is the last, and that workgroup delivers ACK / iter_max (and zeroes the
+ *             payload of a block that failed, as the reassembly kernel does).  No fences: everything another workgroup
+ *             looks at is moved by device-scope atomics or write-through stores that are complete (s_waitcnt) before the
+ *             counter is incremented; an agent-scope release fence would write back the XCD's whole L2 per segment.
+ *
+ * Replaces four launches (tb_rx_dematch_kernel, ldpc_dec_fast_kernel<true, true>, tb_rx_assemble_kernel,
+ * tb_rx_verdict_kernel) for the segments it serves; those kernels remain for segments of codes the fast decoder does not
+ * take (Zc % 4 != 0) and for small segments that share workgroups, and behind NRLDPC_HIP_TB_FUSED=0.
+ */
+#include <hip/hip_runtime.h>
+#include "ldpc_kernels.h"
+#include "tb_chain.h"
+#include "tb_rx_core.h"
+#include "ldpc_dec_fast_block.h"
+
+typedef const tb_rx_seg_job LDPC_CONST_AS *tb_seg_ptr_t;
+typedef const tb_rx_tb_job LDPC_CONST_AS *tb_tb_ptr_t;
+
+/* stores / loads that other workgroups (other XCDs: other L2s) or the host may look at while the kernel runs */
+template <class T> __device__ __forceinline__ void tb_store_out(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void tb_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct tb_rx_fused_io {
+  const ldpc_dec_args &a;
+  const tb_rx_fused_args &x;
+  ldpc_job_ptr_t job;
+  __device__ __forceinline__ tb_seg_ptr_t seg() const { return (tb_seg_ptr_t)x.segs + job->seg_idx; }
+  __device__ __forceinline__ tb_tb_ptr_t tb() const { return (tb_tb_ptr_t)x.tbs + seg()->tb; }
+  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(a.llr + (size_t)job->llr_off); }
+  __device__ __forceinline__ int8_t *out() const { return a.out + (size_t)job->out_off; }
+  __device__ __forceinline__ int max_pass() const { return job->num_max_iter + 1; }
+  __device__ __forceinline__ int use_crc() const { return 1; }
+  static constexpr bool syndrome = false; /* CRC stop: nobody looks at the parity of the hard decisions */
+  __device__ __forceinline__ int crcE() const { return job->E; }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return a.crc_pow_tbl[job->crc_type]; }
+  __device__ __forceinline__ int out_mode() const { return 0; }
+  __device__ __forceinline__ int *tb_abort() const { return (a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr; }
+  __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ bool eager_check() const { return false; }
+  static constexpr bool bn_tickets = true;
+  __device__ __forceinline__ bool tables_resident() const { return false; }
+  __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
+  __device__ __forceinline__ uint32_t abort_load() const { return 0u; }
+  __device__ __forceinline__ bool abort_is(uint32_t) const { return false; }
+  __device__ __forceinline__ bool has_abort() const { return true; }
+  __device__ __forceinline__ void put16(uint4 *p, uint32_t x0, uint32_t y, uint32_t z, uint32_t t) const { *p = make_uint4(x0, y, z, t); }
+  __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return *p; }
+  __device__ __forceinline__ const uint32_t *src32_prologue() const { return src32(); }
+  __device__ __forceinline__ uint32_t *stage_core() const { return nullptr; }
+  static constexpr bool tb_epilogue = true;
+  __device__ __forceinline__ bool tb_fused() const { return job->seg_idx >= 0; }
+
+  /* The segment's part of nr_postDecode (phy_procedures_nr_gNB.c:271-300).  bits_word(w) = the block's hard decisions 32w ..
+   * 32w + 31, MSB first inside each byte, as the dword the output row would hold (bnProc.h:1353-1380): byte k of it is byte
+   * 4w + k of the segment.  flags = the block body's LDS words ([2], [4], [5] are free here).  Called by every thread. */
+  template <class Bits> __device__ __forceinline__ void tb_finish(int n_iter, Bits bits_word, int *flags) const
+  {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u;
+    if (x.trace && tid == 0)
+      x.trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+    const tb_seg_ptr_t sj = seg();
+    const tb_tb_ptr_t tj = tb();
+    const uint32_t tbi = sj->tb, C = tj->C, seg_bytes = tj->seg_bytes, bbytes = tj->B >> 3, abytes = tj->A >> 3;
+    const uint32_t first = sj->r * seg_bytes;
+    uint32_t count = 0; /* bytes of b = payload || TB CRC this segment carries */
+    if (first < bbytes)
+      count = first + seg_bytes <= bbytes ? seg_bytes : bbytes - first;
+    const bool ok = n_iter <= (int)tj->num_max_iter;
+    uint32_t xr = 0;
+    if (ok) {
+      uint8_t *dst = x.payload + tj->payload_off + first;
+      const uint32_t pay_n = first < abytes ? (count < abytes - first ? count : abytes - first) : 0u; /* the rest is the TB CRC */
+      const bool al = (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
+      const uint32_t Bt = tj->B - 8 * first; /* bit i of the segment is followed by Bt - 1 - i bits of b */
+      const uint32_t *pow = x.pow24a;
+      for (uint32_t w = tid; 4 * w < count; w += nt) {
+        uint32_t word = bits_word((int)w);
+        const uint32_t nb = count - 4 * w;
+        if (nb < 4)
+          word &= (1u << (8 * nb)) - 1u;
+        if (4 * w < pay_n) {
+          const uint32_t pb = pay_n - 4 * w;
+          if (pb >= 4 && al) {
+            tb_store_out(reinterpret_cast<uint32_t *>(dst + 4 * w), word);
+          } else {
+            for (uint32_t k = 0; k < 4 && k < pb; k++)
+              tb_store_out(dst + 4 * w + k, (uint8_t)(word >> (8 * k)));
+          }
+        }
+        if (C > 1) { /* partial TB CRC: bit i contributes x^(Bt - 1 - i) * x^24 mod g (crc_byte.c:148-182 is linear in the bits) */
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t i = 32 * w + 4 * (uint32_t)q;
+            if (i < 8 * count) { /* four bits and their four table entries (one aligned 16-byte load: Bt, i multiples of 4) */
+              const uint4 pw = *reinterpret_cast<const uint4 *>(pow + (Bt - 4 - i));
+              const uint32_t nib = (word >> (8 * (q >> 1) + ((q & 1) ? 0 : 4))) & 0xfu; /* bit 3 = bit i of the segment */
+              xr ^= (pw.w & (0u - ((nib >> 3) & 1u))) ^ (pw.z & (0u - ((nib >> 2) & 1u))) ^ (pw.y & (0u - ((nib >> 1) & 1u))) ^
+                    (pw.x & (0u - (nib & 1u)));
+            }
+          }
+        }
+      }
+    }
+    for (int off = 32; off; off >>= 1)
+      xr ^= __shfl_xor(xr, off);
+    if (tid == 0) {
+      flags[2] = 0;
+      flags[4] = 0;
+      flags[5] = 0;
+    }
+    __syncthreads();
+    if (lane == 0 && xr)
+      atomicXor(reinterpret_cast<unsigned int *>(&flags[2]), xr);
+    tb_wait_stores(); /* this thread's payload bytes have left for memory */
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t xall = (uint32_t)flags[2];
+      /* returning atomics whose results are waited for: they have been performed -- where every XCD sees them -- before
+       * the count below can be seen */
+      uint32_t o1 = 0;
+      if (C > 1 && ok && xall)
+        o1 = __hip_atomic_fetch_xor(&x.acc[tbi], xall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int o2 = __hip_atomic_exchange(&a.n_iter[job->iter_idx], n_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(o1), "v"(o2) : "memory");
+      tb_wait_stores();
+      const int before = __hip_atomic_fetch_add(&x.done[tbi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (int)C - 1)
+        flags[4] = 1;
+    }
+    __syncthreads();
+    if (!flags[4])
+      return;
+    /* the last segment of the transport block to finish: every sibling's pass count and CRC share are in memory */
+    if (tid < 64) {
+      const int nmi = (int)tj->num_max_iter;
+      int imax = 0, bad = 0;
+      for (uint32_t r = lane; r < C; r += 64) {
+        const int it = __hip_atomic_load(&a.n_iter[tj->seg0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        imax = it > imax ? it : imax;
+        bad |= it > nmi;
+      }
+      for (int off = 32; off; off >>= 1) {
+        const int o = __shfl_xor(imax, off);
+        imax = o > imax ? o : imax;
+        bad |= __shfl_xor(bad, off);
+      }
+      if (lane == 0) {
+        const uint32_t crc = __hip_atomic_exchange(&x.acc[tbi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&x.done[tbi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.tb_abort)
+          __hip_atomic_store(&a.tb_abort[tbi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */
+        const int ackv = !bad && (C == 1 || crc == 0);
+        tb_store_out(x.ack + tbi, (uint8_t)ackv);
+        /* a segment that gave up because a sibling had failed reports numMaxIter + 2 (decoder.c:556-559); which siblings
+         * get that far is a matter of timing, so the per-TB figure is capped at "failed" = numMaxIter + 1 */
+        tb_store_out(x.iter_max + tbi, imax > nmi + 1 ? nmi + 1 : imax);
+        flags[5] = ackv;
+      }
+    }
+    __syncthreads();
+    if (!flags[5]) { /* a block that failed delivers zeros, not the bytes of the segments that happened to decode */
+      uint8_t *dst = x.payload + tj->payload_off;
+      const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+      for (uint32_t k = tid; k < head && k < abytes; k += nt)
+        tb_store_out(dst + k, (uint8_t)0);
+      if (abytes > head) {
+        const uint32_t nw = (abytes - head) >> 2;
+        for (uint32_t w = tid; w < nw; w += nt)
+          tb_store_out(reinterpret_cast<uint32_t *>(dst + head) + w, 0u);
+        for (uint32_t k = head + 4 * nw + tid; k < abytes; k += nt)
+          tb_store_out(dst + k, (uint8_t)0);
+      }
+    }
+  }
+};
+
+__global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a, const tb_rx_fused_args x)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  const ldpc_job_ptr_t job = (ldpc_job_ptr_t)a.jobs + blockIdx.x;
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)job->code;
+  const tb_rx_fused_io io{a, x, job};
+  if (x.stagger_ticks && blockIdx.x >= x.stagger_cus && blockIdx.x < x.stagger_cus * x.stagger_slots) {
+    const long long until = (long long)wall_clock64() + (long long)(blockIdx.x / x.stagger_cus) * (long long)x.stagger_ticks;
+    while ((long long)wall_clock64() < until)
+      __builtin_amdgcn_s_sleep(32);
+  }
+  unsigned long long *tr = x.trace ? x.trace + (size_t)blockIdx.x * 8 : nullptr;
+  if (tr && threadIdx.x == 0) {
+    tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID: wave, simd, cu, sh, se ... */
+    tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* HW_REG_XCC_ID */
+    tr[2] = wall_clock64();
+  }
+  if (io.tb_fused()) {
+    const tb_seg_ptr_t sj = io.seg();
+    const tb_rx_geom g = tb_rx_geometry(sj);
+    tb_rx_dematch_block(g, sj->Qm, x.llr + sj->llr_off, x.harq + sj->harq_off, const_cast<int8_t *>(a.llr) + sj->l_off,
+                        reinterpret_cast<int16_t *>(fsm));
+    /* the decoder input is read back by other waves of this workgroup only: workgroup scope (see ldpc_dec_fast_pull_kernel) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (tr && threadIdx.x == 0)
+    tr[3] = wall_clock64();
+  const int n_iter = ldpc_dec_fast_block(fsm, code, io);
+  if (tr && threadIdx.x == 0) {
+    tr[5] = wall_clock64();
+    tr[6] = (unsigned long long)n_iter;
+  }
+  if (!io.tb_fused() && threadIdx.x == 0)
+    a.n_iter[(uint32_t)job->iter_idx] = n_iter;
+}
+
+hipError_t tb_rx_fused_init(void)
+{
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x, int n_threads, int lds_bytes, uint32_t n_jobs, hipStream_t s)
+{
+  if (n_jobs == 0)
+    return hipSuccess;
+  if (!a.jobs || !x.segs || !x.tbs)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(tb_rx_fused_kernel, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  return hipGetLastError();
+}

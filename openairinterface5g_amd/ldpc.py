@@ -22,6 +22,7 @@ nrLDPC_outMode_BIT, nrLDPC_outMode_BITINT8, nrLDPC_outMode_LLRINT8 = 0, 1, 2
 # coding_defs.h:33-36
 CRC24_A, CRC24_B, CRC16, CRC8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HARQ_DEVICE, MEM_HARQ_LIBRARY = 2, 4   # OR-ed into mem for nrLDPC_hip_ulsch_decode: where the soft buffers live
 
 NCOLS = {(1, 13): 68, (1, 23): 35, (1, 89): 27, (2, 15): 52, (2, 13): 32, (2, 23): 17}
 LIFT_SIZES = sorted(a * (1 << j) for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * (1 << j) <= 384)
@@ -367,7 +368,8 @@ class nrLDPC_hip_tb_batch_t(C.Structure):
 
 
 EXPORTS += ["nrLDPC_hip_dlsch_encode", "nrLDPC_hip_ulsch_decode", "nrLDPC_hip_segmentation", "nrLDPC_hip_get_E",
-            "nrLDPC_hip_get_R_ldpc_decoder"]
+            "nrLDPC_hip_get_R_ldpc_decoder", "nrLDPC_hip_harq_release", "nrLDPC_hip_harq_release_all", "nrLDPC_hip_harq_read",
+            "nrLDPC_hip_host_alloc", "nrLDPC_hip_host_free", "nrLDPC_hip_host_register", "nrLDPC_hip_host_unregister"]
 HARQ_STRIDE = 66 * 384
 
 
@@ -381,7 +383,46 @@ def _tb_lib():
     L.nrLDPC_hip_get_E.restype = C.c_uint32
     L.nrLDPC_hip_get_R_ldpc_decoder.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32), C.c_int32]
     L.nrLDPC_hip_get_R_ldpc_decoder.restype = C.c_int32
+    L.nrLDPC_hip_harq_release.argtypes = [C.c_uint64]
+    L.nrLDPC_hip_harq_read.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.nrLDPC_hip_host_alloc.argtypes = [C.c_uint64]
+    L.nrLDPC_hip_host_alloc.restype = C.c_void_p
+    L.nrLDPC_hip_host_free.argtypes = [C.c_void_p]
+    L.nrLDPC_hip_host_free.restype = None
+    L.nrLDPC_hip_host_register.argtypes = [C.c_void_p, C.c_uint64]
+    L.nrLDPC_hip_host_unregister.argtypes = [C.c_void_p]
     return L
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory from nrLDPC_hip_host_alloc (what a C caller without the HIP runtime
+    uses): the GPU reads it in place.  Keep the object alive while `a` is in use."""
+
+    def __init__(self, shape, dtype):
+        self._lib = _tb_lib()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self._lib.nrLDPC_hip_host_alloc(max(n, 1))
+        if not self._p:
+            raise RuntimeError("nrLDPC_hip_host_alloc failed: " + self._lib.nrLDPC_hip_last_error().decode())
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._p)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._lib.nrLDPC_hip_host_free(self._p)
+            self._p = None
+
+
+def harq_read(harq_id, n, first=0):
+    """int16[n] of the soft buffers the library keeps for block `harq_id` (MEM_HARQ_LIBRARY); waits for the GPU."""
+    out = np.zeros(n, np.int16)
+    _check(_tb_lib().nrLDPC_hip_harq_read(harq_id, out.ctypes.data, first, n), "nrLDPC_hip_harq_read")
+    return out
+
+
+def harq_release(harq_id=None):
+    L = _tb_lib()
+    return L.nrLDPC_hip_harq_release_all() if harq_id is None else L.nrLDPC_hip_harq_release(harq_id)
 
 
 def nr_segmentation(B, BG):
@@ -429,13 +470,19 @@ def dlsch_encode_host(tbs, payloads):
     return [coded[co[i]:co[i] + tbs[i]["G"]].copy() for i in range(len(tbs))]
 
 
-def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None):
+def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=None, pinned=False):
     """RX chain for a batch of transport blocks, host buffers.  llrs: list of int16[G]; harq: int16 array
     [total segments, HARQ_STRIDE] holding the soft buffers of all TBs back to back (updated in place); each tb dict
     may carry 'round' and 'llrLen' ('llrLen' is updated).  harq_off: explicit int16 offsets of the TBs' soft buffers in
-    `harq` (any order, gaps allowed) instead of back to back.  Returns (payloads, ack bool[n], iter_max int32[n])."""
+    `harq` (any order, gaps allowed) instead of back to back.  Returns (payloads, ack bool[n], iter_max int32[n]).
+    Soft buffers on the GPU while everything else stays on the host (what nr_ulsch_decoding's caller needs: the LLRs of a
+    slot arrive in host memory, d[r] persists per HARQ process): `harq` a torch int16 CUDA tensor (MEM_HARQ_DEVICE), or
+    harq=None with harq_ids = one id per TB (MEM_HARQ_LIBRARY: the library keeps them; harq_read() looks at them).
+    pinned: the LLR array goes into page-locked memory (nrLDPC_hip_host_alloc) and is pulled by the GPU in place."""
     L = _tb_lib()
     n = len(tbs)
+    if harq_ids is not None or not isinstance(harq, np.ndarray):
+        return _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned)
     po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
     co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
     segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
@@ -445,7 +492,9 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None):
         assert len(ho) == n and all(o + c * HARQ_STRIDE <= harq.size for o, c in zip(ho, segs))
     assert harq.dtype == np.int16 and harq.flags.c_contiguous and harq.size >= max(o + c * HARQ_STRIDE for o, c in zip(ho, segs))
     pay = np.zeros(int(po[-1]) + 16, np.uint8)
-    llr = np.zeros(int(co[-1]) + 16, np.int16)
+    keep = PinnedArray(int(co[-1]) + 16, np.int16) if pinned else None
+    llr = keep.a if pinned else np.zeros(int(co[-1]) + 16, np.int16)
+    llr[:] = 0
     for i, x in enumerate(llrs):
         llr[co[i]:co[i] + tbs[i]["G"]] = x
     ack = np.zeros(n, np.uint8)
@@ -454,6 +503,36 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None):
     b = nrLDPC_hip_tb_batch_t(n_tb=n, tb=arr, payload=pay.ctypes.data, coded=llr.ctypes.data, harq=harq.ctypes.data,
                               harq_stride=HARQ_STRIDE, ack=ack.ctypes.data, iter_max=itm.ctypes.data, mem=MEM_HOST,
                               stream=None)
+    _check(L.nrLDPC_hip_ulsch_decode(C.byref(b)), "nrLDPC_hip_ulsch_decode")
+    for i, t in enumerate(tbs):
+        t["llrLen"] = arr[i].llrLen
+    return [pay[po[i]:po[i] + tbs[i]["A"] // 8].copy() for i in range(n)], ack.astype(bool), itm
+
+
+def _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned):
+    """host payload / LLRs / verdicts with the soft buffers resident on the GPU (see ulsch_decode_host)"""
+    n = len(tbs)
+    po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
+    segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
+    if harq_ids is not None:
+        assert harq is None and len(harq_ids) == n
+        ho, hp, mem = list(harq_ids), None, MEM_HOST | MEM_HARQ_LIBRARY
+    else:
+        ho = list(harq_off) if harq_off is not None else list(np.cumsum([0] + [c * HARQ_STRIDE for c in segs])[:n])
+        assert harq.is_cuda and harq.is_contiguous() and harq.numel() >= max(o + c * HARQ_STRIDE for o, c in zip(ho, segs))
+        hp, mem = harq.data_ptr(), MEM_HOST | MEM_HARQ_DEVICE
+    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    keep = PinnedArray(int(co[-1]) + 16, np.int16) if pinned else None
+    llr = keep.a if pinned else np.zeros(int(co[-1]) + 16, np.int16)
+    llr[:] = 0
+    for i, x in enumerate(llrs):
+        llr[co[i]:co[i] + tbs[i]["G"]] = x
+    ack = np.zeros(n, np.uint8)
+    itm = np.zeros(n, np.int32)
+    arr = _tb_array(tbs, po, co, ho, numMaxIter)
+    b = nrLDPC_hip_tb_batch_t(n_tb=n, tb=arr, payload=pay.ctypes.data, coded=llr.ctypes.data, harq=hp,
+                              harq_stride=HARQ_STRIDE, ack=ack.ctypes.data, iter_max=itm.ctypes.data, mem=mem, stream=None)
     _check(L.nrLDPC_hip_ulsch_decode(C.byref(b)), "nrLDPC_hip_ulsch_decode")
     for i, t in enumerate(tbs):
         t["llrLen"] = arr[i].llrLen
@@ -482,23 +561,42 @@ def dlsch_encode_device(tbs, payload, coded, stream=None):
     _check(L.nrLDPC_hip_dlsch_encode(C.byref(b)), "nrLDPC_hip_dlsch_encode")
 
 
+def _ptr(x):
+    """address of a torch tensor / numpy array / PinnedArray, None for None"""
+    if x is None:
+        return None
+    if isinstance(x, PinnedArray):
+        return x.a.ctypes.data
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
 class PreparedTbBatch:
     """A transport-block batch descriptor built once and submitted many times (slot after slot with the same
     allocation): keeps the ctypes marshalling out of the caller's per-slot path.  `encode()` / `decode()` are the bare
-    C calls nrLDPC_hip_dlsch_encode / nrLDPC_hip_ulsch_decode (asynchronous on the batch's stream)."""
+    C calls nrLDPC_hip_dlsch_encode / nrLDPC_hip_ulsch_decode (asynchronous on the batch's stream with device buffers,
+    synchronous with host buffers).  Buffers: torch CUDA tensors (mem = MEM_DEVICE, the default), or numpy arrays /
+    PinnedArray objects with mem = MEM_HOST, optionally | MEM_HARQ_DEVICE (harq a CUDA tensor) or | MEM_HARQ_LIBRARY
+    (harq None, harq_ids = one id per transport block)."""
 
-    def __init__(self, tbs, payload, coded_or_llr, harq=None, ack=None, iter_max=None, numMaxIter=8, stream=None):
-        import torch
+    def __init__(self, tbs, payload, coded_or_llr, harq=None, ack=None, iter_max=None, numMaxIter=8, stream=None, mem=MEM_DEVICE,
+                 harq_ids=None):
         self._lib = _tb_lib()
         po, co, ho, _ = tb_layout(tbs)
         self._keep = (payload, coded_or_llr, harq, ack, iter_max)
-        self.arr = _tb_array(tbs, po, co, ho if harq is not None else None, numMaxIter)
-        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if harq_ids is not None:
+            assert mem & MEM_HARQ_LIBRARY and len(harq_ids) == len(tbs)
+            ho = list(harq_ids)
+        self.arr = _tb_array(tbs, po, co, ho if (harq is not None or harq_ids is not None) else None, numMaxIter)
+        s = None
+        if mem & MEM_DEVICE:
+            import torch
+            s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         self.batch = nrLDPC_hip_tb_batch_t(
-            n_tb=len(tbs), tb=self.arr, payload=payload.data_ptr(), coded=coded_or_llr.data_ptr(),
-            harq=None if harq is None else harq.data_ptr(), harq_stride=0 if harq is None else HARQ_STRIDE,
-            ack=None if ack is None else ack.data_ptr(), iter_max=None if iter_max is None else iter_max.data_ptr(),
-            mem=MEM_DEVICE, stream=s)
+            n_tb=len(tbs), tb=self.arr, payload=_ptr(payload), coded=_ptr(coded_or_llr),
+            harq=_ptr(harq), harq_stride=0 if (harq is None and harq_ids is None) else HARQ_STRIDE,
+            ack=_ptr(ack), iter_max=_ptr(iter_max), mem=mem, stream=s)
 
     def encode(self):
         _check(self._lib.nrLDPC_hip_dlsch_encode(C.byref(self.batch)), "nrLDPC_hip_dlsch_encode")
@@ -510,17 +608,24 @@ class PreparedTbBatch:
     # two warm-up calls there; a call whose descriptors repeat only enqueues kernels and memsets.
 
 
-def ulsch_decode_device(tbs, llr, harq, payload, ack, iter_max, numMaxIter=8, stream=None):
+def ulsch_decode_device(tbs, llr, harq, payload, ack, iter_max, numMaxIter=8, stream=None, harq_ids=None):
     """llr: torch int16 [>= co[-1]], harq: torch int16 [>= ho[-1]], payload: torch uint8 [>= po[-1]] (out),
-    ack: torch uint8 [n], iter_max: torch int32 [n].  Asynchronous; tb dicts get their llrLen updated."""
+    ack: torch uint8 [n], iter_max: torch int32 [n].  Asynchronous; tb dicts get their llrLen updated.
+    harq=None with harq_ids: the library keeps the soft buffers (MEM_HARQ_LIBRARY)."""
     import torch
     L = _tb_lib()
     po, co, ho, _ = tb_layout(tbs)
-    assert llr.is_cuda and llr.dtype == torch.int16 and harq.dtype == torch.int16 and harq.numel() >= ho[-1]
+    assert llr.is_cuda and llr.dtype == torch.int16
+    mem = MEM_DEVICE
+    if harq_ids is not None:
+        assert harq is None and len(harq_ids) == len(tbs)
+        ho, mem = list(harq_ids), MEM_DEVICE | MEM_HARQ_LIBRARY
+    else:
+        assert harq.dtype == torch.int16 and harq.numel() >= ho[-1]
     arr = _tb_array(tbs, po, co, ho, numMaxIter)
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    b = nrLDPC_hip_tb_batch_t(n_tb=len(tbs), tb=arr, payload=payload.data_ptr(), coded=llr.data_ptr(), harq=harq.data_ptr(),
-                              harq_stride=HARQ_STRIDE, ack=ack.data_ptr(), iter_max=iter_max.data_ptr(), mem=MEM_DEVICE,
+    b = nrLDPC_hip_tb_batch_t(n_tb=len(tbs), tb=arr, payload=payload.data_ptr(), coded=llr.data_ptr(), harq=_ptr(harq),
+                              harq_stride=HARQ_STRIDE, ack=ack.data_ptr(), iter_max=iter_max.data_ptr(), mem=mem,
                               stream=s)
     _check(L.nrLDPC_hip_ulsch_decode(C.byref(b)), "nrLDPC_hip_ulsch_decode")
     for i, t in enumerate(tbs):

@@ -144,6 +144,87 @@ def decode_sharded(BG: int, Z: int, R: int, llr_root, n_blocks: int, numMaxIter:
 
 
 # ---- a slot's transport blocks (BASELINE configs[4]) -------------------------------------------------------------------
+class _DistTransport:
+    """point-to-point through torch.distributed (nccl = RCCL on ROCm, gloo on CPU)"""
+
+    def op(self, kind, tensor, peer, group):
+        import torch.distributed as dist
+        return dist.P2POp(dist.isend if kind == "send" else dist.irecv, tensor, peer, group)
+
+    def batch(self, ops):
+        import torch.distributed as dist
+        return dist.batch_isend_irecv(ops) if ops else []
+
+
+class CopyTransport:
+    """Stand-in for a backend that cannot send to its own rank (gloo): the sends and receives of a loopback run are
+    matched in posting order -- what NCCL does with the operations of one group call -- and executed as copies.  For the
+    CPU tests of the loopback protocol; the GPU test drives the same protocol through RCCL."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self):
+        self.pending = []
+
+    def op(self, kind, tensor, peer, group):
+        return (kind, tensor)
+
+    def batch(self, ops):
+        for kind, t in ops:
+            if kind == "send":
+                self.pending.append(t)
+            else:
+                src = self.pending.pop(0)
+                assert src.numel() == t.numel() and src.dtype == t.dtype, "send / receive mismatch"
+                t.copy_(src)
+        return [self._Done()]
+
+
+class _Share:
+    """What ONE rank holds of a slot: its contiguous range of whole transport blocks, the HARQ soft buffers of those blocks
+    (they stay here from round to round), its receive buffer for the LLRs (peers) and its result buffers."""
+
+    def __init__(self, parent, rank: int):
+        import torch
+        p = parent
+        self.p, self.rank = p, rank
+        self.t0, self.t1 = p.cut[rank], p.cut[rank + 1]
+        n_h = int(p.ho[self.t1] - p.ho[self.t0])
+        self.harq = torch.zeros((max(n_h, 1),), dtype=torch.int16, device=p.device)
+        n_loc = self.t1 - self.t0
+        n_llr = max(int(p.co[self.t1] - p.co[self.t0]), 1)
+        self.llr = None if rank == p.root else torch.empty((n_llr,), dtype=torch.int16, device=p.device)
+        self.pay = torch.zeros((max(int(p.po[self.t1] - p.po[self.t0]), 1),), dtype=torch.uint8, device=p.device)
+        self.ack = torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=p.device)
+        self.itm = torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=p.device)
+        self.prepared = {}
+
+    def lo(self, off, i):
+        return int(off[i] - off[self.t0])
+
+    def decode_chunk(self, a: int, b: int, llr, rnd: int):
+        """transport blocks [a, b) (global indices, inside this share's range) through the chain; llr = this share's LLRs"""
+        if b <= a:
+            return
+        p = self.p
+        views = (llr[self.lo(p.co, a):], self.harq[self.lo(p.ho, a):], self.pay[self.lo(p.po, a):], self.ack[a - self.t0:], self.itm[a - self.t0:])
+        tbs = p.tbs[a:b]
+        if p.decode_fn is not None:
+            for t in tbs:
+                t["round"] = rnd
+            p.decode_fn(tbs, *views, p.numMaxIter)
+            return
+        # the descriptor array is marshalled once per (LLR buffer, chunk, round) and resubmitted slot after slot
+        key = (llr.data_ptr(), a, b, rnd)
+        if key not in self.prepared:
+            for t in tbs:
+                t["round"] = rnd
+            self.prepared[key] = p.ldpc.PreparedTbBatch(tbs, views[2], views[0], views[1], views[3], views[4], p.numMaxIter)
+        self.prepared[key].decode()
+
+
 class ShardedUlsch:
     """A slot's PUSCH transport blocks decoded on the GPUs of all ranks: the UL-SCH chain of the library
     (nrLDPC_hip_ulsch_decode: de-interleave, rate de-match with HARQ combining, LDPC decode with CRC stop, reassembly,
@@ -157,25 +238,32 @@ class ShardedUlsch:
     flight together, nr_ulsch_decoding.c:435-468): the root posts the LLR sends of all chunks, chunk-major, and decodes
     its own range while they drain; a peer posts all its receives, decodes chunk k as soon as it has arrived -- while
     chunks k+1.. are still on the links -- and returns that chunk's payload / ACKs / pass counts at once; the root's
-    receives of the results were posted behind its sends.  Nothing in it waits on the host with the nccl backend (a
-    work's wait() orders streams); with gloo (CPU tests) the same calls block."""
+    receives of the results were posted behind its sends.  With the nccl backend a work's wait() orders streams; with
+    gloo (CPU tests) the same calls block.  On a peer every chunk is a call of its own into the library, whose plan cache
+    (csrc/tb_api.inc.cpp TbPlanCache) holds them side by side: from the second slot on no chunk call builds or uploads
+    anything.
+
+    loopback = V > 1 (one process, world size 1): the slot is cut for V virtual ranks, all of them this process, and every
+    LLR range / result range of the virtual peers travels by a real point-to-point pair -- isend and irecv to this very
+    rank inside one batch_isend_irecv, the same views, chunking and posting order as with V processes.  That is how the
+    send / receive path is exercised on a box with one GPU (RCCL executes ncclSend / ncclRecv to self; the peers' chain
+    calls run on the same GPU, one after the other)."""
 
     def __init__(self, tbs: Sequence[dict], root: int = 0, group=None, device=None, numMaxIter: int = 8,
-                 decode_fn: Optional[Callable] = None, chunks: int = 3):
+                 decode_fn: Optional[Callable] = None, chunks: int = 3, loopback: int = 0, transport=None):
         import torch
         from . import ldpc
         self.ldpc, self.root, self.group, self.numMaxIter, self.decode_fn = ldpc, root, group, numMaxIter, decode_fn
         self.rank, self.world = _rank_world(group)
+        self.loopback = loopback > 1
+        if self.loopback:
+            assert self.world == 1 and root == 0, "loopback: one process plays every rank"
+            self.world = int(loopback)               # virtual ranks from here on
         self.tbs = [dict(t) for t in tbs]
         self.po, self.co, self.ho, self.segs = ldpc.tb_layout(self.tbs)
         costs = [tb_cost(t) for t in self.tbs]
         self.cut = partition_transport_blocks(costs, self.world)
-        t0, t1 = self.cut[self.rank], self.cut[self.rank + 1]
-        self.t0, self.t1 = t0, t1
-        self.local = self.tbs[t0:t1]          # offsets of the local layout = global offsets minus the range start
         self.device = torch.device("cpu") if device is None else device
-        n_h = int(self.ho[t1] - self.ho[t0])
-        self.harq = torch.zeros((max(n_h, 1),), dtype=torch.int16, device=self.device)
         self.llr_ranges = [(int(self.co[a]), int(self.co[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.pay_ranges = [(int(self.po[a]), int(self.po[b])) for a, b in zip(self.cut[:-1], self.cut[1:])]
         self.tb_ranges = list(zip(self.cut[:-1], self.cut[1:]))
@@ -185,90 +273,105 @@ class ShardedUlsch:
         for r, (a, b) in enumerate(self.tb_ranges):
             n = 1 if (r == root or self.world == 1) else max(1, min(chunks, b - a))
             self.chunk_cut.append([a + c for c in partition_transport_blocks(costs[a:b], n)])
-        self._buf, self._prepared = None, {}
+        self.shares = {r: _Share(self, r) for r in (range(self.world) if self.loopback else [self.rank])}
+        me = self.shares[self.rank]
+        self.t0, self.t1, self.harq = me.t0, me.t1, me.harq     # (this rank's own share, as before)
+        self._all = None
+        self.p2p_bytes = 0            # bytes this process has put on point-to-point sends (LLRs out / results back)
+        self.transport = _DistTransport() if transport is None else transport
 
-    # ---- one chunk of this rank's range through the chain --------------------------------------------------------------
-    def _decode_chunk(self, a: int, b: int, llr, rnd: int):
-        """transport blocks [a, b) (global indices, inside this rank's range); llr = this rank's LLR buffer"""
-        if b <= a:
-            return
-        pay, ack, itm = self._buf["pay"], self._buf["ack"], self._buf["itm"]
-        lo = lambda off, i: int(off[i] - off[self.t0])
-        views = (llr[lo(self.co, a):], self.harq[lo(self.ho, a):], pay[lo(self.po, a):], ack[a - self.t0:], itm[a - self.t0:])
-        tbs = self.tbs[a:b]
-        if self.decode_fn is not None:
-            for t in tbs:
-                t["round"] = rnd
-            self.decode_fn(tbs, *views, self.numMaxIter)
-            return
-        # the descriptor array is marshalled once per (LLR buffer, chunk, round) and resubmitted slot after slot
-        key = (llr.data_ptr(), a, b, rnd)
-        if key not in self._prepared:
-            for t in tbs:
-                t["round"] = rnd
-            self._prepared[key] = self.ldpc.PreparedTbBatch(tbs, views[2], views[0], views[1], views[3], views[4], self.numMaxIter)
-        self._prepared[key].decode()
+    def _sent(self, t):
+        self.p2p_bytes += t.numel() * t.element_size()
+        return t
 
     def decode(self, llr_root, rnd: int = 0):
         """Returns (payload uint8 flat in the tb_layout offsets, ack uint8[n_tb], iter_max int32[n_tb]) on root,
         (None, None, None) elsewhere."""
         import torch
         import torch.distributed as dist
-        n_loc = self.t1 - self.t0
+        T = self.transport
         root, world, rank = self.root, self.world, self.rank
-        if self._buf is None:     # persistent local buffers: the per-slot path allocates nothing
-            n_llr = max(int(self.co[self.t1] - self.co[self.t0]), 1)
-            self._buf = dict(llr=None if rank == root else torch.empty((n_llr,), dtype=torch.int16, device=self.device),
-                             pay=torch.zeros((max(int(self.po[self.t1] - self.po[self.t0]), 1),), dtype=torch.uint8, device=self.device),
-                             ack=torch.zeros((max(n_loc, 1),), dtype=torch.uint8, device=self.device),
-                             itm=torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device))
-            if rank == root and world > 1:   # assembled results of the whole slot
-                self._buf.update(pay_all=torch.zeros((int(self.po[-1]),), dtype=torch.uint8, device=self.device),
-                                 ack_all=torch.zeros((len(self.tbs),), dtype=torch.uint8, device=self.device),
-                                 itm_all=torch.zeros((len(self.tbs),), dtype=torch.int32, device=self.device))
-        pay, ack, itm = self._buf["pay"], self._buf["ack"], self._buf["itm"]
+        me = self.shares[rank]
+        n_loc = me.t1 - me.t0
         if world == 1:
-            self._decode_chunk(self.t0, self.t1, llr_root, rnd)
+            me.decode_chunk(me.t0, me.t1, llr_root, rnd)
             total = int(self.po[-1])
-            return (pay[:total] if pay.numel() >= total else torch.cat([pay, pay.new_zeros(total - pay.numel())])), \
-                ack[:len(self.tbs)], itm[:len(self.tbs)]
+            return (me.pay[:total] if me.pay.numel() >= total else torch.cat([me.pay, me.pay.new_zeros(total - me.pay.numel())])), \
+                me.ack[:len(self.tbs)], me.itm[:len(self.tbs)]
         g = self.group
-        peer = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        loop = self.loopback
+        peer = (lambda r: 0) if loop else ((lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r))
         n_rounds = max(len(c) - 1 for c in self.chunk_cut)
+        live = lambda r, k: r != root and k + 1 < len(self.chunk_cut[r]) and self.chunk_cut[r][k + 1] > self.chunk_cut[r][k]
+
+        def llr_recv_op(sh, k):       # a peer's receive of its chunk k
+            c = self.chunk_cut[sh.rank]
+            return T.op("recv", sh.llr[sh.lo(self.co, c[k]):sh.lo(self.co, c[k + 1])], peer(root), g)
+
+        def result_send_ops(sh, k):   # a peer's results of chunk k
+            a, b = self.chunk_cut[sh.rank][k], self.chunk_cut[sh.rank][k + 1]
+            return [T.op("send", self._sent(sh.pay[sh.lo(self.po, a):sh.lo(self.po, b)]), peer(root), g),
+                    T.op("send", self._sent(sh.ack[a - sh.t0:b - sh.t0]), peer(root), g),
+                    T.op("send", self._sent(sh.itm[a - sh.t0:b - sh.t0]), peer(root), g)]
+
         if rank == root:
-            works = []
+            if self._all is None:     # assembled results of the whole slot (persistent: the per-slot path allocates nothing)
+                self._all = (torch.zeros((int(self.po[-1]),), dtype=torch.uint8, device=self.device),
+                             torch.zeros((len(self.tbs),), dtype=torch.uint8, device=self.device),
+                             torch.zeros((len(self.tbs),), dtype=torch.int32, device=self.device))
+            pay_all, ack_all, itm_all = self._all
+
+            def result_recv_ops(r, k):
+                a, b = self.chunk_cut[r][k], self.chunk_cut[r][k + 1]
+                return [T.op("recv", pay_all[int(self.po[a]):int(self.po[b])], peer(r), g),
+                        T.op("recv", ack_all[a:b], peer(r), g), T.op("recv", itm_all[a:b], peer(r), g)]
+
+            works, arrived = [], {}
             for k in range(n_rounds):                                  # LLRs out, chunk-major: every link busy at once
-                ops = [dist.P2POp(dist.isend, llr_root[int(self.co[c[k]]):int(self.co[c[k + 1]])], peer(r), g)
-                       for r, c in enumerate(self.chunk_cut) if r != root and k + 1 < len(c) and c[k + 1] > c[k]]
-                works += dist.batch_isend_irecv(ops) if ops else []
-            self._decode_chunk(self.t0, self.t1, llr_root, rnd)        # own range, while the sends drain
-            pay_all, ack_all, itm_all = self._buf["pay_all"], self._buf["ack_all"], self._buf["itm_all"]
-            for k in range(n_rounds):                                  # results back, in the order the peers produce them
                 ops = []
-                for r, c in enumerate(self.chunk_cut):
-                    if r != root and k + 1 < len(c) and c[k + 1] > c[k]:
-                        a, b = c[k], c[k + 1]
-                        ops += [dist.P2POp(dist.irecv, pay_all[int(self.po[a]):int(self.po[b])], peer(r), g),
-                                dist.P2POp(dist.irecv, ack_all[a:b], peer(r), g),
-                                dist.P2POp(dist.irecv, itm_all[a:b], peer(r), g)]
-                works += dist.batch_isend_irecv(ops) if ops else []
+                for r in range(world):
+                    if live(r, k):
+                        c = self.chunk_cut[r]
+                        ops.append(T.op("send", self._sent(llr_root[int(self.co[c[k]]):int(self.co[c[k + 1]])]), peer(r), g))
+                        if loop:                                        # ... and, playing peer r, its receive (same order)
+                            ops.append(llr_recv_op(self.shares[r], k))
+                w = T.batch(ops)
+                works += w
+                arrived[k] = w
+            me.decode_chunk(me.t0, me.t1, llr_root, rnd)               # own range, while the sends drain
+            if loop:
+                # the virtual peers' part of the protocol, in the order real peers would run it: chunk k decoded when it has
+                # arrived, its results sent at once -- with the root's matching receives in the same batch
+                for k in range(n_rounds):
+                    for w in arrived[k]:
+                        w.wait()
+                    for r in range(world):
+                        if live(r, k):
+                            sh, c = self.shares[r], self.chunk_cut[r]
+                            sh.decode_chunk(c[k], c[k + 1], sh.llr, rnd)
+                            ops = []
+                            for s_op, r_op in zip(result_send_ops(sh, k), result_recv_ops(r, k)):
+                                ops += [s_op, r_op]
+                            works += T.batch(ops)
+            else:
+                for k in range(n_rounds):                              # results back, in the order the peers produce them
+                    ops = []
+                    for r in range(world):
+                        if live(r, k):
+                            ops += result_recv_ops(r, k)
+                    works += T.batch(ops)
             if n_loc:
-                pay_all[int(self.po[self.t0]):int(self.po[self.t1])] = pay[:int(self.po[self.t1] - self.po[self.t0])]
-                ack_all[self.t0:self.t1] = ack[:n_loc]
-                itm_all[self.t0:self.t1] = itm[:n_loc]
+                pay_all[int(self.po[me.t0]):int(self.po[me.t1])] = me.pay[:int(self.po[me.t1] - self.po[me.t0])]
+                ack_all[me.t0:me.t1] = me.ack[:n_loc]
+                itm_all[me.t0:me.t1] = me.itm[:n_loc]
             for w in works:
                 w.wait()
             return pay_all, ack_all, itm_all
         # ---- a peer ----
-        llr = self._buf["llr"]
         c = self.chunk_cut[rank]
-        lo = lambda off, i: int(off[i] - off[self.t0])
         recvs = []
         for k in range(len(c) - 1):
-            if c[k + 1] > c[k]:
-                recvs.append(dist.batch_isend_irecv([dist.P2POp(dist.irecv, llr[lo(self.co, c[k]):lo(self.co, c[k + 1])], peer(root), g)]))
-            else:
-                recvs.append([])
+            recvs.append(T.batch([llr_recv_op(me, k)]) if c[k + 1] > c[k] else [])
         sends = []
         for k in range(len(c) - 1):
             a, b = c[k], c[k + 1]
@@ -276,10 +379,8 @@ class ShardedUlsch:
                 continue
             for w in recvs[k]:
                 w.wait()
-            self._decode_chunk(a, b, llr, rnd)
-            sends += dist.batch_isend_irecv([dist.P2POp(dist.isend, pay[lo(self.po, a):lo(self.po, b)], peer(root), g),
-                                             dist.P2POp(dist.isend, ack[a - self.t0:b - self.t0], peer(root), g),
-                                             dist.P2POp(dist.isend, itm[a - self.t0:b - self.t0], peer(root), g)])
+            me.decode_chunk(a, b, me.llr, rnd)
+            sends += T.batch(result_send_ops(me, k))
         for w in sends:
             w.wait()
         return None, None, None

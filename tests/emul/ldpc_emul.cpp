@@ -335,3 +335,34 @@ extern "C" int ldpc_emul_desc_edges(int BG, int Z, int R, int *dims /*nrows,ncol
   }
   return 0;
 }
+
+/* ---- UL-SCH front step of one segment (tb_rx_core.h: the de-matching kernel and the fused segment kernel's prologue) ------
+ * The workgroup's phases, thread after thread; the LDS image is a heap buffer of exactly the size the kernels reserve. */
+#include "../../openairinterface5g_amd/csrc/tb_rx_core.h"
+#include "../../openairinterface5g_amd/csrc/nr_coding_host.h"
+
+extern "C" int tb_emul_rx_dematch(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_t C, uint32_t F, uint32_t K, int rv, uint32_t E, uint32_t Qm,
+                                  uint32_t num_llr, int clear, int nt, const int16_t *f, int16_t *w, int8_t *l)
+{
+  nr_hip_rm_t rm;
+  if (nr_hip_rate_match_geometry(Tbslbrm, BG, Zc, C, F, K, rv, E, &rm) != 0)
+    return -1;
+  tb_rx_seg_job j;
+  memset(&j, 0, sizeof(j));
+  j.E = E; j.Qm = Qm; j.Ncb = rm.Ncb; j.Foffset = rm.Foffset; j.Fin = rm.Fin; j.V = rm.V; j.rank0 = rm.rank0;
+  j.clear = clear ? 1u : 0u;
+  j.K = K; j.F = F; j.Z = Zc; j.num_llr = num_llr;
+  const tb_rx_geom g = tb_rx_geometry(&j);
+  std::vector<tb_u32x4> lds(g.span / 8 + 1);
+  memset(lds.data(), 0x5a, lds.size() * sizeof(tb_u32x4)); /* poison: phase Z must initialise what is read */
+  int16_t *e_lds = reinterpret_cast<int16_t *>(lds.data());
+  for (int tid = 0; tid < nt; tid++)
+    tb_rx_phase_zero(g, e_lds, l, (uint32_t)tid, (uint32_t)nt);
+  const uint32_t nlaps = tb_rx_laps(g);
+  for (uint32_t lap = 0; lap < nlaps; lap++)
+    for (int tid = 0; tid < nt; tid++)
+      tb_rx_phase_scatter_lap_qm(Qm, g, f, e_lds, lap, nlaps, (uint32_t)tid, (uint32_t)nt);
+  for (int tid = 0; tid < nt; tid++)
+    tb_rx_phase_stream(g, e_lds, w, l, (uint32_t)tid, (uint32_t)nt);
+  return (int)g.span;
+}

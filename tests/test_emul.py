@@ -78,3 +78,47 @@ def test_encoder_every_code(emul):
                     out[:] = 7
                     n = fn(BG, Z, Kb, info.ctypes.data, out.ctypes.data)
                     assert n == ref.size and np.array_equal(out[:n], ref), (BG, Z, Kb, fn.__name__)
+
+
+def test_rx_dematch_phases_against_the_oracle(emul):
+    """tb_rx_core.h (the de-matching kernel = the fused segment kernel's prologue), a workgroup's threads walked phase by
+    phase: soft buffer and int8 decoder input equal nr_deinterleaving_ldpc -> nr_rate_matching_ldpc_rx -> the caller's
+    pack as the oracle restates them -- first transmission and a combining round on a dirty buffer, rv 0-3, LBRM,
+    repetition (several laps), fillers, every Qm, unaligned soft buffers (scalar tail path)."""
+    emul.tb_emul_rx_dematch.argtypes = [C.c_uint32, C.c_int] + [C.c_uint32] * 4 + [C.c_int] + [C.c_uint32] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 3
+    rng = np.random.default_rng(77)
+    cases = 0
+    for BG, A, lbrm in ((1, 30000, 0), (1, 30000, 24000), (2, 3000, 0), (1, 9000, 0), (2, 640, 0), (1, 100000, 150000)):
+        s = O.segmentation(None, O.len_with_crc(1, A), BG)
+        Z, K, F, Cn = s["Z"], s["K"], s["F"], s["C"]
+        N = (66 if BG == 1 else 50) * Z
+        for Qm in (2, 4, 6, 8):
+            for rv in range(4):
+                for rate in (0.25, 0.6, 0.92, 0.08):                # 0.08: E > Ncb, several laps
+                    E = max(Qm * 4, int((K - F) / rate) // Qm * Qm)
+                    R, _ = O.get_R(rv, E, BG, Z, 0, 0)
+                    ncols = O.NCOLS[(BG, R)]
+                    f = rng.integers(-300, 300, E).astype(np.int16)
+                    for clear, misalign in ((1, 0), (0, 0), (0, 1)):
+                        w0 = rng.integers(-2000, 2000, 66 * 384 + 16).astype(np.int16)
+                        Ncb = N if not lbrm else min(N, (3 * lbrm // (2 * Cn)))
+                        w0[misalign + Ncb:misalign + N] = 0      # the reference's d[r] is calloc'ed and never written behind Ncb
+                        # oracle: the reference's three steps
+                        e = O.deinterleave(E, Qm, f)
+                        d_ref = w0[misalign:misalign + N].copy()
+                        rc, d_ref = O.rate_match_rx(lbrm, BG, Z, d_ref, e, Cn, rv, clear, E, F, K - F - 2 * Z)
+                        assert rc == 0
+                        l_ref = O.llr_prepack(d_ref, BG, Z, K, F, ncols)
+                        # emulated workgroup
+                        w = w0.copy()
+                        l = np.full(ncols * Z + 8, 0x11, np.int8)
+                        span = emul.tb_emul_rx_dematch(lbrm, BG, Z, Cn, F, K, rv, E, Qm, ncols * Z, clear, 256, f.ctypes.data,
+                                                       w[misalign:].ctypes.data, l.ctypes.data)
+                        assert span > 0
+                        got = w[misalign:misalign + N]
+                        assert np.array_equal(got, d_ref), (BG, A, Qm, rv, rate, clear, misalign)
+                        assert np.array_equal(w[misalign + N:], w0[misalign + N:])      # nothing behind the row is touched
+                        assert np.array_equal(l[:ncols * Z], l_ref), (BG, A, Qm, rv, rate, clear, misalign)
+                        assert (l[ncols * Z:] == 0x11).all()
+                        cases += 1
+    assert cases > 1000

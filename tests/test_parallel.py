@@ -172,3 +172,61 @@ def test_transport_blocks_sharded_world2(built):
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _loop_worker(port, ret, backend="gloo", device="cpu"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=0, world_size=1)
+    try:
+        from openairinterface5g_amd import ldpc
+        from test_gpu_tb_chain import make_tbs
+        all_tbs = make_tbs()
+        tbs = [all_tbs[i] for i in (0, 2, 3, 4, 5, 10, 11, 12, 0, 2, 3, 4)]
+        sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, loopback=3, device=torch.device(device),
+                                   transport=parallel.CopyTransport() if backend == "gloo" else None)   # gloo cannot send to itself
+        one = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, device=torch.device(device))
+        assert sh.world == 3 and len(sh.shares) == 3 and [len(c) for c in sh.chunk_cut] == [2, 4, 4]
+        po, co, ho, segs = ldpc.tb_layout(tbs)
+        rng = np.random.default_rng(6)
+        ok = True
+        for rnd in range(2):
+            llr = torch.zeros(int(co[-1]), dtype=torch.int16)
+            if rnd == 0:
+                sent = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+            for i, t in enumerate(tbs):
+                c = O.dlsch_encode(t, sent[i])
+                y = (1.0 - 2.0 * c.astype(np.float64) + (1.25 if rnd == 0 else 0.7) * rng.standard_normal(c.size)) * 8.0
+                llr[co[i]:co[i] + t["G"]] = torch.from_numpy(np.clip(np.rint(y), -127, 127).astype(np.int16))
+            before = sh.p2p_bytes
+            pay, ack, itm = sh.decode(llr, rnd)
+            pay1, ack1, itm1 = one.decode(llr, rnd)
+            ok &= torch.equal(pay[:int(po[-1])], pay1[:int(po[-1])]) and torch.equal(ack, ack1) and torch.equal(itm, itm1)
+            # every LLR of the virtual peers and every result of theirs went through a send / receive pair
+            expect = 2 * int(co[-1] - co[sh.cut[1]]) + int(po[-1] - po[sh.cut[1]]) + 5 * (len(tbs) - sh.cut[1])
+            ok &= sh.p2p_bytes - before == expect
+            harq = torch.cat([sh.shares[r].harq[:int(ho[sh.cut[r + 1]] - ho[sh.cut[r]])] for r in range(3)])
+            ok &= torch.equal(harq, one.harq[:int(ho[-1])])
+            ok &= (int(ack.sum()) < len(tbs)) if rnd == 0 else (int(ack.sum()) == len(tbs))
+        ret.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transport_blocks_loopback_one_process(built):
+    """ShardedUlsch(loopback=3): one process plays three ranks, the virtual peers' LLR ranges and results travel through
+    send / receive pairs to the process itself -- the protocol of the N > 1 run (views, chunking, posting order) with a
+    world of one.  Here (gloo cannot send to its own rank) the pairs are matched in posting order and executed as copies;
+    tests/test_bench.py drives the same protocol through RCCL on the GPU.  Results and soft buffers equal the unsharded
+    run's over two HARQ rounds."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_loop_worker, args=(port, ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
