@@ -139,7 +139,11 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
         llr = ((1.0 - 2.0 * coded.float()) * 10 + 1.8 * torch.randn(coded.numel(), device=dev, generator=g)).round() \
             .clamp(-127, 127).to(torch.int16)
         torch.cuda.synchronize()
-    sh = parallel.ShardedUlsch(tbs, device=dev, numMaxIter=MAX_ITER)
+    # a process group of ONE rank (BENCH_FORCE_DIST=1 on a one-GPU box): the slot is cut for 4 virtual ranks and the virtual
+    # peers' LLRs and results go through real RCCL send / receive pairs to this rank itself (parallel.ShardedUlsch
+    # loopback) -- the N > 1 protocol on hardware, not a measurement of N > 1
+    loop = 4 if (dist is not None and world == 1) else 0
+    sh = parallel.ShardedUlsch(tbs, device=dev, numMaxIter=MAX_ITER, loopback=loop)
     if dist is not None:
         # every rank reached the collective section with its inputs built (a rank that raised above never gets here and
         # the others find out from the watchdog time-out of this all-reduce instead of hanging in the scatter)
@@ -166,13 +170,101 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
         return None
     pay, ack, itm = out
     ok = bool(ack.all().item()) and all(torch.equal(pay[po[i]:po[i] + A // 8], payload[po[i]:po[i] + A // 8]) for i in range(n_tb))
-    return {"workload": "64 PUSCH transport blocks of one slot (273 PRB x 13 symbols, 64QAM, TBS 213 176 bit: 1664 code "
+    return {"loopback_virtual_ranks": loop, "rccl_p2p_bytes": int(sh.p2p_bytes), "rccl_p2p_bytes_per_slot": int(sh.p2p_bytes // (steps + 2)),
+            "workload": "64 PUSCH transport blocks of one slot (273 PRB x 13 symbols, 64QAM, TBS 213 176 bit: 1664 code "
                         "segments) arriving on rank 0: scatter LLRs -> UL-SCH chain on every rank -> gather payloads/ACKs",
             "scaling": "strong", "n_gpus": world, "transport_blocks_per_rank": [int(b - a) for a, b in sh.tb_ranges],
             "pipeline_chunks_per_rank": [len(c) - 1 for c in sh.chunk_cut],
             "steps": steps, "ms_per_slot": dt / steps * 1e3, "info_gbps": n_tb * A * steps / dt / 1e9,
             "coded_gbps": n_tb * G * steps / dt / 1e9, "llr_bytes_scattered": int(co[-1]) * 2,
             "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
+
+
+def chain_roofline(pkg, torch):
+    """The memory-bound kernel of the path on the driver's own box: the UL-SCH chain's de-matching step (de-interleave +
+    rate de-match with HARQ combining + int8 pack; nr_rate_matching.c:310-388, 507-603, nr_ulsch_decoding.c:195-210) for
+    one slot of BASELINE configs[4] (64 transport blocks, 1664 segments), device-resident.  Algorithmic bytes from the job
+    list: per segment E int16 LLRs in, n = max(Ncb, positions the decoder reads) int16 soft values out (and in, on a
+    retransmission), ncols*Zc int8 decoder input out.  Time: HIP events around the kernel on its stream
+    (nrLDPC_hip_chain_timing), the separate de-matching launch (NRLDPC_HIP_TB_FUSED=0) -- in the default path the same
+    code is the prologue of the fused segment kernel, whose duration is reported beside it."""
+    m = pkg.ldpc
+    A = 213176
+    while m.nr_segmentation(A + 24, 1) is None:
+        A += 8
+    G = (12 * 13 - 6) * 273 * 6
+    n_tb = 64
+    tbs = [dict(A=A, G=G, BG=1, Qm=6, Nl=1, rv=0, tbslbrm=0, round=0) for _ in range(n_tb)]
+    po, co, ho, segs = m.tb_layout(tbs)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    payload = torch.randint(0, 256, (int(po[-1]) + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    coded = torch.zeros(int(co[-1]) + 16, dtype=torch.uint8, device="cuda")
+    m.PreparedTbBatch(tbs, payload, coded).encode()
+    llr = ((1.0 - 2.0 * coded.float()) * 10 + 1.8 * torch.randn(coded.numel(), device="cuda", generator=g)).round().clamp(-127, 127).to(torch.int16)
+    harq = torch.zeros(int(ho[-1]) + 16, dtype=torch.int16, device="cuda")
+    pay_out = torch.zeros_like(payload)
+    ack = torch.zeros(n_tb, dtype=torch.uint8, device="cuda")
+    itm = torch.zeros(n_tb, dtype=torch.int32, device="cuda")
+    dec = m.PreparedTbBatch(tbs, pay_out, llr, harq, ack, itm)
+    dec.decode()
+    torch.cuda.synchronize()
+    # per-segment geometry, as the library derives it
+    sg = m.nr_segmentation(A + 24, 1)
+    Zc, C_ = sg["Z"], sg["C"]
+    llr_len = 0
+    alg = 0
+    for r in range(C_):
+        E = m.nr_get_E(G, C_, 6, 1, r)
+        R, llr_len = m.nr_get_R_ldpc_decoder(0, E, 1, Zc, llr_len, 0)
+        ncols = m.NCOLS[(1, R)]
+        n = max(66 * Zc, ncols * Zc - 2 * Zc)
+        alg += 2 * E + 2 * n + ncols * Zc
+    alg *= n_tb
+    res = {"kernel": "tb_rx_dematch_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "segments": int(sum(segs)),
+           "algorithmic_bytes_per_launch": int(alg),
+           "model": "per segment: E int16 in + max(Ncb, decoder positions) int16 soft values out + ncols*Zc int8 out (first "
+                    "transmission: the soft buffer is cleared, not read)"}
+    prev = os.environ.get("NRLDPC_HIP_TB_FUSED")
+    try:
+        for mode, key in (("0", "dematch_us"), ("1", "fused_segment_kernel_us")):
+            os.environ["NRLDPC_HIP_TB_FUSED"] = mode
+            for _ in range(3):
+                dec.decode()
+            torch.cuda.synchronize()
+            m.chain_timing(True)
+            ts = []
+            for _ in range(12):
+                dec.decode()
+                ts.append(m.chain_timing(True, read=True))
+            m.chain_timing(False)
+            ts = np.array(ts)
+            if mode == "0":
+                res["dematch_us"] = float(np.median(ts[:, 0]))
+                res["decoder_us"] = float(np.median(ts[:, 1]))
+                res["reassembly_verdict_us"] = float(np.median(ts[:, 2]))
+            else:
+                res["fused_segment_kernel_us"] = float(np.median(ts[:, 1]))
+    finally:
+        if prev is None:
+            os.environ.pop("NRLDPC_HIP_TB_FUSED", None)
+        else:
+            os.environ["NRLDPC_HIP_TB_FUSED"] = prev
+    res["achieved"] = alg / (res["dematch_us"] * 1e-6) / 1e9
+    res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    res["all_ack"] = bool(ack.all().item())
+    return res
+
+
+def build_identity(pkg):
+    """What ran: the library's version string, the sha256 of the shared object this process loaded and of the decoder
+    kernel's sources it was built from -- compared with what profiles/hbm_traffic.json says the PMC passes measured."""
+    import hashlib
+    lib = Path(pkg.ldpc.LIB_PATH)
+    src = hashlib.sha256()
+    for n in ("ldpc_dec_fast_core.h", "ldpc_dec_fast_block.h", "ldpc_decoder_fast.hip", "ldpc_graph.c", "ldpc_graph.h"):
+        src.update((ROOT / "openairinterface5g_amd" / "csrc" / n).read_bytes())
+    return {"version": pkg.load_library().nrLDPC_hip_version().decode(), "lib_sha256": hashlib.sha256(lib.read_bytes()).hexdigest()[:16],
+            "decoder_source_sha256": src.hexdigest()[:16]}
 
 
 def main():
@@ -185,6 +277,7 @@ def main():
                     help="fixed-work launches only (used under rocprofv3 so that its per-kernel average covers one regime)")
     ap.add_argument("--kernel", type=int, default=0, help="0 = best kernel for the code, 1 = generic kernel")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling slot measurement (configs[4])")
+    ap.add_argument("--no-chain", action="store_true", help="skip the chain_roofline measurement (de-matching kernel, configs[4])")
     args = ap.parse_args()
 
     import torch
@@ -287,6 +380,13 @@ def main():
         except Exception as e:                      # the secondary experiment must not cost the headline line
             strong = {"error": f"{type(e).__name__}: {e}"[:300]}
             print(f"[bench] strong-scaling slot failed on rank {rank}: {strong['error']}", file=sys.stderr, flush=True)
+    chain = None
+    if not args.no_chain and rank == 0:
+        try:
+            chain = chain_roofline(pkg, torch)
+        except Exception as e:
+            chain = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] chain_roofline failed: {chain['error']}", file=sys.stderr, flush=True)
     devices = [torch.cuda.current_device()]
     if dist is not None:
         ords = [None] * world
@@ -308,6 +408,13 @@ def main():
         # actually binds the kernel (VALU issue).
         achieved = BATCH * A_MIN / kern_avg_s / 1e9
         binding = {"name": "VALU issue (messages never leave LDS; HBM is idle 99 % of the time)"}
+        ident = build_identity(pkg)
+        # the PMC file is a tracked artefact of an earlier GPU run: say whether it was collected on the decoder this run
+        # executed (same kernel sources) and on this very shared object
+        measured = pmc.get("measured_on") or {}
+        binding["counters_measured_on"] = measured or None
+        binding["stale"] = measured.get("decoder_source_sha256") != ident["decoder_source_sha256"]
+        binding["same_shared_object"] = measured.get("lib_sha256") == ident["lib_sha256"]
         if pmc.get("valu_wave_insts_per_launch"):
             n_simd = 256 * 4
             # mean issue time per VALU instruction: derived by tools/valu_issue_model.py (disassembly opcode histogram x
@@ -335,6 +442,8 @@ def main():
                                                 "GBs_at_this_speed": BATCH * A_MSG / kern_avg_s / 1e9,
                                                 "frac_of_hbm_peak": BATCH * A_MSG / kern_avg_s / 1e9 / HBM_PEAK_GBS},
                          "binding_resource": binding},
+            "chain_roofline": chain,
+            "build": ident,
             "operating_point": op,
             "strong_scaling_slot": strong,
             # how the ranks were really run: the communicator's size (0 = no process group, plain single process) and

@@ -274,6 +274,11 @@ int32_t nrLDPC_hip_code_info(int BG, int Z, int R, int32_t info[8]);
  * off or unavailable), caller slots, server kernel launches so far, calls served through it, and summed over those calls
  * in ns: GPU doorbell-seen -> payload staged, staged -> decoded, host doorbell -> completion seen, whole host call} */
 int32_t nrLDPC_hip_server_stats(int64_t out[8]);
+/* HIP events around the stages of the calling thread's nrLDPC_hip_ulsch_decode calls, recorded on the stream the kernels
+ * run on (primary device): enable != 0 switches the recording on for the calls that follow; out_us, when not NULL, receives
+ * the last recorded call's {de-matching kernel, decoder launches (the fused segment kernel), reassembly + verdict kernels,
+ * their sum} in microseconds (waits for that call).  What bench.py's chain_roofline is computed from.  0 / -1. */
+int32_t nrLDPC_hip_chain_timing(int32_t enable, float out_us[4]);
 const char *nrLDPC_hip_last_error(void);
 const char *nrLDPC_hip_version(void);
 

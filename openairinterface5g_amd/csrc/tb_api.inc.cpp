@@ -70,6 +70,28 @@ struct TbPlan {
    * a row's Ncb values in the caller's array is never touched */
   struct HarqRun { size_t first; uint32_t rows, width; bool upload; };
   std::vector<HarqRun> harq_runs;
+  /* staged outputs that do not tile their range (the caller aligned every block's payload, say): runs of equally sized,
+   * equally spaced blocks -- one strided copy each instead of one copy per block (64 copies of a slot's 64 blocks cost
+   * 0.9 ms of enqueueing; nothing between the blocks is touched either way) */
+  struct OutRun { size_t first, width, pitch; uint32_t rows; };
+  std::vector<OutRun> out_runs;
+  void build_out_runs(const uint64_t *off, const size_t *len, uint32_t n)
+  {
+    out_runs.clear();
+    for (uint32_t i = 0; i < n; i++) {
+      if (!out_runs.empty()) {
+        OutRun &r = out_runs.back();
+        const size_t last = r.first + (size_t)(r.rows - 1) * r.pitch;
+        if (len[i] == r.width && off[i] > last && (r.rows == 1 ? off[i] - last >= r.width : off[i] - last == r.pitch)) {
+          if (r.rows == 1)
+            r.pitch = (size_t)off[i] - last;
+          r.rows++;
+          continue;
+        }
+      }
+      out_runs.push_back(OutRun{(size_t)off[i], len[i], len[i], 1u});
+    }
+  }
   uint64_t stamp = 0; /* LRU */
   /* the descriptors tb[0 .. n_tb) of a call (one device's share of the batch); salt = whatever else the plan depends on */
   bool matches(const nrLDPC_hip_tb_t *tb, uint32_t n_tb, const uint64_t salt[3]) const
@@ -90,9 +112,10 @@ struct TbPlan {
 };
 
 /* A thread's plans of one direction: a handful, least recently used one replaced -- a caller that alternates between a few
- * allocations (parallel.ShardedUlsch sends a slot as three chunks per rank; a scheduler's DL / UL patterns) finds each of
- * them again instead of rebuilding the one plan every call. */
-#define TB_PLAN_SLOTS 8
+ * allocations (parallel.ShardedUlsch sends a slot as three chunks per rank; a large host-buffer call is worked on in up to
+ * eight pieces, first transmissions and retransmissions alternating; a scheduler's DL / UL patterns) finds each of them
+ * again instead of rebuilding the one plan every call. */
+#define TB_PLAN_SLOTS 24
 struct TbPlanCache {
   TbPlan slot[TB_PLAN_SLOTS];
   uint64_t clock = 0;
@@ -121,13 +144,23 @@ struct TbPlanCache {
 struct TbCtx {
   TbPlanCache tx, rx;
   DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small, trace_d;
-  PinBuf jobs_h, small_h;
+  PinBuf jobs_h, small_h, payload_h;
+  /* the host-buffer decode in flight: what tb_rx_finish has to hand over from payload_h (0 bytes: the kernels wrote the
+   * caller's page-locked array themselves) */
+  size_t fin_pay_lo = 0, fin_pay_n = 0;
   hipStream_t own = nullptr, last = nullptr;
+  hipStream_t aux = nullptr;          /* copy lane of the chunked host-buffer decode (tb_rx_enqueue_host) */
+  /* nrLDPC_hip_chain_timing: HIP events around the stages of this thread's UL-SCH calls, on the stream the kernels run on */
+  bool timing = false, timed = false;
+  hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> chunk_ev;
   hipEvent_t uploaded = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr; /* device-resident batches cut over several GPUs (tb_run_sharded) */
   bool pending = false;
   void drain() /* nothing of this thread's stays in flight (error paths, thread exit) */
   {
+    if (aux)
+      (void)hipStreamSynchronize(aux);
     if (own)
       (void)hipStreamSynchronize(own);
     pending = false;
@@ -198,6 +231,18 @@ int tb_multi_mode()
 
 /* NRLDPC_HIP_TB_FUSED=0: de-matching, decoding, reassembly and verdict as four launches (the round-3 path, kept as the
  * cross-check); default: one fused segment kernel wherever the fast decoder serves the segment (tb_rx_fused.hip) */
+/* NRLDPC_HIP_TB_PULL: page-locked host LLRs of nrLDPC_hip_ulsch_decode -- 0: always copied to the device first (in chunks
+ * that overlap with the decoding of the chunks before them, as pageable LLRs are); 1 (default) / 2: read in place by the
+ * segments' workgroups, 1 only for calls below NRLDPC_HIP_TB_PULL_MAX_MB when that is set.  Measured on the 64-block slot
+ * (31.4 MB of LLRs, profiles/r04/slot_chain_host.json): in place 0.70 ms -- the launch's workgroups keep 48 GB/s on the
+ * link while others decode, one launch, no copy -> kernel edge -- against 0.75 ms for the chunked copy-engine pipeline and
+ * 0.56 ms for the bare transfer. */
+int tb_pull_mode()
+{
+  const char *e = getenv("NRLDPC_HIP_TB_PULL");
+  return e ? atoi(e) : 1;
+}
+
 int tb_fused_mode()
 {
   const char *e = getenv("NRLDPC_HIP_TB_FUSED");
@@ -372,6 +417,15 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     pl.n_seg = n_seg; pl.n_aux = cj.size(); pl.scratch_top = ar.top;
     pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi;
     pl.out_dense = ex.cod_sum == ex.cod_hi - ex.cod_lo;
+    {
+      std::vector<uint64_t> off(ntb);
+      std::vector<size_t> len(ntb);
+      for (uint32_t i = 0; i < ntb; i++) {
+        off[i] = tbs[i].coded_off;
+        len[i] = tbs[i].G;
+      }
+      pl.build_out_runs(off.data(), len.data(), ntb);
+    }
     pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[2] = o_enc; pl.off[3] = o_chk; pl.off[4] = o_acc;
     pl.threads[0] = enc_threads; pl.lds[0] = enc_lds;
     pl.remember(tbs, ntb, salt);
@@ -418,8 +472,8 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     if (pl.out_dense) {
       HIP_TRY(hipMemcpyAsync(hc + pl.ext[2], c.io_coded.p, pl.ext[3] - pl.ext[2], hipMemcpyDefault, s));
     } else {
-      for (uint32_t i = 0; i < ntb; i++)
-        HIP_TRY(hipMemcpyAsync(hc + tbs[i].coded_off, c.io_coded.p + (tbs[i].coded_off - pl.ext[2]), tbs[i].G, hipMemcpyDefault, s));
+      for (const TbPlan::OutRun &r : pl.out_runs)
+        HIP_TRY(hipMemcpy2DAsync(hc + r.first, r.pitch, c.io_coded.p + (r.first - pl.ext[2]), r.pitch, r.width, r.rows, hipMemcpyDefault, s));
     }
   }
   return 0;
@@ -495,7 +549,17 @@ int16_t *harq_lookup(uint64_t id, size_t n, bool fresh, hipStream_t s)
  * several GPUs, the owning GPU's memory): the device works on copies of exactly the ranges its blocks touch.  Two things are
  * never staged: LLRs in page-locked host memory (the segments' workgroups read them over the link in place) and soft
  * buffers that already live here (NRLDPC_HIP_MEM_HARQ_DEVICE on this GPU, NRLDPC_HIP_MEM_HARQ_LIBRARY). */
-int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bool staged, hipStream_t s_direct)
+/* host-buffer calls that come in several pieces (tb_rx_enqueue_host): where this piece's LLRs already are, and where its
+ * verdicts go in the call's page-locked result area */
+struct RxHostStage {
+  const int16_t *llr_dev; /* device copy of the caller's LLR array, biased like it (index = coded_off); NULL: none yet */
+  bool no_pull;           /* do not read page-locked LLRs in place: a copy is (being) made */
+  uint32_t call_tb0, call_ntb;
+  size_t pay_lo, pay_hi;  /* payload bytes the whole call's transport blocks touch */
+};
+
+int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bool staged, hipStream_t s_direct,
+                  const RxHostStage *st = nullptr)
 {
   hipStream_t s;
   if (tb_begin(s, s_direct, staged) != 0)
@@ -755,7 +819,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
                  o_acc = o_mg1 + align_up(mgrp[1].size() * sizeof(ldpc_dec_mgroup), 16), /* per TB: CRC accumulators, abort
                                                                                             flags, finished-segment counters:
                                                                                             uploaded as zeros, left zero */
-                 jobs_bytes = o_acc + align_up((size_t)ntb * 3 * sizeof(uint32_t), 16),
+                 o_slots = o_acc + align_up((size_t)ntb * 4 * sizeof(uint32_t), 16), /* (+ per TB: generation) */
+                 jobs_bytes = o_slots + align_up(n_seg * sizeof(uint64_t), 16), /* per segment: the fused kernel's slots */
                  o_iter = jobs_bytes; /* n_iter lives behind the uploaded part in the same device buffer */
     if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 ||
         pl.jobs_d.ensure(o_iter + n_seg * sizeof(int32_t)) != 0)
@@ -795,8 +860,17 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     pl.ext[0] = ex.pay_lo; pl.ext[1] = ex.pay_hi; pl.ext[2] = ex.cod_lo; pl.ext[3] = ex.cod_hi;
     pl.ext[4] = harq_lib ? 0 : ex.harq_lo; pl.ext[5] = harq_lib ? 0 : ex.harq_hi;
     pl.out_dense = ex.pay_sum == ex.pay_hi - ex.pay_lo;
+    {
+      std::vector<uint64_t> off(ntb);
+      std::vector<size_t> len(ntb);
+      for (uint32_t i = 0; i < ntb; i++) {
+        off[i] = tbs[i].payload_off;
+        len[i] = tbs[i].A / 8;
+      }
+      pl.build_out_runs(off.data(), len.data(), ntb);
+    }
     pl.harq_runs.swap(runs);
-    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[4] = o_iter; pl.off[5] = o_acc;
+    pl.off[0] = o_tb; pl.off[1] = o_seg; pl.off[4] = o_iter; pl.off[5] = o_acc; pl.off[6] = o_slots;
     pl.legacy_off = o_leg; pl.n_legacy_seg = sj_legacy.size(); pl.n_legacy_tb = n_legacy_tb; pl.any_fused = any_fused;
     pl.rx_lds_elems = rx_lds_elems;
     pl.llr_len.resize(ntb);
@@ -818,27 +892,30 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   uint8_t *ack = b->ack + tb0;
   int32_t *iter_max = b->iter_max + tb0;
   const size_t stride2 = (size_t)b->harq_stride * sizeof(int16_t);
+  const bool to_host = staged && !(b->mem & NRLDPC_HIP_MEM_DEVICE);
+  const bool payload_direct = false;
   if (staged) {
     const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
-    if (c.io_payload.ensure(pay_n) != 0 || c.io_small.ensure((size_t)ntb * 8 + 64) != 0 || c.small_h.ensure((size_t)ntb * 8 + 64) != 0)
-      return -1;
     /* LLRs in page-locked host memory are read in place (the device address of the caller's array); anything else is copied */
     const int16_t *pulled = nullptr;
-    static const int pull_env = [] { const char *e = getenv("NRLDPC_HIP_TB_PULL"); return e ? atoi(e) : 1; }();
-    if (pull_env && !(b->mem & NRLDPC_HIP_MEM_DEVICE) && host_ptr_is_pinned(b->coded)) {
-      void *dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, b->coded, 0) == hipSuccess)
-        pulled = static_cast<const int16_t *>(dp);
-      else
-        (void)hipGetLastError();
-    }
-    if (pulled) {
-      llr = pulled;
+    if (st && st->llr_dev) {
+      llr = st->llr_dev;
     } else {
-      if (c.io_coded.ensure(cod_n * 2) != 0)
-        return -1;
-      HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyDefault, s));
-      llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
+      if (to_host && !(st && st->no_pull) && tb_pull_mode() != 0 && host_ptr_is_pinned(b->coded)) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, b->coded, 0) == hipSuccess)
+          pulled = static_cast<const int16_t *>(dp);
+        else
+          (void)hipGetLastError();
+      }
+      if (pulled) {
+        llr = pulled;
+      } else {
+        if (c.io_coded.ensure(cod_n * 2) != 0)
+          return -1;
+        HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyDefault, s));
+        llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
+      }
     }
     if (harq_staged) {
       const size_t harq_lo = pl.ext[4], harq_n = pl.ext[5] - pl.ext[4];
@@ -850,15 +927,55 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
                                    hipMemcpyDefault, s));
       harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     }
-    payload = c.io_payload.p - pay_lo;
-    iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
-    ack = c.io_small.p + (size_t)ntb * 4;
+    if (to_host) {
+      /* verdicts: straight into this thread's page-locked result area (device-mapped; tb_rx_finish hands them over) -- no
+       * copy engine for a few bytes; payload: into the caller's array when that is page-locked too, else via a device copy */
+      const uint32_t call_tb0 = st ? st->call_tb0 : tb0, call_ntb = st ? st->call_ntb : ntb;
+      if (c.small_h.ensure((size_t)call_ntb * 8 + 64) != 0)
+        return -1;
+      void *dp = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dp, c.small_h.p, 0));
+      iter_max = static_cast<int32_t *>(dp) + (tb0 - call_tb0);
+      ack = static_cast<uint8_t *>(dp) + (size_t)call_ntb * 4 + (tb0 - call_tb0);
+      /* payload: into device memory, then one copy per piece into PAGE-LOCKED host memory -- the caller's array when it is
+       * page-locked, else this thread's staging area, handed over by tb_rx_finish.  (A device -> host copy into pageable
+       * memory makes the host wait for the piece before it can enqueue the next one; and letting the kernels store the
+       * payload bytes over the link themselves was measured at 48 ms per slot: 4-byte writes, each one waited for.) */
+      const size_t lo = st ? st->pay_lo : pay_lo, n = st ? st->pay_hi - st->pay_lo : pay_n;
+      if (host_ptr_is_pinned(b->payload)) {
+        c.fin_pay_n = 0;
+      } else {
+        (void)hipGetLastError();
+        if (c.payload_h.ensure(n) != 0)
+          return -1;
+        c.fin_pay_lo = lo;
+        c.fin_pay_n = n;
+      }
+    } else {
+      if (c.io_small.ensure((size_t)ntb * 8 + 64) != 0)
+        return -1;
+      iter_max = reinterpret_cast<int32_t *>(c.io_small.p);
+      ack = c.io_small.p + (size_t)ntb * 4;
+    }
+    if (!payload_direct) {
+      if (c.io_payload.ensure(pay_n) != 0)
+        return -1;
+      payload = c.io_payload.p - pay_lo;
+    }
   }
   const tb_rx_seg_job *d_seg = reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + o_seg);
   const tb_rx_seg_job *d_leg = reinterpret_cast<const tb_rx_seg_job *>(pl.jobs_d.p + pl.legacy_off);
   const tb_rx_tb_job *d_tb = reinterpret_cast<const tb_rx_tb_job *>(pl.jobs_d.p + o_tb);
+  if (c.timing) {
+    for (hipEvent_t &e : c.tev)
+      if (!e)
+        HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(c.tev[0], s));
+  }
   HIP_TRY(tb_launch_rx_dematch(d_leg, (uint32_t)pl.n_legacy_seg, pl.rx_lds_elems, llr, harq, reinterpret_cast<int8_t *>(c.scratch.p), s,
                                n_seg <= (size_t)G().n_cus));
+  if (c.timing)
+    HIP_TRY(hipEventRecord(c.tev[1], s));
   ldpc_dec_args da;
   memset(&da, 0, sizeof(da));
   da.llr = reinterpret_cast<const int8_t *>(c.scratch.p);
@@ -874,7 +991,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   da.tb_abort = d_abort;
   tb_rx_fused_args fx;
   fx.segs = d_seg; fx.tbs = d_tb; fx.llr = llr; fx.harq = harq; fx.payload = payload; fx.ack = ack; fx.iter_max = iter_max;
-  fx.acc = d_acc; fx.done = d_abort + ntb; fx.pow24a = G().crc_pow_24a_long;
+  fx.done = d_abort + ntb; fx.gen = reinterpret_cast<uint32_t *>(d_abort + 2 * ntb);
+  fx.slots = reinterpret_cast<unsigned long long *>(pl.jobs_d.p + pl.off[6]); fx.pow24a = G().crc_pow_24a_long;
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
   fx.trace = nullptr;
   for (size_t k = 0; k < pl.dec.size(); k++) {
@@ -916,25 +1034,30 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     else
       HIP_TRY(ldpc_launch_dec_fast_multi_jobs(da, dl.kind == 3 ? 4 : 1, dl.threads, dl.lds, dl.n, s));
   }
+  if (c.timing)
+    HIP_TRY(hipEventRecord(c.tev[2], s));
   if (pl.n_legacy_tb)
     HIP_TRY(tb_launch_rx_assemble(d_tb, ntb, d_leg, (uint32_t)pl.n_legacy_seg, d_iter, c.scratch.p, payload, ack, iter_max, d_acc, d_abort,
                                   G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], s));
+  if (c.timing) {
+    HIP_TRY(hipEventRecord(c.tev[3], s));
+    c.timed = true;
+  }
   if (staged) {
-    const bool to_host = !(b->mem & NRLDPC_HIP_MEM_DEVICE);
-    if (pl.out_dense) {
-      HIP_TRY(hipMemcpyAsync(b->payload + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDefault, s));
+    /* payload back: to the caller's array, or (host call, pageable array) to this thread's page-locked staging area */
+    uint8_t *pay_dst = (to_host && c.fin_pay_n) ? c.payload_h.p - c.fin_pay_lo : b->payload;
+    if (pl.out_dense || pay_dst != b->payload) { /* (the staging area is ours: one copy of the whole range) */
+      HIP_TRY(hipMemcpyAsync(pay_dst + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDefault, s));
     } else {
-      for (uint32_t i = 0; i < ntb; i++)
-        HIP_TRY(hipMemcpyAsync(b->payload + tbs[i].payload_off, c.io_payload.p + (tbs[i].payload_off - pl.ext[0]), tbs[i].A / 8,
-                               hipMemcpyDefault, s));
+      for (const TbPlan::OutRun &r : pl.out_runs)
+        HIP_TRY(hipMemcpy2DAsync(pay_dst + r.first, r.pitch, c.io_payload.p + (r.first - pl.ext[0]), r.pitch, r.width, r.rows,
+                                 hipMemcpyDefault, s));
     }
     if (harq_staged)
       for (const TbPlan::HarqRun &r : pl.harq_runs)
         HIP_TRY(hipMemcpy2DAsync(b->harq + r.first, stride2, c.io_harq.p + (r.first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, r.rows,
                                  hipMemcpyDefault, s));
-    if (to_host) {
-      HIP_TRY(hipMemcpyAsync(c.small_h.p, c.io_small.p, (size_t)ntb * 5, hipMemcpyDeviceToHost, s));
-    } else { /* a peer GPU's share of a device-resident batch: the verdicts go to the owner's arrays */
+    if (!to_host) { /* a peer GPU's share of a device-resident batch: the verdicts go to the owner's arrays */
       HIP_TRY(hipMemcpyAsync(b->iter_max + tb0, c.io_small.p, (size_t)ntb * 4, hipMemcpyDefault, s));
       HIP_TRY(hipMemcpyAsync(b->ack + tb0, c.io_small.p + (size_t)ntb * 4, ntb, hipMemcpyDefault, s));
     }
@@ -948,35 +1071,114 @@ int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
     return 0;
   TbCtx &c = tls_tb;
   HIP_TRY(hipStreamSynchronize(c.own));
-  memcpy(b->iter_max + tb0, c.small_h.p, (size_t)ntb * 4);
+  memcpy(b->iter_max + tb0, c.small_h.p, (size_t)ntb * 4); /* (written by the kernels: the area is device-mapped) */
   memcpy(b->ack + tb0, c.small_h.p + (size_t)ntb * 4, ntb);
+  if (c.fin_pay_n) { /* block by block: nothing between the blocks' payloads is touched */
+    for (uint32_t i = tb0; i < tb0 + ntb; i++)
+      memcpy(b->payload + b->tb[i].payload_off, c.payload_h.p + (b->tb[i].payload_off - c.fin_pay_lo), b->tb[i].A / 8);
+    c.fin_pay_n = 0;
+  }
   return 0;
 }
 
 /* Whole transport blocks per device, contiguous index ranges, balanced by decoder work ~ segments x edges x Zc (SURVEY
  * 8e: a TB stays on one GPU so that its CRC, its abort flag and its HARQ buffers stay local).  cut[k] .. cut[k+1] = the
  * share of part k. */
-void tb_partition(const nrLDPC_hip_tb_batch_t *b, int parts, uint32_t *cut)
+void tb_partition(const nrLDPC_hip_tb_batch_t *b, int parts, uint32_t *cut, uint32_t first = 0, uint32_t count = UINT32_MAX)
 {
-  std::vector<double> cost(b->n_tb, 1.0);
+  if (count == UINT32_MAX)
+    count = b->n_tb - first;
+  std::vector<double> cost(count, 1.0);
   double total = 0;
-  for (uint32_t i = 0; i < b->n_tb; i++) {
-    const nrLDPC_hip_tb_t &t = b->tb[i];
+  for (uint32_t i = 0; i < count; i++) {
+    const nrLDPC_hip_tb_t &t = b->tb[first + i];
     nr_hip_seg_t sg;
     if (t.A && (t.BG == 1 || t.BG == 2) && nr_hip_segmentation((uint32_t)nr_hip_len_with_crc(1, (int)t.A), t.BG, &sg) == 0)
       cost[i] = (double)sg.C * sg.Zc * (t.BG == 1 ? 316.0 : 197.0);
     total += cost[i];
   }
-  cut[0] = 0;
+  cut[0] = first;
   double acc = 0;
   uint32_t i = 0;
   for (int k = 1; k < parts; k++) {
     const double target = total * k / parts;
-    while (i < b->n_tb && acc + cost[i] * 0.5 <= target)
+    while (i < count && acc + cost[i] * 0.5 <= target)
       acc += cost[i++];
-    cut[k] = i;
+    cut[k] = first + i;
   }
-  cut[parts] = b->n_tb;
+  cut[parts] = first + count;
+}
+
+/* Host buffers, one device's share [tb0, tb0 + ntb) of a call.  Small calls: one piece (page-locked LLRs read in place).
+ * Large calls: the LLRs cross the link through the copy engine in K chunks of whole transport blocks on a stream of their
+ * own, back to back at the link's streaming rate; chunk k is de-matched and decoded -- on the compute stream, behind an
+ * event -- while chunks k+1.. are still on the link, so that what a call costs beyond its transfer is one chunk's decoding
+ * and one copy -> kernel edge (the reference overlaps the same way: segments are decoded by the pool while the next
+ * symbols are still being demodulated). */
+int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
+{
+  RxHostStage st{nullptr, false, tb0, ntb, 0, 0};
+  if (ntb == 0)
+    return tb_rx_enqueue(b, tb0, ntb, true, nullptr, &st);
+  size_t lo = SIZE_MAX, hi = 0;
+  st.pay_lo = SIZE_MAX;
+  for (uint32_t i = tb0; i < tb0 + ntb; i++) {
+    lo = std::min(lo, (size_t)b->tb[i].coded_off);
+    hi = std::max(hi, (size_t)b->tb[i].coded_off + b->tb[i].G);
+    st.pay_lo = std::min(st.pay_lo, (size_t)b->tb[i].payload_off);
+    st.pay_hi = std::max(st.pay_hi, (size_t)b->tb[i].payload_off + b->tb[i].A / 8);
+  }
+  const size_t bytes = (hi - lo) * sizeof(int16_t);
+  static const size_t pull_max = [] { const char *e = getenv("NRLDPC_HIP_TB_PULL_MAX_MB"); return e ? (size_t)atoi(e) << 20 : SIZE_MAX; }();
+  static const int chunks_env = [] { const char *e = getenv("NRLDPC_HIP_TB_HOST_CHUNKS"); return e ? atoi(e) : 0; }(); /* tuning knob */
+  const int mode = tb_pull_mode();
+  int K = chunks_env > 0 ? chunks_env : (int)std::min<size_t>(8, bytes / ((size_t)5 << 20));
+  K = std::min<int>(K, (int)ntb / 2);
+  const bool pinned = host_ptr_is_pinned(b->coded);
+  if (K < 2 || (pinned && (mode == 2 || (mode == 1 && bytes < pull_max))))
+    return tb_rx_enqueue(b, tb0, ntb, true, nullptr, &st);
+  hipStream_t s;
+  if (tb_begin(s, nullptr, true) != 0)
+    return -1;
+  TbCtx &c = tls_tb;
+  if (!c.aux)
+    HIP_TRY(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+  while (c.chunk_ev.size() < (size_t)K + 1) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c.chunk_ev.push_back(ev);
+  }
+  if (c.io_coded.ensure(bytes) != 0)
+    return -1;
+  /* the staging buffer may still be read by the previous call's kernels on the compute stream */
+  HIP_TRY(hipEventRecord(c.chunk_ev[K], s));
+  HIP_TRY(hipStreamWaitEvent(c.aux, c.chunk_ev[K], 0));
+  uint32_t cut[9];
+  tb_partition(b, K, cut, tb0, ntb);
+  const int16_t *src = static_cast<const int16_t *>(b->coded);
+  st.llr_dev = reinterpret_cast<const int16_t *>(c.io_coded.p) - lo;
+  st.no_pull = true;
+  auto copy_chunk = [&](int k) -> int {
+    size_t a = SIZE_MAX, e = 0;
+    for (uint32_t i = cut[k]; i < cut[k + 1]; i++) {
+      a = std::min(a, (size_t)b->tb[i].coded_off);
+      e = std::max(e, (size_t)b->tb[i].coded_off + b->tb[i].G);
+    }
+    if (e > a)
+      HIP_TRY(hipMemcpyAsync(c.io_coded.p + (a - lo) * 2, src + a, (e - a) * 2, hipMemcpyHostToDevice, c.aux));
+    HIP_TRY(hipEventRecord(c.chunk_ev[k], c.aux));
+    return 0;
+  };
+  if (copy_chunk(0) != 0)
+    return -1;
+  for (int k = 0; k < K; k++) { /* the copy lane always holds the next chunk's copy while this one's kernels are enqueued */
+    if (k + 1 < K && copy_chunk(k + 1) != 0)
+      return -1;
+    HIP_TRY(hipStreamWaitEvent(s, c.chunk_ev[k], 0));
+    if (tb_rx_enqueue(b, cut[k], cut[k + 1] - cut[k], true, nullptr, &st) != 0)
+      return -1;
+  }
+  return 0;
 }
 
 /* Run a batch over the library's GPUs.  enq(tb0, n, staged, stream) / fin(tb0, n) work on the current device.
@@ -1094,7 +1296,10 @@ int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b)
   if (b->n_tb == 0)
     return ensure_ready();
   return tb_run_sharded(
-      b, [&](uint32_t tb0, uint32_t n, bool staged, hipStream_t s) { return tb_rx_enqueue(b, tb0, n, staged, s); },
+      b,
+      [&](uint32_t tb0, uint32_t n, bool staged, hipStream_t s) {
+        return (staged && !(b->mem & NRLDPC_HIP_MEM_DEVICE)) ? tb_rx_enqueue_host(b, tb0, n) : tb_rx_enqueue(b, tb0, n, staged, s);
+      },
       [&](uint32_t tb0, uint32_t n) { return tb_rx_finish(b, tb0, n); });
 }
 
@@ -1136,6 +1341,26 @@ int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(dst, e.p + first, n * sizeof(int16_t), hipMemcpyDeviceToHost));
   return 0;
+}
+
+int32_t nrLDPC_hip_chain_timing(int32_t enable, float out_us[4])
+{
+  if (ensure_ready() != 0)
+    return -1;
+  UseDevice use(g.dev[0]);
+  TbCtx &c = tls_tb;
+  int rc = 0;
+  if (out_us) {
+    if (!c.timed)
+      return set_error("no timed UL-SCH call on this thread yet");
+    HIP_TRY(hipEventSynchronize(c.tev[3]));
+    float ms[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++)
+      HIP_TRY(hipEventElapsedTime(&ms[k], c.tev[k], c.tev[k + 1]));
+    out_us[0] = ms[0] * 1e3f; out_us[1] = ms[1] * 1e3f; out_us[2] = ms[2] * 1e3f; out_us[3] = (ms[0] + ms[1] + ms[2]) * 1e3f;
+  }
+  c.timing = enable != 0;
+  return rc;
 }
 
 void *nrLDPC_hip_host_alloc(uint64_t bytes)

@@ -30,8 +30,8 @@ hipError_t tb_launch_rx_dematch(const tb_rx_seg_job *jobs, uint32_t n, uint32_t 
 /* Fused segment kernel (tb_rx_fused.hip): one workgroup takes a code segment from the received LLRs to its payload bytes --
  * de-matching (tb_rx_core.h) as the prologue of the decoder's block body, and instead of an output row the segment's bytes
  * of the payload, its share of the TB CRC and, from the last segment of a transport block to finish, the block's verdict.
- * Jobs = ldpc_dec_job with seg_idx >= 0 (a job with seg_idx < 0 is decoded as by ldpc_launch_dec_fast_jobs).  acc[], done[]
- * and the abort flags are zero on entry and on exit. */
+ * Jobs = ldpc_dec_job with seg_idx >= 0 (a job with seg_idx < 0 is decoded as by ldpc_launch_dec_fast_jobs).  done[] and
+ * the abort flags are zero on entry and on exit. */
 struct tb_rx_fused_args {
   const tb_rx_seg_job *segs;
   const tb_rx_tb_job *tbs;
@@ -40,8 +40,10 @@ struct tb_rx_fused_args {
   uint8_t *payload;
   uint8_t *ack;
   int32_t *iter_max;
-  uint32_t *acc;       /* per TB: XOR of the segments' partial TB CRC registers */
-  int *done;           /* per TB: segments finished */
+  unsigned long long *slots; /* per segment: {CRC share, pass count | generation << 16}: written by the segment, read by
+                                the last segment of its transport block to finish */
+  uint32_t *gen;       /* per TB: generation, + 1 per call (never reset: the slots of earlier calls stay distinguishable) */
+  int *done;           /* per TB: segments finished (zero on entry and on exit) */
   const uint32_t *pow24a;
   /* First-round stagger.  The workgroups that share a CU start together and would stay in step -- all of them in their
    * memory-bound prologue (the CU's VALUs idle, HBM contended by every CU at once), then all of them decoding.  Workgroup

@@ -87,11 +87,16 @@ TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__rest
   const uint32_t EQ = E / QM;
   const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
   const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
-  for (uint32_t jj0 = tid; jj0 < EQ; jj0 += 2 * nt) {
-    /* two symbols per step: both loads are in flight before either is consumed */
-    int16_t v[2][QM];
+#ifndef TB_RX_U
+#define TB_RX_U 2
+#endif
+  constexpr int U = TB_RX_U; /* symbols per thread and step: their loads are in flight before the first is consumed.  (Four
+                                per step measured 4 % slower on the whole slot than two, two soft-buffer chunks per step in
+                                phase B level with one: profiles/r04/ab_dematch_variants.txt) */
+  for (uint32_t jj0 = tid; jj0 < EQ; jj0 += U * nt) {
+    int16_t v[U][QM];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
       const uint32_t jj = jj0 + (uint32_t)u * nt;
       if (jj < EQ) {
         if (vec) {
@@ -107,7 +112,7 @@ TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__rest
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
       const uint32_t jj = jj0 + (uint32_t)u * nt;
       if (jj < EQ) {
 #pragma unroll
@@ -202,6 +207,10 @@ TB_RX_HD void tb_rx_phase_stream(const tb_rx_geom &g, const int16_t *e_lds, int1
    * step of a retransmission is a round trip to HBM; the stores of the first chunk cannot be moved across the second's load
    * by the compiler, which does not know that the two never overlap) */
   const chunk_t zero = {(tb_u32x4){0u, 0u, 0u, 0u}};
+#ifndef TB_RX_BCHUNKS
+#define TB_RX_BCHUNKS 1
+#endif
+#if TB_RX_BCHUNKS == 2
   for (uint32_t p0 = 8 * tid; p0 < n8; p0 += 16 * nt) {
     const uint32_t p1 = p0 + 8 * nt;
     chunk_t old0 = zero, old1 = zero;
@@ -214,6 +223,14 @@ TB_RX_HD void tb_rx_phase_stream(const tb_rx_geom &g, const int16_t *e_lds, int1
     if (p1 < n8)
       finish(p1, old1);
   }
+#else
+  for (uint32_t p0 = 8 * tid; p0 < n8; p0 += 8 * nt) {
+    chunk_t old0 = zero;
+    if (!clear)
+      old0.q = *reinterpret_cast<const tb_u32x4 *>(w + p0);
+    finish(p0, old0);
+  }
+#endif
   for (uint32_t p = n8 + tid; p < n; p += nt) {
     const int16_t ev = received(p);
     const int16_t acc = (int16_t)((clear ? 0 : w[p]) + ev);

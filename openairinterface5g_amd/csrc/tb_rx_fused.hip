@@ -13,11 +13,12 @@
  *             copy engine, no copy -> kernel edge.
  *   body      ldpc_dec_fast_block (CRC stop, transport-block abort flag).
  *   epilogue  instead of an output row: the segment's bytes of the payload (stores that leave the caches), its share of the
- *             TB CRC register (linear: XOR-ed into a per-TB accumulator) and its pass count; a per-TB counter tells the
- *             last segment to finish that it is the last, and that workgroup delivers ACK / iter_max (and zeroes the
- *             payload of a block that failed, as the reassembly kernel does).  No fences: everything another workgroup
- *             looks at is moved by device-scope atomics or write-through stores that are complete (s_waitcnt) before the
- *             counter is incremented; an agent-scope release fence would write back the XCD's whole L2 per segment.
+ *             TB CRC register (the CRC is linear in the bits) and its pass count in one 8-byte slot tagged with the block's
+ *             generation; a per-TB counter tells the last segment to finish that it is the last, and that workgroup
+ *             collects the slots (waiting until each shows the generation), delivers ACK / iter_max and zeroes the
+ *             payload of a block that failed, as the reassembly kernel does.  No fences: everything another workgroup
+ *             looks at is moved by device-scope atomics or write-through stores; an agent-scope release fence would
+ *             write back the XCD's whole L2 per segment.
  *
  * Replaces four launches (tb_rx_dematch_kernel, ldpc_dec_fast_kernel<true, true>, tb_rx_assemble_kernel,
  * tb_rx_verdict_kernel) for the segments it serves; those kernels remain for segments of codes the fast decoder does not
@@ -83,6 +84,9 @@ struct tb_rx_fused_io {
     if (first < bbytes)
       count = first + seg_bytes <= bbytes ? seg_bytes : bbytes - first;
     const bool ok = n_iter <= (int)tj->num_max_iter;
+    /* the block's generation: written by the last segment of the PREVIOUS call that held this block (a kernel boundary
+     * ago: a scalar load sees it), constant while this launch's segments of the block are running */
+    const uint32_t gen_prev = ((const uint32_t LDPC_CONST_AS *)x.gen)[tbi];
     uint32_t xr = 0;
     if (ok) {
       uint8_t *dst = x.payload + tj->payload_off + first;
@@ -120,26 +124,21 @@ struct tb_rx_fused_io {
     }
     for (int off = 32; off; off >>= 1)
       xr ^= __shfl_xor(xr, off);
-    if (tid == 0) {
-      flags[2] = 0;
-      flags[4] = 0;
-      flags[5] = 0;
-    }
-    __syncthreads();
+    /* (flags[2], the block body's CRC register, is zero whenever the segment decoded -- which is when xr can be non-zero;
+     * flags[4], flags[5] are zero since the block's prologue) */
     if (lane == 0 && xr)
       atomicXor(reinterpret_cast<unsigned int *>(&flags[2]), xr);
     tb_wait_stores(); /* this thread's payload bytes have left for memory */
     __syncthreads();
+    /* What the block's last segment needs of this one travels in ONE 8-byte store -- {CRC share, pass count, the block's
+     * generation} -- and nothing orders it against the count below: the last segment reads the slots until every one carries
+     * the current generation.  (A slot that shows the generation also says that the segment's payload bytes are in memory:
+     * they were waited for above.)  So a segment's epilogue costs one atomic's round trip, not two. */
+    const uint32_t gen = gen_prev + 1u;
     if (tid == 0) {
-      const uint32_t xall = (uint32_t)flags[2];
-      /* returning atomics whose results are waited for: they have been performed -- where every XCD sees them -- before
-       * the count below can be seen */
-      uint32_t o1 = 0;
-      if (C > 1 && ok && xall)
-        o1 = __hip_atomic_fetch_xor(&x.acc[tbi], xall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int o2 = __hip_atomic_exchange(&a.n_iter[job->iter_idx], n_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(o1), "v"(o2) : "memory");
-      tb_wait_stores();
+      const unsigned long long slot = (unsigned long long)(ok ? (uint32_t)flags[2] : 0u) |
+                                      ((unsigned long long)(((uint32_t)n_iter & 0xffffu) | (gen << 16)) << 32);
+      __hip_atomic_store(&x.slots[job->seg_idx], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int before = __hip_atomic_fetch_add(&x.done[tbi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (before == (int)C - 1)
         flags[4] = 1;
@@ -147,23 +146,29 @@ struct tb_rx_fused_io {
     __syncthreads();
     if (!flags[4])
       return;
-    /* the last segment of the transport block to finish: every sibling's pass count and CRC share are in memory */
+    /* the last segment of the transport block to finish */
     if (tid < 64) {
       const int nmi = (int)tj->num_max_iter;
       int imax = 0, bad = 0;
+      uint32_t crc = 0;
       for (uint32_t r = lane; r < C; r += 64) {
-        const int it = __hip_atomic_load(&a.n_iter[tj->seg0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long v;
+        while ((uint32_t)((v = __hip_atomic_load(&x.slots[tj->seg0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 48) != (gen & 0xffffu))
+          __builtin_amdgcn_s_sleep(2);
+        const int it = (int)((v >> 32) & 0xffffu);
         imax = it > imax ? it : imax;
         bad |= it > nmi;
+        crc ^= (uint32_t)v;
       }
       for (int off = 32; off; off >>= 1) {
         const int o = __shfl_xor(imax, off);
         imax = o > imax ? o : imax;
         bad |= __shfl_xor(bad, off);
+        crc ^= __shfl_xor(crc, off);
       }
       if (lane == 0) {
-        const uint32_t crc = __hip_atomic_exchange(&x.acc[tbi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&x.done[tbi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&x.gen[tbi], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.tb_abort)
           __hip_atomic_store(&a.tb_abort[tbi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         /* single-segment TBs were CRC-checked inside the decoder (phy_procedures_nr_gNB.c:293-299) */

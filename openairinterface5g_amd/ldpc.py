@@ -369,7 +369,8 @@ class nrLDPC_hip_tb_batch_t(C.Structure):
 
 EXPORTS += ["nrLDPC_hip_dlsch_encode", "nrLDPC_hip_ulsch_decode", "nrLDPC_hip_segmentation", "nrLDPC_hip_get_E",
             "nrLDPC_hip_get_R_ldpc_decoder", "nrLDPC_hip_harq_release", "nrLDPC_hip_harq_release_all", "nrLDPC_hip_harq_read",
-            "nrLDPC_hip_host_alloc", "nrLDPC_hip_host_free", "nrLDPC_hip_host_register", "nrLDPC_hip_host_unregister"]
+            "nrLDPC_hip_host_alloc", "nrLDPC_hip_host_free", "nrLDPC_hip_host_register", "nrLDPC_hip_host_unregister",
+            "nrLDPC_hip_chain_timing"]
 HARQ_STRIDE = 66 * 384
 
 
@@ -383,14 +384,16 @@ def _tb_lib():
     L.nrLDPC_hip_get_E.restype = C.c_uint32
     L.nrLDPC_hip_get_R_ldpc_decoder.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32), C.c_int32]
     L.nrLDPC_hip_get_R_ldpc_decoder.restype = C.c_int32
-    L.nrLDPC_hip_harq_release.argtypes = [C.c_uint64]
-    L.nrLDPC_hip_harq_read.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
-    L.nrLDPC_hip_host_alloc.argtypes = [C.c_uint64]
-    L.nrLDPC_hip_host_alloc.restype = C.c_void_p
-    L.nrLDPC_hip_host_free.argtypes = [C.c_void_p]
-    L.nrLDPC_hip_host_free.restype = None
-    L.nrLDPC_hip_host_register.argtypes = [C.c_void_p, C.c_uint64]
-    L.nrLDPC_hip_host_unregister.argtypes = [C.c_void_p]
+    if hasattr(L, "nrLDPC_hip_harq_release"):       # (absent from older builds of the library loaded through NRLDPC_HIP_LIB for A/B runs)
+        L.nrLDPC_hip_harq_release.argtypes = [C.c_uint64]
+        L.nrLDPC_hip_harq_read.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.nrLDPC_hip_host_alloc.argtypes = [C.c_uint64]
+        L.nrLDPC_hip_host_alloc.restype = C.c_void_p
+        L.nrLDPC_hip_host_free.argtypes = [C.c_void_p]
+        L.nrLDPC_hip_host_free.restype = None
+        L.nrLDPC_hip_host_register.argtypes = [C.c_void_p, C.c_uint64]
+        L.nrLDPC_hip_host_unregister.argtypes = [C.c_void_p]
+        L.nrLDPC_hip_chain_timing.argtypes = [C.c_int32, C.c_void_p]
     return L
 
 
@@ -411,6 +414,15 @@ class PinnedArray:
         if getattr(self, "_p", None):
             self._lib.nrLDPC_hip_host_free(self._p)
             self._p = None
+
+
+def chain_timing(enable=True, read=False):
+    """nrLDPC_hip_chain_timing: switch the per-stage HIP events of this thread's UL-SCH calls on / off; read=True returns
+    the last recorded call's (de-matching, decoder / fused kernel, reassembly + verdict, sum) in microseconds."""
+    L = _tb_lib()
+    out = (C.c_float * 4)()
+    _check(L.nrLDPC_hip_chain_timing(int(bool(enable)), out if read else None), "nrLDPC_hip_chain_timing")
+    return tuple(out) if read else None
 
 
 def harq_read(harq_id, n, first=0):

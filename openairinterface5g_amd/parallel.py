@@ -77,9 +77,10 @@ def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: in
     lo, hi = ranges[rank]
     if world == 1:
         return flat_root[lo:hi]
+    as_bytes = lambda t: t.view(torch.uint8) if t.dtype == torch.int16 else t   # (no 16-bit integers in the NCCL process group)
     if rank == root:
         device = flat_root.device if device is None else device
-        ops = [dist.P2POp(dist.isend, flat_root[a:b], dist.get_global_rank(group, r) if group is not None else r, group)
+        ops = [dist.P2POp(dist.isend, as_bytes(flat_root[a:b]), dist.get_global_rank(group, r) if group is not None else r, group)
                for r, (a, b) in enumerate(ranges) if r != root and b > a]
         mine = flat_root[lo:hi]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
@@ -88,7 +89,7 @@ def scatter_ranges(flat_root, ranges: Sequence[Tuple[int, int]], dtype, root: in
     shard = out[:hi - lo] if out is not None else torch.empty((hi - lo,), dtype=dtype, device=device if device is not None else "cpu")
     if hi > lo:
         src = dist.get_global_rank(group, root) if group is not None else root
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, shard, src, group)]):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, as_bytes(shard), src, group)]):
             w.wait()
     return shard
 
@@ -104,14 +105,16 @@ def gather_ranges(local, ranges: Sequence[Tuple[int, int]], total: int, root: in
     if rank == root:
         out = torch.empty((total,), dtype=local.dtype, device=local.device)
         out[lo:hi] = local[:hi - lo]
-        ops = [dist.P2POp(dist.irecv, out[a:b], dist.get_global_rank(group, r) if group is not None else r, group)
+        as_bytes = lambda t: t.view(torch.uint8) if t.dtype == torch.int16 else t
+        ops = [dist.P2POp(dist.irecv, as_bytes(out[a:b]), dist.get_global_rank(group, r) if group is not None else r, group)
                for r, (a, b) in enumerate(ranges) if r != root and b > a]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return out
     if hi > lo:
         dst = dist.get_global_rank(group, root) if group is not None else root
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:hi - lo].contiguous(), dst, group)]):
+        loc = local[:hi - lo].contiguous()
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, loc.view(torch.uint8) if loc.dtype == torch.int16 else loc, dst, group)]):
             w.wait()
     return None
 
@@ -148,7 +151,10 @@ class _DistTransport:
     """point-to-point through torch.distributed (nccl = RCCL on ROCm, gloo on CPU)"""
 
     def op(self, kind, tensor, peer, group):
+        import torch
         import torch.distributed as dist
+        if tensor.dtype == torch.int16:      # the NCCL / RCCL process group has no 16-bit integer type: the LLRs travel as bytes
+            tensor = tensor.view(torch.uint8)
         return dist.P2POp(dist.isend if kind == "send" else dist.irecv, tensor, peer, group)
 
     def batch(self, ops):

@@ -1,5 +1,7 @@
-"""bench.py's launch paths: `--gpus N` spawns its own ranks, and the RCCL path (process group, point-to-point set-up,
-strong-scaling slot) runs on hardware even when the box has one GPU."""
+"""bench.py's launch paths: `--gpus N` spawns its own ranks; with one GPU the process-group path runs with one rank, and
+the strong-scaling slot's scatter / gather protocol is driven through real RCCL send / receive pairs to the rank itself
+(parallel.ShardedUlsch loopback: four virtual ranks in one process) -- ncclSend / ncclRecv, view slicing and stream ordering
+on hardware; what it does not show is a second GPU."""
 import json
 import os
 import subprocess
@@ -28,6 +30,9 @@ def test_gpus_n_without_a_launcher_spawns_its_own_ranks(built):
 
 @pytest.mark.gpu
 def test_rccl_path_runs_on_one_gpu(hip):
+    """BENCH_FORCE_DIST=1: process group of one rank on the nccl (= RCCL) backend; the slot of configs[4] is cut for four
+    virtual ranks, 48 of its 64 transport blocks travel as isend / irecv pairs to rank 0 itself in three chunks per virtual
+    peer and their payloads / ACKs / pass counts come back the same way; every payload byte must equal what was sent."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=900)
@@ -36,7 +41,13 @@ def test_rccl_path_runs_on_one_gpu(hip):
     assert line["rccl_ranks"] == 1 and line["rank_devices"] == [0] and line["n_gpus"] == 1
     assert line["value"] > 10.0 and line["roofline"]["frac"] > 0 and line["config"]["mean_passes"] == 9.0
     s = line["strong_scaling_slot"]
-    assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["transport_blocks_per_rank"] == [64]
+    assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["transport_blocks_per_rank"] == [16, 16, 16, 16]
+    assert s["loopback_virtual_ranks"] == 4 and s["pipeline_chunks_per_rank"] == [1, 3, 3, 3]
+    # 48 transport blocks' LLRs out (int16) + their payload bytes, ACKs and pass counts back, per slot
+    assert s["rccl_p2p_bytes_per_slot"] >= 48 * (245700 * 2 + 213176 // 8 + 5)
+    c = line["chain_roofline"]
+    assert "error" not in c and c["all_ack"] and 0.2 < c["frac"] < 1.0 and c["fused_segment_kernel_us"] > 0
+    assert line["roofline"]["binding_resource"]["stale"] in (True, False) and line["build"]["version"].startswith("libldpc_hip")
 
 
 @pytest.mark.gpu

@@ -2,8 +2,10 @@
 """profiles/hbm_traffic.json from the rocprofv3 PMC passes of tools/gpu_pmc.sh (FETCH_SIZE / WRITE_SIZE, separate
 passes).  Units and the gfx950 correction follow MI355X_MICROARCH.md "HBM": both counters are in KiB per dispatch,
 and FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled."""
-import csv, glob, json, sys
+import csv, glob, hashlib, json, sys
 from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 root = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
 def maxval(sub, counter):
     vals = []
@@ -25,6 +27,8 @@ out = {"ldpc_dec_bg1_z384_r13_b1024_bytes_per_launch": int((2 * fetch_kib + writ
        # per-opcode issue times of profiles/r01/valu_rate_ubench.txt, weighted by the code's task structure
        # (tools/valu_issue_model.py -> profiles/rNN/valu_issue_model.json); not a hand-entered figure any more
        "valu_avg_ns_per_wave_inst_per_simd": model_avg_ns,
+       # what the counters were collected on (bench.py compares this with what it runs and says `stale` when they differ)
+       "measured_on": __import__("bench").build_identity(__import__("openairinterface5g_amd")),
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes on bench.py (1024 x BG1 Zc=384 R13, 9 passes)"}
 Path("profiles").mkdir(exist_ok=True)
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

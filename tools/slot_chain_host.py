@@ -8,7 +8,8 @@ blocks of 26 segments, 273 PRB x 13 symbols, 64QAM = 31.4 MB of int16 LLRs per s
   library   NRLDPC_HIP_MEM_HOST | NRLDPC_HIP_MEM_HARQ_LIBRARY: soft buffers kept by the library
   resident  everything in device memory (the HBM-resident figure bench.py reports), for reference
 
-each with pageable and with page-locked LLRs (page-locked: the segments' workgroups pull them over the link in place),
+each with pageable host arrays and with page-locked ones (LLRs: copied in chunks that overlap with the decoding, or read in
+place by the segments' workgroups for small calls; payload and verdicts: written by the kernels in place),
 for a first transmission (round 0) and a retransmission (round 1, rv 2), plus the latency of a 1-TB call.  Prints one
 JSON object; the link's own rate is measured with a plain pinned hipMemcpy of the same size beside it.
 
@@ -89,10 +90,14 @@ def run(n, out):
         t["llrLen"] = int(d0.arr[i].llrLen)
     d1 = m.PreparedTbBatch(tbs1, pay_d, llr1_d, harq_d, ack_d, itm_d)
     out["resident"] = {"round0_ms": timed(d0.decode, reps), "round1_ms": timed(d1.decode, reps), "all_ack": bool(ack_d.all().item())}
-    pay_h = np.zeros(int(po[n]) + 16, np.uint8)
-    ack_h, itm_h = np.zeros(n, np.uint8), np.zeros(n, np.int32)
     ids = list(range(0x100, 0x100 + n))
     for pinned in (False, True):
+        # pageable run: every host array pageable; page-locked run: LLRs, payload and verdict arrays page-locked
+        if pinned:
+            keep_out = (m.PinnedArray(int(po[n]) + 16, np.uint8), m.PinnedArray(max(n, 1), np.uint8), m.PinnedArray(max(n, 1), np.int32))
+            pay_h, ack_h, itm_h = (k.a for k in keep_out)
+        else:
+            pay_h, ack_h, itm_h = np.zeros(int(po[n]) + 16, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32)
         srcs = []
         for llr_d in (llr0_d, llr1_d):
             if pinned:
