@@ -172,6 +172,19 @@ typedef struct nrLDPC_hip_dec_batch {
 /* 0 on success, negative on bad parameters / HIP error.  DEVICE mem: asynchronous w.r.t. the host. */
 int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b);
 
+/* A MIXED batch of code blocks in one call: every block with its own code, iteration cap and buffers -- what a slot's
+ * segments look like when several UEs with different allocations are decoded together (BASELINE configs[2]: short BG2 blocks
+ * of Zc = 64 and Zc = 208 in one batch).  Device memory only; outMode and the stop mode (check_crc NULL / non-NULL) must be
+ * the same for all blocks; block i reports into n_iter[i].  The blocks are sorted by workgroup shape into as few launches as
+ * the shapes allow (a launch whose last workgroup round is partly empty takes smaller blocks along); the job list derived
+ * from an array that repeats byte for byte is reused.  0, negative on bad parameters / HIP error; enqueue only. */
+typedef struct nrLDPC_hip_dec_job {
+  t_nrLDPC_dec_params params;
+  const int8_t *llr; /* ncols(BG, R) * Z int8, 4-byte aligned for the fast kernel */
+  int8_t *out;       /* BIT: 4 * ceil(ncols*Z / 32) bytes (4-byte aligned), else ncols*Z bytes */
+} nrLDPC_hip_dec_job_t;
+int32_t LDPCdecoder_jobs(const nrLDPC_hip_dec_job_t *jobs, uint32_t n_jobs, int32_t *n_iter, int32_t mem, void *stream);
+
 typedef struct nrLDPC_hip_enc_batch {
   uint8_t BG;
   uint16_t Zc;

@@ -1104,4 +1104,5 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
 } /* extern "C" */
 
 #include "tb_api.inc.cpp"
+#include "dec_jobs.inc.cpp"
 #include "tb_offload.inc.cpp"

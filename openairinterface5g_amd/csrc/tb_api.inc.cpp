@@ -100,6 +100,18 @@ struct TbPlan {
     return valid && key.size() == n + 32 && memcmp(key.data(), &n_tb, 4) == 0 && memcmp(key.data() + 8, salt, 24) == 0 &&
            memcmp(key.data() + 32, tb, n) == 0;
   }
+  /* any descriptor array as bytes (LDPCdecoder_jobs) */
+  bool matches_raw(const void *d, size_t n, const uint64_t salt[3]) const
+  {
+    return valid && key.size() == n + 32 && memcmp(key.data() + 8, salt, 24) == 0 && memcmp(key.data() + 32, d, n) == 0;
+  }
+  void remember_raw(const void *d, size_t n, const uint64_t salt[3])
+  {
+    key.assign(n + 32, 0);
+    memcpy(key.data() + 8, salt, 24);
+    memcpy(key.data() + 32, d, n);
+    valid = true;
+  }
   void remember(const void *tb_bytes, uint32_t n_tb, const uint64_t salt[3])
   {
     const size_t n = (size_t)n_tb * sizeof(nrLDPC_hip_tb_t);
@@ -128,6 +140,15 @@ struct TbPlanCache {
       }
     return nullptr;
   }
+  TbPlan *find_raw(const void *d, size_t n, const uint64_t salt[3])
+  {
+    for (TbPlan &p : slot)
+      if (p.matches_raw(d, n, salt)) {
+        p.stamp = ++clock;
+        return &p;
+      }
+    return nullptr;
+  }
   TbPlan &victim() /* an unused slot, else the least recently used one; the caller rebuilds it */
   {
     TbPlan *v = &slot[0];
@@ -141,8 +162,9 @@ struct TbPlanCache {
   }
 };
 
+#define TB_SIDE_STREAMS 3
 struct TbCtx {
-  TbPlanCache tx, rx;
+  TbPlanCache tx, rx, cb; /* cb: mixed code-block batches (dec_jobs.inc.cpp) */
   DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small, trace_d;
   PinBuf jobs_h, small_h, payload_h;
   /* the host-buffer decode in flight: what tb_rx_finish has to hand over from payload_h (0 bytes: the kernels wrote the
@@ -150,6 +172,8 @@ struct TbCtx {
   size_t fin_pay_lo = 0, fin_pay_n = 0;
   hipStream_t own = nullptr, last = nullptr;
   hipStream_t aux = nullptr;          /* copy lane of the chunked host-buffer decode (tb_rx_enqueue_host) */
+  hipStream_t side[TB_SIDE_STREAMS] = {nullptr, nullptr, nullptr}; /* decoder launches side by side (NRLDPC_HIP_TB_OVERLAP) */
+  hipEvent_t side_ev[TB_SIDE_STREAMS + 1] = {nullptr, nullptr, nullptr, nullptr};
   /* nrLDPC_hip_chain_timing: HIP events around the stages of this thread's UL-SCH calls, on the stream the kernels run on */
   bool timing = false, timed = false;
   hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -161,6 +185,9 @@ struct TbCtx {
   {
     if (aux)
       (void)hipStreamSynchronize(aux);
+    for (hipStream_t q : side)
+      if (q)
+        (void)hipStreamSynchronize(q);
     if (own)
       (void)hipStreamSynchronize(own);
     pending = false;
@@ -213,13 +240,10 @@ int tb_wait_upload(TbCtx &c)
  * segments to fill the GPU anyway, small segments of the same code, iteration cap and CRC share workgroups
  * (ldpc_dec_fast_mblock.h: a lifted row of a small code fills only a fraction of a 64-item task). */
 /* NRLDPC_HIP_TB_CLASSES=0: one decoder launch per kernel for the whole batch (workgroup shape = the largest segment's) */
-bool tb_classes_enabled()
+bool tb_classes_enabled() /* (read when a plan is built, part of its key: the tests switch it between calls) */
 {
-  static const int v = [] {
-    const char *e = getenv("NRLDPC_HIP_TB_CLASSES");
-    return (e && atoi(e) == 0) ? 0 : 1;
-  }();
-  return v != 0;
+  const char *e = getenv("NRLDPC_HIP_TB_CLASSES");
+  return !(e && atoi(e) == 0);
 }
 #define TB_MULTI_MIN_PER_CU 64 /* shared workgroups from this many small segments per CU on (see profiles/r03/README.md) */
 /* read when a plan is built (not cached: the tests switch it between calls) */
@@ -240,6 +264,14 @@ int tb_multi_mode()
 int tb_pull_mode()
 {
   const char *e = getenv("NRLDPC_HIP_TB_PULL");
+  return e ? atoi(e) : 1;
+}
+
+/* NRLDPC_HIP_TB_FILL=0: every workgroup-shape class of a mixed call gets launches of its own (the round-3 plan); default:
+ * a launch's last workgroup round is filled with jobs of the smaller classes.  Read when a plan is built, part of its key. */
+int tb_fill_mode()
+{
+  const char *e = getenv("NRLDPC_HIP_TB_FILL");
   return e ? atoi(e) : 1;
 }
 
@@ -589,7 +621,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   const bool harq_staged = !harq_lib && !harq_here;
   const int fused_mode = tb_fused_mode();
   uint64_t salt[3] = {(uint64_t)b->harq_stride | ((uint64_t)(harq_lib ? 2 : (harq_staged ? 1 : 0)) << 32),
-                            (uint64_t)(fused_mode & 0xff) | ((uint64_t)(tb_multi_mode() & 0xff) << 8) | ((uint64_t)tb_classes_enabled() << 16),
+                            (uint64_t)(fused_mode & 0xff) | ((uint64_t)(tb_multi_mode() & 0xff) << 8) | ((uint64_t)tb_classes_enabled() << 16) |
+                                ((uint64_t)(tb_fill_mode() & 0xff) << 24),
                             harq_lib ? harq_tbl.gen.load() : 0};
   TbPlan *hit = c.rx.find(tbs, ntb, salt);
   if (hit) {
@@ -785,28 +818,56 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       }
       i0 = i1;
     }
-    /* one launch per (kernel, workgroups of that shape a CU holds), the heaviest segments first in each */
+    /* Decoder launches.  A job-array launch has ONE workgroup shape (threads, LDS = the maxima over its jobs), so the jobs
+     * are sorted by kernel and by how many workgroups of their shape a CU holds (1, 2, 4, 8, 16+; the heaviest first inside
+     * a class) and cut into launches class by class -- and a launch whose last workgroup round would be partly empty takes
+     * jobs of the following, smaller classes along until that round is full: they run in slots that would otherwise idle
+     * (a smaller job fits any larger shape), and the smaller classes' own launches get shorter.  Round 3 gave every class
+     * its own launch: 9 workgroup rounds for the 93 small TBS x 64 where 4.3 rounds of work exist.
+     * NRLDPC_HIP_TB_FILL=0: no filling. */
+    const int fill_env = tb_fill_mode();
+    auto per_cu_of = [&](int kind, int threads, int lds) {
+      const int waves = kind == 0 ? 16 : 32; /* the fast kernel's 128 VGPRs allow 16 waves per CU */
+      return std::max(1, std::min(waves * 64 / std::max(threads, 64), (160 * 1024) / std::max(lds, 1024)));
+    };
     auto wg_class = [&](const ShapedJob &j) {
       if (!classes)
         return 0;
-      const int per_cu = std::min(2048 / std::max(j.threads, 64), (160 * 1024) / std::max(j.lds, 1024));
+      const int per_cu = per_cu_of(j.kind, j.threads, j.lds);
       return per_cu >= 16 ? 4 : per_cu >= 8 ? 3 : per_cu >= 4 ? 2 : per_cu >= 2 ? 1 : 0;
     };
     std::stable_sort(single.begin(), single.end(), [&](const ShapedJob &x, const ShapedJob &y) {
-      const int cx = wg_class(x) * 2 + x.kind, cy = wg_class(y) * 2 + y.kind;
+      const int cx = x.kind * 8 + wg_class(x), cy = y.kind * 8 + wg_class(y);
       return cx != cy ? cx < cy : (classes && x.cost > y.cost);
     });
     std::vector<ldpc_dec_job> single_jobs(single.size());
-    std::vector<TbPlan::DecLaunch> dec;
-    for (size_t q = 0; q < single.size(); q++) {
+    for (size_t q = 0; q < single.size(); q++)
       single_jobs[q] = single[q].dj;
-      if (q == 0 || wg_class(single[q]) != wg_class(single[q - 1]) || single[q].kind != single[q - 1].kind)
-        dec.push_back(TbPlan::DecLaunch{single[q].kind, q * sizeof(ldpc_dec_job), 0, 0, 64, 0, false});
-      TbPlan::DecLaunch &dl = dec.back();
-      dl.n++;
-      dl.threads = std::max(dl.threads, single[q].threads);
-      dl.lds = std::max(dl.lds, single[q].lds);
-      dl.fused |= single[q].dj.seg_idx >= 0;
+    std::vector<TbPlan::DecLaunch> dec;
+    for (size_t q = 0; q < single.size();) {
+      const int kind = single[q].kind, cls = wg_class(single[q]);
+      size_t e = q;
+      int threads = 64, lds = 0;
+      while (e < single.size() && single[e].kind == kind && wg_class(single[e]) == cls) {
+        threads = std::max(threads, single[e].threads);
+        lds = std::max(lds, single[e].lds);
+        e++;
+      }
+      if (classes && fill_env) {
+        const size_t slots = (size_t)G().n_cus * (size_t)per_cu_of(kind, threads, lds);
+        const size_t rem = (e - q) % slots;
+        size_t room = rem ? slots - rem : 0;
+        /* (jobs of the classes behind: they fit when neither their threads nor their LDS exceed the launch's) */
+        while (room && e < single.size() && single[e].kind == kind && single[e].threads <= threads && single[e].lds <= lds) {
+          e++;
+          room--;
+        }
+      }
+      TbPlan::DecLaunch dl{kind, q * sizeof(ldpc_dec_job), 0, (uint32_t)(e - q), threads, lds, false};
+      for (size_t i = q; i < e; i++)
+        dl.fused |= single[i].dj.seg_idx >= 0;
+      dec.push_back(dl);
+      q = e;
     }
     const size_t n_seg = sj.size();
     const size_t o_tb = 0, o_seg = align_up(tbj.size() * sizeof(tb_rx_tb_job), 16),
@@ -995,14 +1056,40 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   fx.slots = reinterpret_cast<unsigned long long *>(pl.jobs_d.p + pl.off[6]); fx.pow24a = G().crc_pow_24a_long;
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
   fx.trace = nullptr;
+  /* A call that mixes code sizes has several decoder launches (TbPlan::DecLaunch); nothing orders them among themselves --
+   * disjoint jobs, scratch rows, per-block state.  NRLDPC_HIP_TB_OVERLAP=1 sends them out on side streams, forked from and
+   * joined to the call's stream, so that the CUs one launch leaves free could take the next one's workgroups.  Default 0:
+   * with several hardware queues active every kernel of the call runs 2 - 4 x longer on this stack (the 96 large workgroups
+   * of the 93-small-TBS mix: 38 -> 162 us; the whole call 0.35 -> 0.53 ms; profiles/r04/small_tbs_overlap.txt) -- round 3
+   * had seen the same with the unfused kernels.  What replaces it is in the plan: launches that fill their last workgroup
+   * round with jobs of the smaller classes. */
+  static const int overlap_env = [] { const char *e = getenv("NRLDPC_HIP_TB_OVERLAP"); return e ? atoi(e) : 0; }();
+  const size_t n_side = (overlap_env && pl.dec.size() >= 2 && !c.timing) ? std::min<size_t>(pl.dec.size() - 1, TB_SIDE_STREAMS) : 0;
+  if (n_side) {
+    for (size_t j = 0; j < TB_SIDE_STREAMS + 1; j++)
+      if (!c.side_ev[j])
+        HIP_TRY(hipEventCreateWithFlags(&c.side_ev[j], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c.side_ev[TB_SIDE_STREAMS], s)); /* fork: behind the uploads, the copies in and the de-matching launch */
+    for (size_t j = 0; j < n_side; j++) {
+      if (!c.side[j])
+        HIP_TRY(hipStreamCreateWithFlags(&c.side[j], hipStreamNonBlocking));
+      HIP_TRY(hipStreamWaitEvent(c.side[j], c.side_ev[TB_SIDE_STREAMS], 0));
+    }
+  }
+  hipStream_t s_call = s;
   for (size_t k = 0; k < pl.dec.size(); k++) {
     const TbPlan::DecLaunch &dl = pl.dec[k];
+    const size_t lane = n_side ? k % (n_side + 1) : 0;
+    hipStream_t s = lane ? c.side[lane - 1] : s_call; /* (shadows the call's stream inside the loop) */
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + dl.jobs_off);
     da.mgroups = reinterpret_cast<const ldpc_dec_mgroup *>(pl.jobs_d.p + dl.grp_off);
     if (dl.kind == 0 && dl.fused) {
       /* more than one workgroup per CU in the first round: staggered start (tb_chain.h).  NRLDPC_HIP_TB_STAGGER_US = the
-       * offset between the two workgroups of a CU (k workgroups: 2 / k of it each), 0 = off */
-      static const int stagger_us = [] { const char *e = getenv("NRLDPC_HIP_TB_STAGGER_US"); return e ? atoi(e) : 8; }();
+       * offset between the two workgroups of a CU (k workgroups: 2 / k of it each).  Default 0 = off: measured level to
+       * slower at every offset (profiles/r04/fused_stagger_sweep.txt) -- a CU's workgroups only share their prologue in the
+       * first round, drift apart by themselves afterwards, and a workgroup that decodes alone is no faster than one that
+       * shares its CU (profiles/r04/wg_trace_*.txt) */
+      static const int stagger_us = [] { const char *e = getenv("NRLDPC_HIP_TB_STAGGER_US"); return e ? atoi(e) : 0; }();
       const int per_cu = std::min(16 / std::max(dl.threads / 64, 1), (160 * 1024) / std::max(dl.lds, 1024));
       fx.stagger_ticks = 0;
       if (stagger_us > 0 && per_cu >= 2 && dl.n > (uint32_t)G().n_cus) {
@@ -1033,6 +1120,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       HIP_TRY(ldpc_launch_dec_generic_jobs(da, dl.threads, dl.lds, dl.n, s));
     else
       HIP_TRY(ldpc_launch_dec_fast_multi_jobs(da, dl.kind == 3 ? 4 : 1, dl.threads, dl.lds, dl.n, s));
+  }
+  for (size_t j = 0; j < n_side; j++) { /* join */
+    HIP_TRY(hipEventRecord(c.side_ev[j], c.side[j]));
+    HIP_TRY(hipStreamWaitEvent(s, c.side_ev[j], 0));
   }
   if (c.timing)
     HIP_TRY(hipEventRecord(c.tev[2], s));

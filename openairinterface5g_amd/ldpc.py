@@ -70,6 +70,10 @@ class nrLDPC_hip_dec_batch_t(C.Structure):
                 ("mem", C.c_int32), ("stream", C.c_void_p), ("kernel", C.c_int32)]
 
 
+class nrLDPC_hip_dec_job_t(C.Structure):
+    _fields_ = [("params", t_nrLDPC_dec_params), ("llr", C.c_void_p), ("out", C.c_void_p)]
+
+
 class nrLDPC_hip_enc_batch_t(C.Structure):
     _fields_ = [("BG", C.c_uint8), ("Zc", C.c_uint16), ("Kb", C.c_uint8), ("n_blocks", C.c_uint32),
                 ("in_", C.c_void_p), ("in_stride", C.c_uint32), ("out", C.c_void_p), ("out_stride", C.c_uint32),
@@ -80,6 +84,7 @@ class nrLDPC_hip_enc_batch_t(C.Structure):
 _CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
 
 EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "LDPCdecoder_batch", "LDPCencoder_batch",
+           "LDPCdecoder_jobs",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
 
@@ -323,6 +328,32 @@ def decode_batch_device(BG, Z, R, llr, out, n_iter, numMaxIter=8, outMode=nrLDPC
                                out=out.data_ptr(), out_stride=out.stride(0) * out.element_size(),
                                n_iter=n_iter.data_ptr(), mem=MEM_DEVICE, stream=s, kernel=kernel)
     _check(L.LDPCdecoder_batch(C.byref(b)), "LDPCdecoder_batch")
+
+
+class PreparedDecJobs:
+    """A MIXED batch of code blocks (LDPCdecoder_jobs): blocks = list of dict(BG, Z, R, llr=torch int8 row on the GPU,
+    out=torch uint8 row, numMaxIter=8, E=0, crc_type=CRC24_B); all with one outMode / stop mode.  Marshalled once,
+    submitted many times; decode() only enqueues on the stream.  n_iter: torch int32 [len(blocks)]."""
+
+    def __init__(self, blocks, n_iter, outMode=nrLDPC_outMode_BIT, check_crc=False, stream=None):
+        import torch
+        self._lib = load_library()
+        self._lib.LDPCdecoder_jobs.argtypes = [C.POINTER(nrLDPC_hip_dec_job_t), C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]
+        self._lib.LDPCdecoder_jobs.restype = C.c_int32
+        self._keep = (blocks, n_iter)
+        self.arr = (nrLDPC_hip_dec_job_t * len(blocks))()
+        for i, b in enumerate(blocks):
+            assert b["llr"].is_cuda and b["out"].is_cuda and b["llr"].is_contiguous() and b["out"].is_contiguous()
+            self.arr[i].params = make_dec_params(b["BG"], b["Z"], b["R"], b.get("numMaxIter", 8), outMode, check_crc, b.get("E", 0),
+                                                 b.get("crc_type", CRC24_B))
+            self.arr[i].llr = b["llr"].data_ptr()
+            self.arr[i].out = b["out"].data_ptr()
+        assert n_iter.is_cuda and n_iter.dtype == torch.int32 and n_iter.numel() >= len(blocks)
+        self.n, self.n_iter = len(blocks), n_iter
+        self.stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+
+    def decode(self):
+        _check(self._lib.LDPCdecoder_jobs(self.arr, self.n, self.n_iter.data_ptr(), MEM_DEVICE, self.stream), "LDPCdecoder_jobs")
 
 
 def encode_batch_host(BG, Zc, info, Kb=None):

@@ -364,6 +364,45 @@ def test_config3_mixed_bg2_batch_every_block(hip):
             assert np.array_equal(it, it_ref) and np.array_equal(out, out_ref), (BG, Z, R, kern)
 
 
+def test_config3_as_one_mixed_call(hip):
+    """BASELINE configs[2] as ONE call (LDPCdecoder_jobs): the 4 x 256 short BG2 blocks of the test above shuffled into
+    one job array -- plus blocks of a lifting size the fast kernel does not take (Zc = 30: generic kernel) and one large
+    BG1 block, so that the call spans workgroup shapes and both kernels -- every block with its own buffers; bits and
+    pass counts of every block against the oracle, in parity-check and in CRC stop mode, submitted twice (the second
+    submission reuses the job list)."""
+    import os
+    import torch
+    m = hip.ldpc
+    rng = np.random.default_rng(34)
+    codes = [(2, 64, 15)] * 256 + [(2, 64, 13)] * 256 + [(2, 208, 15)] * 256 + [(2, 208, 13)] * 256 + [(2, 30, 15)] * 40 + [(1, 384, 13)] * 3
+    order = rng.permutation(len(codes))
+    for use_crc in (False, True):
+        blocks, refs = [], []
+        for k in order:
+            BG, Z, R = codes[k]
+            K = kbits(BG, Z)
+            info = random_info(rng, BG, Z, with_crc24b=use_crc)
+            llr = make_llr(rng, BG, Z, R, float(rng.choice([-3.0, -1.0, 0.0, 2.0])), info)
+            E = K if use_crc else 0
+            if use_crc and (K % 8 or K < 48):
+                continue
+            refs.append(O.decode(BG, Z, R, llr, 8, 0, use_crc, E, 1, vec=True))
+            blocks.append(dict(BG=BG, Z=Z, R=R, E=E, crc_type=1, llr=torch.from_numpy(llr).cuda(),
+                               out=torch.full((m.out_bytes(BG, Z, R),), 0x33, dtype=torch.uint8, device="cuda")))
+        n_iter = torch.zeros(len(blocks), dtype=torch.int32, device="cuda")
+        jobs = m.PreparedDecJobs(blocks, n_iter, check_crc=use_crc)
+        for rep in range(2):
+            n_iter.zero_()
+            jobs.decode()
+            torch.cuda.synchronize()
+            it = n_iter.cpu().numpy()
+            for i, (b, (n_ref, out_ref)) in enumerate(zip(blocks, refs)):
+                assert it[i] == n_ref, (use_crc, rep, i, b["BG"], b["Z"], b["R"], int(it[i]), n_ref)
+                if not use_crc or n_ref >= 3:
+                    assert np.array_equal(b["out"].cpu().numpy(), out_ref), (use_crc, rep, i, b["BG"], b["Z"], b["R"])
+        assert len(set(n_iter.cpu().numpy().tolist())) >= 3
+
+
 def test_ldpctest_acceptance_and_seed_identical_bler(hip):
     """The reference CI's acceptance criterion for the library (`ldpctest -l{3872..8448} -s10 -n100` must print
     `BLER 0.000000`, cmake_targets/autotests/test_case_list.xml:68-94) on a subset, and -- on identical AWGN seeds --

@@ -320,6 +320,22 @@ def test_small_transport_blocks_share_workgroups(hip):
         out, ack, itm = hip.ldpc.ulsch_decode_host(rx, llrs, harq_gpu, numMaxIter=8)
     finally:
         del os.environ["NRLDPC_HIP_TB_MULTI"]
+    # the same call under the other launch plans -- the default (one workgroup per segment, launches cut by workgroup shape,
+    # last rounds filled with segments of the smaller shapes), without the filling, without the classes, unfused: the plan
+    # decides where a segment runs, never what comes out
+    for env in ({}, {"NRLDPC_HIP_TB_FILL": "0"}, {"NRLDPC_HIP_TB_CLASSES": "0"}, {"NRLDPC_HIP_TB_FUSED": "0"},
+                {"NRLDPC_HIP_TB_FUSED": "0", "NRLDPC_HIP_TB_FILL": "0"}):
+        os.environ.update(env)
+        try:
+            rx2 = [dict(t, round=0, llrLen=0) for t in tbs]
+            harq2 = np.zeros((len(tbs), stride), np.int16)
+            out2, ack2, itm2 = hip.ldpc.ulsch_decode_host(rx2, llrs, harq2, numMaxIter=8)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert np.array_equal(ack2, ack) and np.array_equal(itm2, itm) and np.array_equal(harq2, harq_gpu), env
+        assert all(np.array_equal(a, b) for a, b in zip(out2, out)), env
+        assert [t["llrLen"] for t in rx2] == [t["llrLen"] for t in rx], env
     n_ack = 0
     for i, t in enumerate(tbs):
         harq_ref = [np.zeros(stride, np.int16)]

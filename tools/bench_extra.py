@@ -80,6 +80,18 @@ for regime, snr in (("fixed_work", -12.0), ("operating_point", 1.0)):
     dtg = timeit(graph.replay, 50)
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_replay_ms"] = dtg * 1e3
     res[f"config3_mixed_bg2_z64_z208_{regime}"]["hipgraph_coded_gbps"] = bits / dtg / 1e9
+    # ... and as ONE call: the 1024 blocks interleaved into one job array (LDPCdecoder_jobs: launches cut by workgroup
+    # shape, last rounds filled with smaller blocks)
+    blocks = []
+    for k in range(256):
+        for (BG, Z, R, llr, out, it) in bufs:
+            blocks.append(dict(BG=BG, Z=Z, R=R, llr=llr[k], out=out[k]))
+    it_all = torch.zeros(len(blocks), dtype=torch.int32, device="cuda")
+    jobs = m.PreparedDecJobs(blocks, it_all)
+    dtj = timeit(jobs.decode, 50)
+    same = all(torch.equal(it_all[j::4], bufs[j][5]) for j in range(4))
+    res[f"config3_mixed_bg2_z64_z208_{regime}"].update({"one_call_ms": dtj * 1e3, "one_call_coded_gbps": bits / dtj / 1e9,
+                                                          "one_call_pass_counts_equal": bool(same)})
 
 # ---- the decoder's rate modes (nr_get_R_ldpc_decoder picks them from the code rate): BG1 Zc=384, 1024 blocks per launch ----
 for (BG, Z, R, label) in ((1, 384, 13, "r13"), (1, 384, 23, "r23"), (1, 384, 89, "r89"), (2, 384, 15, "bg2_r15"), (2, 384, 13, "bg2_r13"),
