@@ -119,6 +119,7 @@ int32_t LDPCshutdown(void);
  * NRLDPC_HIP_REQUIRE_BUILD=<text> in the environment it returns -1 -- the loader then refuses the library -- unless the
  * executable's build string contains <text>. */
 int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion);
+int32_t nrLDPC_hip_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion); /* (what the offload-slot library forwards to) */
 /* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
  * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
  * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);

@@ -560,6 +560,11 @@ const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.4 (gfx950)"; }
  * tests/test_abi.py -- an executable of another revision may have moved them). */
 int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
 {
+  return nrLDPC_hip_checkbuildver(mainexec_buildversion, shlib_buildversion);
+}
+/* the same under a name that does not clash with the loader's hook: libldpc_hip_t2.so forwards its own ldpc_checkbuildver here */
+int32_t nrLDPC_hip_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
+{
   static char version[] = "libldpc_hip 0.4 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
   if (shlib_buildversion)
     *shlib_buildversion = version;

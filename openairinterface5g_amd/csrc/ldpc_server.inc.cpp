@@ -405,6 +405,9 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
          * miss after the other in the loop below */
         for (int off = 0; off < 16 * n_units; off += 64)
           _mm_prefetch(reinterpret_cast<const char *>(c.out) + off, _MM_HINT_T0);
+        /* two steps: every unit is waited for and taken into a local copy first, the caller's p_out is written only when
+         * all of them are there -- a call that fails half way leaves p_out as it was */
+        __m128i got[(68 * 384 / 32 * 4 / 12) + 2];
         for (int u = 0; u < n_units; u++) {
           const __m128i *src = reinterpret_cast<const __m128i *>(c.out) + u;
           __m128i v = _mm_load_si128(src);
@@ -425,15 +428,24 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
             }
             v = _mm_load_si128(src);
           }
-          if (rc != 0) {
-            set_error("resident server: the output of a completed call never arrived");
+          if (rc != 0)
             break;
-          }
+          got[u] = v;
+        }
+        if (rc != 0) {
+          /* late stores of this sequence number may still land in the slot's output area: the slot is retired, not handed
+           * to the next caller (as srv_give_up does for a call whose completion never came) */
+          set_error("resident server: the output of a completed call never arrived");
+          srv.slots[c.slot].host_total_s += srv_now() - t_call;
+          srv_give_up(S, c.slot);
+          return -1;
+        }
+        for (int u = 0; u < n_units; u++) {
           const int left = ob - 12 * u;
           if (left >= 12) {
-            memcpy(out + 12 * u, &v, 12);
+            memcpy(out + 12 * u, &got[u], 12);
           } else if (left > 0) {
-            memcpy(out + 12 * u, &v, (size_t)left);
+            memcpy(out + 12 * u, &got[u], (size_t)left);
           }
         }
       } else {

@@ -22,10 +22,9 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
 {
   return nrLDPC_hip_offload_encoder(input, output, impp);
 }
+/* the loader's version hook of this slot: the same answer -- ABI string, NRLDPC_HIP_REQUIRE_BUILD gate -- as for
+ * libldpc_hip.so (the gate did not apply to the offload slot) */
 int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
 {
-  (void)mainexec_buildversion;
-  if (shlib_buildversion)
-    *shlib_buildversion = (char *)nrLDPC_hip_version();
-  return 0;
+  return nrLDPC_hip_checkbuildver(mainexec_buildversion, shlib_buildversion);
 }

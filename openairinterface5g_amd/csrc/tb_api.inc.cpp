@@ -1098,13 +1098,13 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         fx.stagger_slots = (uint32_t)per_cu;
       }
       static const char *trace_file = getenv("NRLDPC_HIP_TB_TRACE"); /* diagnostics: per-workgroup clocks of this launch */
-      if (trace_file && c.trace_d.ensure((size_t)dl.n * 64) == 0) {
-        HIP_TRY(hipMemsetAsync(c.trace_d.p, 0, (size_t)dl.n * 64, s));
+      if (trace_file && c.trace_d.ensure((size_t)dl.n * 128) == 0) {
+        HIP_TRY(hipMemsetAsync(c.trace_d.p, 0, (size_t)dl.n * 128, s));
         fx.trace = reinterpret_cast<unsigned long long *>(c.trace_d.p);
       }
       HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
       if (fx.trace) {
-        std::vector<unsigned long long> h((size_t)dl.n * 8);
+        std::vector<unsigned long long> h((size_t)dl.n * 16);
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpy(h.data(), c.trace_d.p, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(trace_file, "wb")) {

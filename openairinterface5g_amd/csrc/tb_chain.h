@@ -52,7 +52,8 @@ struct tb_rx_fused_args {
    * rounds inherit the offset.  0 ticks: off. */
   uint32_t stagger_ticks, stagger_cus, stagger_slots;
   /* diagnostics (NRLDPC_HIP_TB_TRACE=<file>): per workgroup {HW_ID, XCC_ID, wall clock at start, after the prologue, after
-   * the last pass, at the end, pass count, 0} as 8 x uint64; NULL normally */
+   * the last pass, at the end, pass count, after: the LDS image is cleared, the LLRs are scattered, the soft buffer is streamed,
+   * the decoder input is visible to the workgroup, 0...} as 16 x uint64; NULL normally */
   unsigned long long *trace;
 };
 struct ldpc_dec_args;

@@ -5,7 +5,8 @@
  *
  * One workgroup per segment, the segment's received contributions transposed through an LDS image of the part of the
  * circular buffer this transmission touches, so that both sides move whole cache lines:
- *   phase Z  zero the image and the decoder input's punctured columns;
+ *   phase Z  request every thread's first symbols (their latency runs under the rest of this phase), zero the image and
+ *            the decoder input's punctured columns;
  *   phase A  a thread per modulation symbol jj reads the symbol's Qm LLRs f[jj*Qm .. +Qm) in ONE load -- from device
  *            memory, or over the link from the caller's page-locked array -- and drops each at its soft-buffer position
  *            in LDS (e_lds[pos(i*E/Qm + jj)]); one lap of the circular buffer at a time, so that every position receives
@@ -79,64 +80,83 @@ TB_RX_HD void tb_rx_phase_zero(const tb_rx_geom &g, int16_t *e_lds, int8_t *__re
 
 /* ---- phase A, one lap ------------------------------------------------------------------------------------------------- */
 TB_RX_HD uint32_t tb_rx_laps(const tb_rx_geom &g) { return (g.E + g.V - 1) / g.V; }
-template <int QM>
-TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *e_lds, uint32_t lap, uint32_t nlaps,
-                                      uint32_t tid, uint32_t nt)
-{
-  const uint32_t E = g.E, V = g.V, rank0 = g.rank0, Foffset = g.Foffset, Fin = g.Fin, p_align = g.p_align, Ncb = g.Ncb;
-  const uint32_t EQ = E / QM;
-  const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
-  const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
 #ifndef TB_RX_U
-#define TB_RX_U 2
+#define TB_RX_U 4
 #endif
-  constexpr int U = TB_RX_U; /* symbols per thread and step: their loads are in flight before the first is consumed.  (Four
-                                per step measured 4 % slower on the whole slot than two, two soft-buffer chunks per step in
-                                phase B level with one: profiles/r04/ab_dematch_variants.txt) */
-  for (uint32_t jj0 = tid; jj0 < EQ; jj0 += U * nt) {
-    int16_t v[U][QM];
+/* The first TB_RX_U symbols of every thread (jj = tid + u * nt), requested BEFORE the LDS image is cleared: their trip to
+ * HBM -- or over the link to the caller's page-locked array -- runs under the clearing and its barrier, and all of them are
+ * in flight together (unconditional loads from a clamped index: a load inside `if (jj < EQ)` is not moved across the
+ * branch by the compiler).  A 512-thread workgroup covers a 64QAM segment's 1575 symbols with them; what is left is walked
+ * by the loop of tb_rx_phase_scatter_lap. */
+template <int QM> struct tb_rx_first { tb_sym<QM> sy[TB_RX_U]; };
+template <int QM>
+TB_RX_HD void tb_rx_phase_load_first(const tb_rx_geom &g, const int16_t *__restrict__ f, uint32_t tid, uint32_t nt, tb_rx_first<QM> &first)
+{
+  const uint32_t EQ = g.E / QM;
+  const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t jj = jj0 + (uint32_t)u * nt;
-      if (jj < EQ) {
-        if (vec) {
-          const tb_sym<QM> sy = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+  for (int u = 0; u < TB_RX_U; u++) {
+    uint32_t jj = tid + (uint32_t)u * nt;
+    jj = jj < EQ ? jj : (EQ ? EQ - 1 : 0);
+    if (vec) {
+      first.sy[u] = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+    } else {
 #pragma unroll
-          for (int i = 0; i < QM; i++)
-            v[u][i] = (int16_t)(sy.w[i >> 1] >> (16 * (i & 1)));
-        } else {
-#pragma unroll
-          for (int i = 0; i < QM; i++)
-            v[u][i] = f[(size_t)jj * QM + i];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t jj = jj0 + (uint32_t)u * nt;
-      if (jj < EQ) {
-#pragma unroll
-        for (int i = 0; i < QM; i++) {
-          const uint32_t k = (uint32_t)i * EQ + jj;
-          if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
-            uint32_t r = rank0 + (k - k_lo);
-            r = r >= V ? r - V : r;
-            const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_align, Ncb);
-            e_lds[q] = lap == 0 ? v[u][i] : (int16_t)(e_lds[q] + v[u][i]);
-          }
-        }
-      }
+      for (int i = 0; i < QM; i += 2)
+        first.sy[u].w[i >> 1] = (uint32_t)(uint16_t)f[(size_t)jj * QM + i] | ((uint32_t)(uint16_t)f[(size_t)jj * QM + i + 1] << 16);
     }
   }
 }
-TB_RX_HD void tb_rx_phase_scatter_lap_qm(uint32_t Qm, const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *e_lds, uint32_t lap,
-                                         uint32_t nlaps, uint32_t tid, uint32_t nt)
+/* one symbol's Qm values to their slots (lap `lap` of `nlaps`: only the values whose k falls into this lap) */
+template <int QM>
+TB_RX_HD void tb_rx_scatter_symbol(const tb_rx_geom &g, const tb_sym<QM> &sy, uint32_t jj, int16_t *e_lds, uint32_t lap, uint32_t nlaps)
 {
-  switch (Qm) {
-    case 2: tb_rx_phase_scatter_lap<2>(g, f, e_lds, lap, nlaps, tid, nt); break;
-    case 4: tb_rx_phase_scatter_lap<4>(g, f, e_lds, lap, nlaps, tid, nt); break;
-    case 6: tb_rx_phase_scatter_lap<6>(g, f, e_lds, lap, nlaps, tid, nt); break;
-    default: tb_rx_phase_scatter_lap<8>(g, f, e_lds, lap, nlaps, tid, nt); break;
+  const uint32_t V = g.V, rank0 = g.rank0, Foffset = g.Foffset, Fin = g.Fin, p_align = g.p_align, Ncb = g.Ncb, EQ = g.E / QM;
+  const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
+#pragma unroll
+  for (int i = 0; i < QM; i++) {
+    const int16_t v = (int16_t)(sy.w[i >> 1] >> (16 * (i & 1)));
+    const uint32_t k = (uint32_t)i * EQ + jj;
+    if (nlaps == 1 || (k >= k_lo && k < k_hi)) {
+      uint32_t r = rank0 + (k - k_lo);
+      r = r >= V ? r - V : r;
+      const uint32_t q = tb_rx_slot(r < Foffset ? r : r + Fin, p_align, Ncb);
+      e_lds[q] = lap == 0 ? v : (int16_t)(e_lds[q] + v);
+    }
+  }
+}
+template <int QM>
+TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *e_lds, uint32_t lap, uint32_t nlaps,
+                                      uint32_t tid, uint32_t nt, const tb_rx_first<QM> &first)
+{
+  const uint32_t EQ = g.E / QM;
+  const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
+#pragma unroll
+  for (int u = 0; u < TB_RX_U; u++) { /* the symbols loaded ahead */
+    const uint32_t jj = tid + (uint32_t)u * nt;
+    if (jj < EQ)
+      tb_rx_scatter_symbol<QM>(g, first.sy[u], jj, e_lds, lap, nlaps);
+  }
+  for (uint32_t jj0 = tid + TB_RX_U * nt; jj0 < EQ; jj0 += 2 * nt) { /* the rest, two symbols per step */
+    tb_sym<QM> sy[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      uint32_t jj = jj0 + (uint32_t)u * nt;
+      jj = jj < EQ ? jj : EQ - 1;
+      if (vec) {
+        sy[u] = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+      } else {
+#pragma unroll
+        for (int i = 0; i < QM; i += 2)
+          sy[u].w[i >> 1] = (uint32_t)(uint16_t)f[(size_t)jj * QM + i] | ((uint32_t)(uint16_t)f[(size_t)jj * QM + i + 1] << 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t jj = jj0 + (uint32_t)u * nt;
+      if (jj < EQ)
+        tb_rx_scatter_symbol<QM>(g, sy[u], jj, e_lds, lap, nlaps);
+    }
   }
 }
 
@@ -242,29 +262,38 @@ TB_RX_HD void tb_rx_phase_stream(const tb_rx_geom &g, const int16_t *e_lds, int1
 }
 
 #if defined(__HIPCC__)
-/* the three phases with their barriers, executed by every thread of the workgroup (wave-uniform arguments) */
-__device__ __forceinline__ void tb_rx_dematch_block(const tb_rx_geom &g, uint32_t Qm, const int16_t *__restrict__ f, int16_t *__restrict__ w,
-                                                    int8_t *__restrict__ l, int16_t *e_lds)
+/* the phases with their barriers, executed by every thread of the workgroup (wave-uniform arguments) */
+template <int QM>
+__device__ __forceinline__ void tb_rx_dematch_block_qm(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *__restrict__ w,
+                                                       int8_t *__restrict__ l, int16_t *e_lds, unsigned long long *stamps)
 {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  tb_rx_first<QM> first;
+  tb_rx_phase_load_first<QM>(g, f, tid, nt, first);
   tb_rx_phase_zero(g, e_lds, l, tid, nt);
   __syncthreads();
+  if (stamps && tid == 0)
+    stamps[0] = wall_clock64();
   const uint32_t nlaps = tb_rx_laps(g);
-  switch (Qm) { /* (outside the lap loop: one instantiation's loop per segment) */
-    case 2:
-      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<2>(g, f, e_lds, lap, nlaps, tid, nt); __syncthreads(); }
-      break;
-    case 4:
-      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<4>(g, f, e_lds, lap, nlaps, tid, nt); __syncthreads(); }
-      break;
-    case 6:
-      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<6>(g, f, e_lds, lap, nlaps, tid, nt); __syncthreads(); }
-      break;
-    default:
-      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<8>(g, f, e_lds, lap, nlaps, tid, nt); __syncthreads(); }
-      break;
+  for (uint32_t lap = 0; lap < nlaps; lap++) {
+    tb_rx_phase_scatter_lap<QM>(g, f, e_lds, lap, nlaps, tid, nt, first);
+    __syncthreads();
   }
+  if (stamps && tid == 0)
+    stamps[1] = wall_clock64();
   tb_rx_phase_stream(g, e_lds, w, l, tid, nt);
+  if (stamps && tid == 0)
+    stamps[2] = wall_clock64();
+}
+__device__ __forceinline__ void tb_rx_dematch_block(const tb_rx_geom &g, uint32_t Qm, const int16_t *__restrict__ f, int16_t *__restrict__ w,
+                                                    int8_t *__restrict__ l, int16_t *e_lds, unsigned long long *stamps = nullptr)
+{
+  switch (Qm) { /* one instantiation's loops per segment */
+    case 2: tb_rx_dematch_block_qm<2>(g, f, w, l, e_lds, stamps); break;
+    case 4: tb_rx_dematch_block_qm<4>(g, f, w, l, e_lds, stamps); break;
+    case 6: tb_rx_dematch_block_qm<6>(g, f, w, l, e_lds, stamps); break;
+    default: tb_rx_dematch_block_qm<8>(g, f, w, l, e_lds, stamps); break;
+  }
 }
 #endif
 #endif

@@ -75,7 +75,7 @@ struct tb_rx_fused_io {
   {
     const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u;
     if (x.trace && tid == 0)
-      x.trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+      x.trace[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
     const tb_seg_ptr_t sj = seg();
     const tb_tb_ptr_t tj = tb();
     const uint32_t tbi = sj->tb, C = tj->C, seg_bytes = tj->seg_bytes, bbytes = tj->B >> 3, abytes = tj->A >> 3;
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     while ((long long)wall_clock64() < until)
       __builtin_amdgcn_s_sleep(32);
   }
-  unsigned long long *tr = x.trace ? x.trace + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long *tr = x.trace ? x.trace + (size_t)blockIdx.x * 16 : nullptr;
   if (tr && threadIdx.x == 0) {
     tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID: wave, simd, cu, sh, se ... */
     tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* HW_REG_XCC_ID */
@@ -218,11 +218,13 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     const tb_seg_ptr_t sj = io.seg();
     const tb_rx_geom g = tb_rx_geometry(sj);
     tb_rx_dematch_block(g, sj->Qm, x.llr + sj->llr_off, x.harq + sj->harq_off, const_cast<int8_t *>(a.llr) + sj->l_off,
-                        reinterpret_cast<int16_t *>(fsm));
+                        reinterpret_cast<int16_t *>(fsm), tr ? tr + 7 : nullptr);
     /* the decoder input is read back by other waves of this workgroup only: workgroup scope (see ldpc_dec_fast_pull_kernel) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (tr && threadIdx.x == 0)
+      tr[10] = wall_clock64();
   }
   if (tr && threadIdx.x == 0)
     tr[3] = wall_clock64();

@@ -84,7 +84,7 @@ class nrLDPC_hip_enc_batch_t(C.Structure):
 _CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
 
 EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "LDPCdecoder_batch", "LDPCencoder_batch",
-           "LDPCdecoder_jobs",
+           "LDPCdecoder_jobs", "nrLDPC_hip_checkbuildver",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
 

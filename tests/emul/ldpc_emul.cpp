@@ -341,6 +341,19 @@ extern "C" int ldpc_emul_desc_edges(int BG, int Z, int R, int *dims /*nrows,ncol
 #include "../../openairinterface5g_amd/csrc/tb_rx_core.h"
 #include "../../openairinterface5g_amd/csrc/nr_coding_host.h"
 
+template <int QM> static void emul_scatter(const tb_rx_geom &g, const int16_t *f, int16_t *e_lds, int8_t *l, int nt)
+{
+  std::vector<tb_rx_first<QM>> first(nt); /* every thread's registers across the barrier */
+  for (int tid = 0; tid < nt; tid++) {
+    tb_rx_phase_load_first<QM>(g, f, (uint32_t)tid, (uint32_t)nt, first[tid]);
+    tb_rx_phase_zero(g, e_lds, l, (uint32_t)tid, (uint32_t)nt);
+  }
+  const uint32_t nlaps = tb_rx_laps(g);
+  for (uint32_t lap = 0; lap < nlaps; lap++)
+    for (int tid = 0; tid < nt; tid++)
+      tb_rx_phase_scatter_lap<QM>(g, f, e_lds, lap, nlaps, (uint32_t)tid, (uint32_t)nt, first[tid]);
+}
+
 extern "C" int tb_emul_rx_dematch(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_t C, uint32_t F, uint32_t K, int rv, uint32_t E, uint32_t Qm,
                                   uint32_t num_llr, int clear, int nt, const int16_t *f, int16_t *w, int8_t *l)
 {
@@ -356,12 +369,12 @@ extern "C" int tb_emul_rx_dematch(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_
   std::vector<tb_u32x4> lds(g.span / 8 + 1);
   memset(lds.data(), 0x5a, lds.size() * sizeof(tb_u32x4)); /* poison: phase Z must initialise what is read */
   int16_t *e_lds = reinterpret_cast<int16_t *>(lds.data());
-  for (int tid = 0; tid < nt; tid++)
-    tb_rx_phase_zero(g, e_lds, l, (uint32_t)tid, (uint32_t)nt);
-  const uint32_t nlaps = tb_rx_laps(g);
-  for (uint32_t lap = 0; lap < nlaps; lap++)
-    for (int tid = 0; tid < nt; tid++)
-      tb_rx_phase_scatter_lap_qm(Qm, g, f, e_lds, lap, nlaps, (uint32_t)tid, (uint32_t)nt);
+  switch (Qm) {
+    case 2: emul_scatter<2>(g, f, e_lds, l, nt); break;
+    case 4: emul_scatter<4>(g, f, e_lds, l, nt); break;
+    case 6: emul_scatter<6>(g, f, e_lds, l, nt); break;
+    default: emul_scatter<8>(g, f, e_lds, l, nt); break;
+  }
   for (int tid = 0; tid < nt; tid++)
     tb_rx_phase_stream(g, e_lds, w, l, (uint32_t)tid, (uint32_t)nt);
   return (int)g.span;

@@ -6,7 +6,7 @@ durations by round, and how many of a CU's workgroups were in their prologue at 
 import sys
 import numpy as np
 
-d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)
 hw, xcc = d[:, 0].astype(np.int64), d[:, 1].astype(np.int64)
 t = d[:, 2:6].astype(np.int64)
 t0 = t[:, 0].min()
@@ -25,6 +25,11 @@ pairs = [v[:2] for v in first.values() if len(v) >= 2]
 print("first two workgroups of a CU differ in launch index by:", np.bincount(np.minimum(np.array([b - a for a, b in pairs]), 600))[:8].tolist(), "...",
       "median", int(np.median([b - a for a, b in pairs])))
 pro, dec, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+if d[:, 7].any():      # finer stamps of the prologue
+    ps = (d[:, 7:11].astype(np.int64) - t0) / 100.0
+    steps = np.stack([ps[:, 0] - t[:, 0], ps[:, 1] - ps[:, 0], ps[:, 2] - ps[:, 1], ps[:, 3] - ps[:, 2], t[:, 1] - ps[:, 3]], axis=1)
+    print("prologue steps (mean us over all workgroups): clear LDS image %.2f | scatter LLRs %.2f | stream soft buffer + decoder input %.2f | "
+          "stores visible (fence + barrier) %.2f | (kernel wrapper -> block body) %.2f" % tuple(steps.mean(axis=0)))
 order = np.argsort(t[:, 0])
 q = max(1, n // 4)
 for k in range(0, n, q):
