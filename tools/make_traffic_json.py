@@ -11,7 +11,9 @@ def maxval(sub, counter):
     vals = []
     for f in glob.glob(str(root / sub / "**" / "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "ldpc_dec" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            # the headline launch only: homogeneous batch, parity-check stop (bench.py's chain_roofline leg runs other kernels
+            # whose argument list mentions ldpc_dec_args)
+            if row["Kernel_Name"].startswith("void ldpc_dec_fast_kernel<false, false>") and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
     return max(vals)   # the fixed-work launches (9 passes) are the largest
 model = sorted(Path("profiles").glob("r0*/valu_issue_model.json"))[-1]  # the newest round's
