@@ -407,7 +407,10 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
           _mm_prefetch(reinterpret_cast<const char *>(c.out) + off, _MM_HINT_T0);
         /* two steps: every unit is waited for and taken into a local copy first, the caller's p_out is written only when
          * all of them are there -- a call that fails half way leaves p_out as it was */
-        __m128i got[(68 * 384 / 32 * 4 / 12) + 2];
+        static thread_local std::vector<__m128i> got_v; /* (up to 2 177 units for a one-byte-per-bit output row of 68 x 384) */
+        if (got_v.size() < (size_t)n_units)
+          got_v.resize((size_t)n_units);
+        __m128i *got = got_v.data();
         for (int u = 0; u < n_units; u++) {
           const __m128i *src = reinterpret_cast<const __m128i *>(c.out) + u;
           __m128i v = _mm_load_si128(src);
