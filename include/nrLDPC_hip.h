@@ -247,7 +247,8 @@ int32_t nrLDPC_hip_dlsch_encode(const nrLDPC_hip_tb_batch_t *b);
 int32_t nrLDPC_hip_ulsch_decode(const nrLDPC_hip_tb_batch_t *b);
 /* Soft buffers kept by the library (NRLDPC_HIP_MEM_HARQ_LIBRARY).  release: forget one transport block's buffers (its HARQ
  * process ended) / all of them; read: copy int16 values [first, first + n) of a block's C x harq_stride soft values to host
- * memory (diagnostics and tests; waits for the GPU).  0, or -1 (unknown id, range outside the buffers). */
+ * memory (diagnostics and tests; a device-memory decode call that wrote them must have completed on its stream).  0, or -1
+ * (unknown id, range outside the buffers). */
 int32_t nrLDPC_hip_harq_release(uint64_t id);
 int32_t nrLDPC_hip_harq_release_all(void);
 int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t n);

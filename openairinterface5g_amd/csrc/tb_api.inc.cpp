@@ -1428,8 +1428,10 @@ int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t
   }
   if (!dst || first + n > e.n)
     return set_error("range outside the soft buffers");
+  /* (no device-wide wait: the resident server kernels of the per-segment entry points may be running for as long as
+   * requests keep coming.  A host-memory decode call has finished when it returns; after a device-memory call the caller
+   * waits for its own stream before it looks.) */
   UseDevice use(g.dev[e.dev]);
-  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(dst, e.p + first, n * sizeof(int16_t), hipMemcpyDeviceToHost));
   return 0;
 }

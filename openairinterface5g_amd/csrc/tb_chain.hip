@@ -14,6 +14,16 @@
 #include "tb_chain.h"
 #include "ldpc_kernels.h"
 #include "ldpc_enc_packed_core.h"
+/* the separate de-matching launch holds 8 workgroups per CU (64 VGPRs): their occupancy hides the LLRs' latency, and symbols
+ * requested ahead of the clearing would only spill (the fused segment kernel, 126 VGPRs and two workgroups per CU, asks
+ * for four: tb_rx_fused.hip) */
+#define TB_RX_U 0
+/* ... and a thread of a first transmission keeps two stores in flight, not all of them: with 32 waves per CU storing
+ * nothing but zeros and saturated sums, an unbounded burst runs 3 % slower than a bounded one (HBM write queues;
+ * profiles/r04/ab_dematch_store_window.txt: 25.3 us unbounded, 24.5 us with a window of 2 = the r03 launch). */
+#ifndef TB_RX_STORE_WINDOW
+#define TB_RX_STORE_WINDOW 2
+#endif
 #include "tb_rx_core.h"
 
 #define TB_THREADS 256

@@ -88,9 +88,10 @@ TB_RX_HD uint32_t tb_rx_laps(const tb_rx_geom &g) { return (g.E + g.V - 1) / g.V
  * in flight together (unconditional loads from a clamped index: a load inside `if (jj < EQ)` is not moved across the
  * branch by the compiler).  A 512-thread workgroup covers a 64QAM segment's 1575 symbols with them; what is left is walked
  * by the loop of tb_rx_phase_scatter_lap. */
-template <int QM> struct tb_rx_first { tb_sym<QM> sy[TB_RX_U]; };
+struct tb_rx_ahead { uint32_t w[TB_RX_U > 0 ? TB_RX_U : 1][4]; }; /* up to Qm = 8 values per symbol; the same storage whatever Qm,
+                                                                    so that only the loads and the scatter are compiled per Qm */
 template <int QM>
-TB_RX_HD void tb_rx_phase_load_first(const tb_rx_geom &g, const int16_t *__restrict__ f, uint32_t tid, uint32_t nt, tb_rx_first<QM> &first)
+TB_RX_HD void tb_rx_phase_load_first(const tb_rx_geom &g, const int16_t *__restrict__ f, uint32_t tid, uint32_t nt, tb_rx_ahead &first)
 {
   const uint32_t EQ = g.E / QM;
   const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
@@ -99,11 +100,14 @@ TB_RX_HD void tb_rx_phase_load_first(const tb_rx_geom &g, const int16_t *__restr
     uint32_t jj = tid + (uint32_t)u * nt;
     jj = jj < EQ ? jj : (EQ ? EQ - 1 : 0);
     if (vec) {
-      first.sy[u] = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+      const tb_sym<QM> sy = *reinterpret_cast<const tb_sym<QM> *>(f + (size_t)jj * QM);
+#pragma unroll
+      for (int i = 0; i < QM / 2; i++)
+        first.w[u][i] = sy.w[i];
     } else {
 #pragma unroll
       for (int i = 0; i < QM; i += 2)
-        first.sy[u].w[i >> 1] = (uint32_t)(uint16_t)f[(size_t)jj * QM + i] | ((uint32_t)(uint16_t)f[(size_t)jj * QM + i + 1] << 16);
+        first.w[u][i >> 1] = (uint32_t)(uint16_t)f[(size_t)jj * QM + i] | ((uint32_t)(uint16_t)f[(size_t)jj * QM + i + 1] << 16);
     }
   }
 }
@@ -127,15 +131,20 @@ TB_RX_HD void tb_rx_scatter_symbol(const tb_rx_geom &g, const tb_sym<QM> &sy, ui
 }
 template <int QM>
 TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *e_lds, uint32_t lap, uint32_t nlaps,
-                                      uint32_t tid, uint32_t nt, const tb_rx_first<QM> &first)
+                                      uint32_t tid, uint32_t nt, const tb_rx_ahead &first)
 {
   const uint32_t EQ = g.E / QM;
   const bool vec = (reinterpret_cast<uintptr_t>(f) & 3) == 0;
 #pragma unroll
   for (int u = 0; u < TB_RX_U; u++) { /* the symbols loaded ahead */
     const uint32_t jj = tid + (uint32_t)u * nt;
-    if (jj < EQ)
-      tb_rx_scatter_symbol<QM>(g, first.sy[u], jj, e_lds, lap, nlaps);
+    if (jj < EQ) {
+      tb_sym<QM> sy;
+#pragma unroll
+      for (int i = 0; i < QM / 2; i++)
+        sy.w[i] = first.w[u][i];
+      tb_rx_scatter_symbol<QM>(g, sy, jj, e_lds, lap, nlaps);
+    }
   }
   for (uint32_t jj0 = tid + TB_RX_U * nt; jj0 < EQ; jj0 += 2 * nt) { /* the rest, two symbols per step */
     tb_sym<QM> sy[2];
@@ -223,34 +232,34 @@ TB_RX_HD void tb_rx_phase_stream(const tb_rx_geom &g, const int16_t *e_lds, int1
             l[twoZ + p0 + t] = lo.b[t];
     }
   };
-  /* two chunks per thread and step, 8 nt positions apart: both soft-buffer loads are in flight before either is used (the
-   * step of a retransmission is a round trip to HBM; the stores of the first chunk cannot be moved across the second's load
-   * by the compiler, which does not know that the two never overlap) */
+  /* gfx9 counts loads AND stores in one in-order counter (vmcnt): waiting for a load waits for every store issued before
+   * it.  The loop over a thread's chunks therefore must not wait for a load that was issued behind the previous chunk's
+   * stores -- each iteration would then take a store's round trip to HBM, twelve times per thread (that was the kernel's
+   * critical path: profiles/r04/ab_dematch_store_waits.txt).  First transmissions load nothing, and their loop has no
+   * load in it (the compiler cannot drop the wait from a loop in which the load is conditional); retransmissions request
+   * the NEXT chunk's soft values before the current chunk's stores go out. */
   const chunk_t zero = {(tb_u32x4){0u, 0u, 0u, 0u}};
-#ifndef TB_RX_BCHUNKS
-#define TB_RX_BCHUNKS 1
+  if (clear) {
+    for (uint32_t p0 = 8 * tid; p0 < n8; p0 += 8 * nt) {
+      finish(p0, zero);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TB_RX_STORE_WINDOW)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB_RX_STORE_WINDOW) : "memory"); /* tuning knob: stores a thread keeps in flight */
 #endif
-#if TB_RX_BCHUNKS == 2
-  for (uint32_t p0 = 8 * tid; p0 < n8; p0 += 16 * nt) {
-    const uint32_t p1 = p0 + 8 * nt;
-    chunk_t old0 = zero, old1 = zero;
-    if (!clear) {
-      old0.q = *reinterpret_cast<const tb_u32x4 *>(w + p0);
-      if (p1 < n8)
-        old1.q = *reinterpret_cast<const tb_u32x4 *>(w + p1);
     }
-    finish(p0, old0);
-    if (p1 < n8)
-      finish(p1, old1);
+  } else {
+    uint32_t p0 = 8 * tid;
+    chunk_t cur = zero;
+    if (p0 < n8)
+      cur.q = *reinterpret_cast<const tb_u32x4 *>(w + p0);
+    for (; p0 < n8; p0 += 8 * nt) {
+      const uint32_t pn = p0 + 8 * nt;
+      chunk_t nxt = zero;
+      if (pn < n8)
+        nxt.q = *reinterpret_cast<const tb_u32x4 *>(w + pn);
+      finish(p0, cur);
+      cur = nxt;
+    }
   }
-#else
-  for (uint32_t p0 = 8 * tid; p0 < n8; p0 += 8 * nt) {
-    chunk_t old0 = zero;
-    if (!clear)
-      old0.q = *reinterpret_cast<const tb_u32x4 *>(w + p0);
-    finish(p0, old0);
-  }
-#endif
   for (uint32_t p = n8 + tid; p < n; p += nt) {
     const int16_t ev = received(p);
     const int16_t acc = (int16_t)((clear ? 0 : w[p]) + ev);
@@ -262,38 +271,43 @@ TB_RX_HD void tb_rx_phase_stream(const tb_rx_geom &g, const int16_t *e_lds, int1
 }
 
 #if defined(__HIPCC__)
-/* the phases with their barriers, executed by every thread of the workgroup (wave-uniform arguments) */
-template <int QM>
-__device__ __forceinline__ void tb_rx_dematch_block_qm(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *__restrict__ w,
-                                                       int8_t *__restrict__ l, int16_t *e_lds, unsigned long long *stamps)
+/* the phases with their barriers, executed by every thread of the workgroup (wave-uniform arguments).  Only the loads and
+ * the scatter are compiled per modulation order; the clearing and the streaming phase exist once. */
+__device__ __forceinline__ void tb_rx_dematch_block(const tb_rx_geom &g, uint32_t Qm, const int16_t *__restrict__ f, int16_t *__restrict__ w,
+                                                    int8_t *__restrict__ l, int16_t *e_lds, unsigned long long *stamps = nullptr)
 {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  tb_rx_first<QM> first;
-  tb_rx_phase_load_first<QM>(g, f, tid, nt, first);
+  tb_rx_ahead first;
+  switch (Qm) {
+    case 2: tb_rx_phase_load_first<2>(g, f, tid, nt, first); break;
+    case 4: tb_rx_phase_load_first<4>(g, f, tid, nt, first); break;
+    case 6: tb_rx_phase_load_first<6>(g, f, tid, nt, first); break;
+    default: tb_rx_phase_load_first<8>(g, f, tid, nt, first); break;
+  }
   tb_rx_phase_zero(g, e_lds, l, tid, nt);
   __syncthreads();
   if (stamps && tid == 0)
     stamps[0] = wall_clock64();
   const uint32_t nlaps = tb_rx_laps(g);
-  for (uint32_t lap = 0; lap < nlaps; lap++) {
-    tb_rx_phase_scatter_lap<QM>(g, f, e_lds, lap, nlaps, tid, nt, first);
-    __syncthreads();
+  switch (Qm) {
+    case 2:
+      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<2>(g, f, e_lds, lap, nlaps, tid, nt, first); __syncthreads(); }
+      break;
+    case 4:
+      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<4>(g, f, e_lds, lap, nlaps, tid, nt, first); __syncthreads(); }
+      break;
+    case 6:
+      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<6>(g, f, e_lds, lap, nlaps, tid, nt, first); __syncthreads(); }
+      break;
+    default:
+      for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<8>(g, f, e_lds, lap, nlaps, tid, nt, first); __syncthreads(); }
+      break;
   }
   if (stamps && tid == 0)
     stamps[1] = wall_clock64();
   tb_rx_phase_stream(g, e_lds, w, l, tid, nt);
   if (stamps && tid == 0)
     stamps[2] = wall_clock64();
-}
-__device__ __forceinline__ void tb_rx_dematch_block(const tb_rx_geom &g, uint32_t Qm, const int16_t *__restrict__ f, int16_t *__restrict__ w,
-                                                    int8_t *__restrict__ l, int16_t *e_lds, unsigned long long *stamps = nullptr)
-{
-  switch (Qm) { /* one instantiation's loops per segment */
-    case 2: tb_rx_dematch_block_qm<2>(g, f, w, l, e_lds, stamps); break;
-    case 4: tb_rx_dematch_block_qm<4>(g, f, w, l, e_lds, stamps); break;
-    case 6: tb_rx_dematch_block_qm<6>(g, f, w, l, e_lds, stamps); break;
-    default: tb_rx_dematch_block_qm<8>(g, f, w, l, e_lds, stamps); break;
-  }
 }
 #endif
 #endif

@@ -457,7 +457,8 @@ def chain_timing(enable=True, read=False):
 
 
 def harq_read(harq_id, n, first=0):
-    """int16[n] of the soft buffers the library keeps for block `harq_id` (MEM_HARQ_LIBRARY); waits for the GPU."""
+    """int16[n] of the soft buffers the library keeps for block `harq_id` (MEM_HARQ_LIBRARY); after a device-memory call:
+    synchronise its stream first."""
     out = np.zeros(n, np.int16)
     _check(_tb_lib().nrLDPC_hip_harq_read(harq_id, out.ctypes.data, first, n), "nrLDPC_hip_harq_read")
     return out

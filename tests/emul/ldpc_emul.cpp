@@ -343,7 +343,7 @@ extern "C" int ldpc_emul_desc_edges(int BG, int Z, int R, int *dims /*nrows,ncol
 
 template <int QM> static void emul_scatter(const tb_rx_geom &g, const int16_t *f, int16_t *e_lds, int8_t *l, int nt)
 {
-  std::vector<tb_rx_first<QM>> first(nt); /* every thread's registers across the barrier */
+  std::vector<tb_rx_ahead> first(nt); /* every thread's registers across the barrier */
   for (int tid = 0; tid < nt; tid++) {
     tb_rx_phase_load_first<QM>(g, f, (uint32_t)tid, (uint32_t)nt, first[tid]);
     tb_rx_phase_zero(g, e_lds, l, (uint32_t)tid, (uint32_t)nt);

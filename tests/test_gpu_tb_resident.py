@@ -209,3 +209,70 @@ def test_device_resident_batches_sharded_over_logical_devices(hip, tmp_path):
         for rnd in range(2):
             for what in ("pay", "ack", "itm", "llrLen"):
                 assert np.array_equal(o[f"caller{rnd}_{what}"], o[f"library{rnd}_{what}"]), (rnd, what)
+
+
+def test_residency_flags_and_mixed_call_errors(hip):
+    """What the new entry points refuse, and the page-locking helpers a C caller without the HIP runtime uses: a soft-buffer
+    pointer that is not device memory under NRLDPC_HIP_MEM_HARQ_DEVICE, both residency flags at once, unknown flag bits,
+    encode with residency flags, releasing / reading an id the library does not hold, a read outside the buffers; a mixed
+    code-block call in host memory or with two stop modes; nrLDPC_hip_host_register / _unregister on an ordinary array, which
+    the GPU then reads in place (the call's results equal the pageable run's)."""
+    import ctypes as C
+    import torch
+    m = hip.ldpc
+    L = m._tb_lib()
+    rng = np.random.default_rng(3)
+    tbs = make_tbs()[:3]
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    llrs = [_noisy(rng, O.dlsch_encode(t, p), 2.0) for t, p in zip(tbs, pays)]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    po, co, ho, _ = m.tb_layout(tbs)
+    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    llr = np.zeros(int(co[-1]) + 16, np.int16)
+    for i, x in enumerate(llrs):
+        llr[co[i]:co[i] + tbs[i]["G"]] = x
+    ack, itm = np.zeros(3, np.uint8), np.zeros(3, np.int32)
+    harq_h = np.zeros(sum(segs) * m.HARQ_STRIDE, np.int16)
+    arr = m._tb_array([dict(t, round=0) for t in tbs], po, co, ho, 8)
+
+    def call(mem, harq_ptr, fn=L.nrLDPC_hip_ulsch_decode):
+        b = m.nrLDPC_hip_tb_batch_t(n_tb=3, tb=arr, payload=pay.ctypes.data, coded=llr.ctypes.data, harq=harq_ptr, harq_stride=m.HARQ_STRIDE,
+                                    ack=ack.ctypes.data, iter_max=itm.ctypes.data, mem=mem, stream=None)
+        return fn(C.byref(b))
+
+    assert call(m.MEM_HOST | m.MEM_HARQ_DEVICE, harq_h.ctypes.data) != 0 and b"harq" in L.nrLDPC_hip_last_error().lower()
+    assert call(m.MEM_HOST | m.MEM_HARQ_DEVICE | m.MEM_HARQ_LIBRARY, None) != 0
+    assert call(m.MEM_HOST | 8, harq_h.ctypes.data) != 0
+    assert call(m.MEM_HOST, None) != 0                                          # host soft buffers need a pointer
+    assert call(m.MEM_HOST | m.MEM_HARQ_LIBRARY, None, L.nrLDPC_hip_dlsch_encode) != 0
+    m.harq_release()
+    assert L.nrLDPC_hip_harq_release(12345) != 0 and L.nrLDPC_hip_harq_read(12345, harq_h.ctypes.data, 0, 8) != 0
+    # pageable run = the reference result; then the same arrays page-locked in place
+    assert call(m.MEM_HOST, harq_h.ctypes.data) == 0 and ack.all()
+    ref = (pay.copy(), itm.copy(), harq_h.copy())
+    assert call(m.MEM_HOST | m.MEM_HARQ_LIBRARY, None) == 0 and ack.all()       # ids = the harq offsets of the layout
+    got = np.concatenate([m.harq_read(int(ho[i]), segs[i] * m.HARQ_STRIDE) for i in range(3)])
+    assert L.nrLDPC_hip_harq_read(int(ho[0]), harq_h.ctypes.data, segs[0] * m.HARQ_STRIDE - 4, 8) != 0     # past the end
+    for i in range(3):      # what the blocks use of their rows equals the host run's
+        s = O.segmentation(None, O.len_with_crc(1, tbs[i]["A"]), tbs[i]["BG"])
+        N = (66 if tbs[i]["BG"] == 1 else 50) * s["Z"]
+        for r in range(segs[i]):
+            a = (sum(segs[:i]) + r) * m.HARQ_STRIDE
+            assert np.array_equal(got[a:a + N], ref[2][a:a + N]), (i, r)
+    assert L.nrLDPC_hip_host_register(llr.ctypes.data, llr.nbytes) == 0
+    try:
+        pay[:] = 0
+        assert call(m.MEM_HOST | m.MEM_HARQ_LIBRARY, None) == 0 and ack.all() and np.array_equal(pay, ref[0]) and np.array_equal(itm, ref[1])
+    finally:
+        assert L.nrLDPC_hip_host_unregister(llr.ctypes.data) == 0
+    m.harq_release()
+    # mixed code-block calls
+    blk = [dict(BG=1, Z=64, R=13, llr=torch.zeros(68 * 64, dtype=torch.int8, device="cuda"),
+                out=torch.zeros(m.out_bytes(1, 64, 13), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    n_it = torch.zeros(2, dtype=torch.int32, device="cuda")
+    jobs = m.PreparedDecJobs(blk, n_it)
+    assert L.LDPCdecoder_jobs(jobs.arr, 2, n_it.data_ptr(), m.MEM_HOST, None) != 0
+    jobs.arr[1].params.check_crc = C.cast(m._CRC_SENTINEL, C.c_void_p).value      # two stop modes in one call
+    jobs.arr[1].params.E, jobs.arr[1].params.crc_type = 22 * 64, 1
+    assert L.LDPCdecoder_jobs(jobs.arr, 2, n_it.data_ptr(), m.MEM_DEVICE, None) != 0
+    assert L.LDPCdecoder_jobs(jobs.arr, 0, n_it.data_ptr(), m.MEM_DEVICE, None) == 0
