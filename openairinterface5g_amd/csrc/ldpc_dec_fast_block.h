@@ -57,7 +57,7 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             check-node phase when the block has converged); same results, same pass counts */
 
 #define LDPC_EAGER_MAX_BAD_LANES 96
-#define LDPC_TIMING_SLOTS 20
+#define LDPC_TIMING_SLOTS 28
 
 /* next ticket of a task queue (wave-uniform) */
 __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
@@ -137,7 +137,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   if (tid < 16)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen, [6] eager check,
-                       [8], [9] check-node task queues of even / odd passes, [10], [11] bit-node task queues likewise */
+                       [8], [9] task queues of even / odd passes */
   /* (the message array is not initialised: the first check-node phase takes r = 0 without reading it and writes every
    * message, wrap-around bytes included)
    * APP := channel LLR (both copies), so that with r = 0 the first check-node phase sees q = llr */
@@ -193,9 +193,15 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       tlog_n++; \
     } \
   } while (0)
+#define LDPC_TSTAMP(id) \
+  do { \
+    LDPC_TLOG_BEGIN(); \
+    LDPC_TLOG_END(3, id); \
+  } while (0)
 #else
 #define LDPC_TLOG_BEGIN() do { } while (0)
 #define LDPC_TLOG_END(phase, deg) do { } while (0)
+#define LDPC_TSTAMP(id) do { } while (0)
 #endif
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
@@ -205,8 +211,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     int tb_ab = 0;
     if (io.has_abort() && tid == 0 && p >= 2 && io.tb_abort())
       tb_ab = __hip_atomic_load(io.tb_abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int *cnq = &flags[8 + (p & 1)], *bnq = &flags[10 + (p & 1)]; /* this pass' task queues */
-    (void)cnq;
+    /* this pass' task queue: tickets 0 .. n_cn_tasks - 1 are the check-node tasks, the ones behind them the bit-node
+     * tickets -- ONE counter, so that the draw that finds the check-node tasks gone is already the draw of a bit-node
+     * ticket (a draw is an LDS atomic round trip on a busy CU: 250-300 clocks, profiles/r04/timeline_phase_switch.txt) */
+    int *const pq = &flags[8 + (p & 1)];
 #ifdef LDPC_ABLATE_CN
     syn = 1;
 #else
@@ -218,8 +226,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
      * comes out of the barrier with its task in hand: the draw is an LDS atomic round trip, and right after a barrier
      * nobody has work to hide it behind (profiles/r03/timeline_*.txt: 1.3 k clocks between the phases). */
     if (p == 1)
-      cn_ticket = ldpc_draw(cnq, lane);
-    for (int task = cn_ticket; task < n_cn_tasks; task = ldpc_draw(cnq, lane)) {
+      cn_ticket = ldpc_draw(pq, lane);
+    int task = cn_ticket;
+    for (; task < n_cn_tasks; task = ldpc_draw(pq, lane)) {
       LDPC_TLOG_BEGIN();
       const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
       const int item = code->f_cn_task[task][2] + lane;
@@ -260,7 +269,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       LDPC_TLOG_END(0, deg);
     }
 #endif
-    const int bn_ticket = ldpc_draw(bnq, lane);
+    const int bn_ticket = task - n_cn_tasks;
     {
       /* flags[p & 1] = how many lanes saw an unsatisfied check of the previous pass (0 = none: the stop criterion; the
        * count itself only steers the eager check below) */
@@ -272,8 +281,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     }
     if (tid == 0) {
       flags[2] = 0;
-      flags[8 + ((p + 1) & 1)] = 0; /* the next pass' queues: last drawn from before the previous pass' barriers, */
-      flags[10 + ((p + 1) & 1)] = 0; /* first drawn from behind the barrier below */
+      flags[8 + ((p + 1) & 1)] = 0; /* the next pass' queue: last drawn from before the previous pass' last barrier, first
+                                       drawn from behind the barrier below */
       /* decoder.c:556-559: once a segment of the transport block has failed, its siblings give up at their next pass */
       if (tb_ab)
         flags[3] = 1;
@@ -295,11 +304,11 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     }
 #ifndef LDPC_ABLATE_BN
     if constexpr (IO::bn_tickets) {
-    for (int ticket = bn_ticket; ticket < n_bn_tickets; ticket = ldpc_draw(bnq, lane)) {
-      const int task = code->f_bn_ticket[ticket][0], cnt = code->f_bn_ticket[ticket][1];
+    for (int ticket = bn_ticket; ticket < n_bn_tickets; ticket = ldpc_draw(pq, lane) - n_cn_tasks) {
       LDPC_TLOG_BEGIN();
-      const int item0 = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];
-      const int maxdeg = code->f_bn_task[task][2];
+      /* (ticket and task record in one scalar load) */
+      const int item0 = code->f_bn_rec[ticket][0] + lane, end = code->f_bn_rec[ticket][1];
+      const int maxdeg = code->f_bn_rec[ticket][2], cnt = code->f_bn_rec[ticket][3];
       if (cnt == 1) {
         if (item0 < end) {
           const int sc = (int)ldpc_umulhi((uint32_t)item0, zq_magic), j = item0 - sc * zq;
@@ -328,7 +337,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       LDPC_TLOG_END(1, maxdeg);
     }
     } else {
-    for (int ticket = bn_ticket; ticket * bn_group < n_bn_tasks; ticket = ldpc_draw(bnq, lane)) {
+    for (int ticket = bn_ticket; ticket * bn_group < n_bn_tasks; ticket = ldpc_draw(pq, lane) - n_cn_tasks) {
       for (int task = ticket * bn_group; task < (ticket + 1) * bn_group && task < n_bn_tasks; task++) {
         LDPC_TLOG_BEGIN();
         const int item = code->f_bn_task[task][0] + lane, end = code->f_bn_task[task][1];

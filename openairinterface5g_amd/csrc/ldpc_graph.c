@@ -282,6 +282,13 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
                                 : (d->f_ext_global ? (uint32_t)(c * Z)
                                                    : (uint32_t)(d->f_lds_ext + (c - d->ncore) * ((mb > 1 || d->f_sub == 4) ? d->f_rstride : Z)));
   }
+  for (int k = 0; k < d->f_n_bn_tickets; k++) {
+    const int task = d->f_bn_ticket[k][0];
+    d->f_bn_rec[k][0] = d->f_bn_task[task][0];
+    d->f_bn_rec[k][1] = d->f_bn_task[task][1];
+    d->f_bn_rec[k][2] = d->f_bn_task[task][2];
+    d->f_bn_rec[k][3] = d->f_bn_ticket[k][1];
+  }
   d->f_ok = 1;
 }
 

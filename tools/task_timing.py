@@ -11,7 +11,7 @@ import openairinterface5g_amd as pkg
 m = pkg.ldpc
 pkg.LDPCinit()
 BG, Z, R = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (1, 384, 13)))
-SLOTS, n = 20, 1024
+SLOTS, n = 28, 1024
 llr = torch.randint(-128, 128, (n, m.NCOLS[(BG, R)] * Z), dtype=torch.int8, device="cuda")
 llr[:, :2 * Z] = 0
 out = torch.zeros((n, max(m.out_bytes(BG, Z, R), 16 * SLOTS * 16 + 64)), dtype=torch.uint8, device="cuda")
@@ -38,6 +38,10 @@ for w, row in enumerate(rows):
     if not row:
         continue
     def name(ph, deg):
+        if ph == 2:
+            return "w"
+        if ph == 3:
+            return "s%d" % deg
         return "C%d" % deg if ph == 0 else ("B%d" % (deg & 63) + ("x%d" % (deg // 64 + 1) if deg >= 64 else ""))
     print("wave %2d:" % w, "  ".join("%s[%d..%d]" % (name(ph, deg), s - first, e - first) for ph, deg, s, e in row))
     for ph in (0, 1):
