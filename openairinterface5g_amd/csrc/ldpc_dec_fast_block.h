@@ -68,6 +68,15 @@ __device__ __forceinline__ int ldpc_draw(int *counter, int lane)
   return LDPC_UNIFORM(t);
 }
 
+/* the same in two halves: the request (an LDS atomic that returns its value whenever) and its use */
+__device__ __forceinline__ int ldpc_draw_issue(int *counter, int lane)
+{
+  int t = 0;
+  if (lane == 0)
+    t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return t;
+}
+
 /* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
 template <class IO>
 __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const IO &io)
@@ -304,7 +313,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     }
 #ifndef LDPC_ABLATE_BN
     if constexpr (IO::bn_tickets) {
-    for (int ticket = bn_ticket; ticket < n_bn_tickets; ticket = ldpc_draw(pq, lane) - n_cn_tasks) {
+    /* the next ticket is asked for behind an item's gather and looked at behind its store: the draw's round trip runs
+     * under the tail of the task (profiles/r04/decoder_ab25_late_draw.txt) */
+    for (int ticket = bn_ticket, nxt = 0; ticket < n_bn_tickets; ticket = LDPC_UNIFORM(nxt) - n_cn_tasks) {
       LDPC_TLOG_BEGIN();
       /* (ticket and task record in one scalar load) */
       const int item0 = code->f_bn_rec[ticket][0] + lane, end = code->f_bn_rec[ticket][1];
@@ -314,7 +325,12 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
           const int sc = (int)ldpc_umulhi((uint32_t)item0, zq_magic), j = item0 - sc * zq;
           const uint32_t colrec = coltbl[sc];
           const uint32_t lw = src32[(int)(colrec & 0xffu) * zq + j];
-          ldpc_fast_bn(L, colrec, maxdeg, j, Z, astride, lw);
+          uint32_t acc_e = 0, acc_o = 0;
+          ldpc_fast_bn_gather(L, colrec, maxdeg, j, Z, 0, acc_e, acc_o);
+          nxt = ldpc_draw_issue(pq, lane);
+          ldpc_fast_bn_finish(L, (int)(colrec & 0xffu), (int)((colrec >> 8) & 0xffu), j, Z, astride, lw, acc_e, acc_o, 0);
+        } else {
+          nxt = ldpc_draw_issue(pq, lane);
         }
       } else {
         /* short columns: one item of each of the ticket's tasks per thread, walked together (the tasks' item ranges follow
@@ -333,6 +349,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
           lw[g] = src32[(int)(rec[g] & 0xffu) * zq + jj[g]];
         }
         ldpc_fast_bn_multi<LDPC_F_BN_GROUP>(L, rec, jj, lw, live, maxdeg, Z, astride);
+        nxt = ldpc_draw_issue(pq, lane);
       }
       LDPC_TLOG_END(1, maxdeg);
     }

@@ -133,7 +133,9 @@ typedef struct ldpc_code_desc {
   /* 1: the items of the degree-19 rows come in PAIRS of neighbouring lanes, each lane taking half of the row's edges
    * (ldpc_fast_cn19_pair): the group holds 2 x rows x Z/4 items, item = 2 x (row item) + half */
   int32_t f_pair19;
-  /* per bit-node ticket {first item, end item, loop bound, tasks}: ticket and task record in one scalar load */
+  /* per bit-node ticket {first item, end item, loop bound, tasks}: ticket and task record in one scalar load.  (Carrying
+   * the column records of a ticket -- or the row records of a check-node task -- in its record, instead of looking them
+   * up in LDS, was slower: profiles/r04/decoder_ab26_record_carried_lookups.txt) */
   int32_t f_bn_rec[LDPC_F_MAX_BN_TASKS][4];
 } ldpc_code_desc_t;
 
