@@ -428,14 +428,24 @@ thread_local CtxHolder<ThreadCtx> tls_ctx_holder[NRLDPC_HIP_MAX_DEVICES];
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-bool host_ptr_is_pinned(const void *p)
+/* is [p, p + bytes) page-locked host memory the GPU can address?  Both ends are asked about: a caller may have registered
+ * only part of an array, and a range that was registered once and given back to the allocator must not be taken for
+ * page-locked because its first byte lies in somebody else's registration now. */
+bool host_ptr_is_pinned(const void *p, size_t bytes = 1)
 {
   hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+  if (!p || hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
     (void)hipGetLastError(); /* plain malloc memory: not an error for us */
     return false;
   }
-  return at.type == hipMemoryTypeHost;
+  if (bytes > 1) {
+    hipPointerAttribute_t at2;
+    if (hipPointerGetAttributes(&at2, static_cast<const uint8_t *>(p) + bytes - 1) != hipSuccess || at2.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  return true;
 }
 
 /* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it), with the
@@ -730,12 +740,12 @@ int dec_host_enqueue(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_pa
      * event), otherwise into this thread's page-locked staging rows, copied out chunk by chunk in dec_host_finish */
     void *dp = nullptr;
     int8_t *out0 = b->out + (size_t)i0 * b->out_stride;
-    if (((reinterpret_cast<uintptr_t>(out0) | b->out_stride) & 3) == 0 && host_ptr_is_pinned(out0) &&
+    if (((reinterpret_cast<uintptr_t>(out0) | b->out_stride) & 3) == 0 && host_ptr_is_pinned(out0, (size_t)(n_part - 1) * b->out_stride + 1) &&
         hipHostGetDevicePointer(&dp, out0, 0) == hipSuccess) {
       c.out_direct = true;
       out_dev = static_cast<int8_t *>(dp);
     }
-    if (host_ptr_is_pinned(b->n_iter + i0) && hipHostGetDevicePointer(&dp, b->n_iter + i0, 0) == hipSuccess) {
+    if (host_ptr_is_pinned(b->n_iter + i0, (size_t)n_part * sizeof(int32_t)) && hipHostGetDevicePointer(&dp, b->n_iter + i0, 0) == hipSuccess) {
       c.iter_direct = true;
       iter_dev = static_cast<int32_t *>(dp);
     }
@@ -897,7 +907,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
   /* host buffers: contiguous block ranges over the sharding devices (code blocks are independent, nothing is
    * exchanged), every device fed over its own link; a handful of blocks stays on the primary device */
   const int parts = b->n_blocks >= 64u * (uint32_t)g.n_shard ? g.n_shard : 1;
-  const bool pinned = b->n_blocks >= 16 && host_ptr_is_pinned(b->llr);
+  const bool pinned = b->n_blocks >= 16 && host_ptr_is_pinned(b->llr, (size_t)(b->n_blocks - 1) * b->llr_stride + 1);
   int rc = 0;
   for (int k = 0; k < parts && rc == 0; k++) {
     uint32_t lo, hi;

@@ -962,7 +962,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     if (st && st->llr_dev) {
       llr = st->llr_dev;
     } else {
-      if (to_host && !(st && st->no_pull) && tb_pull_mode() != 0 && host_ptr_is_pinned(b->coded)) {
+      if (to_host && !(st && st->no_pull) && tb_pull_mode() != 0 &&
+          host_ptr_is_pinned(static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * sizeof(int16_t))) {
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, b->coded, 0) == hipSuccess)
           pulled = static_cast<const int16_t *>(dp);
@@ -1003,7 +1004,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
        * memory makes the host wait for the piece before it can enqueue the next one; and letting the kernels store the
        * payload bytes over the link themselves was measured at 48 ms per slot: 4-byte writes, each one waited for.) */
       const size_t lo = st ? st->pay_lo : pay_lo, n = st ? st->pay_hi - st->pay_lo : pay_n;
-      if (host_ptr_is_pinned(b->payload)) {
+      if (host_ptr_is_pinned(b->payload + lo, n)) {
         c.fin_pay_n = 0;
       } else {
         (void)hipGetLastError();
@@ -1225,7 +1226,7 @@ int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t nt
   const int mode = tb_pull_mode();
   int K = chunks_env > 0 ? chunks_env : (int)std::min<size_t>(8, bytes / ((size_t)5 << 20));
   K = std::min<int>(K, (int)ntb / 2);
-  const bool pinned = host_ptr_is_pinned(b->coded);
+  const bool pinned = host_ptr_is_pinned(static_cast<const int16_t *>(b->coded) + lo, bytes);
   if (K < 2 || (pinned && (mode == 2 || (mode == 1 && bytes < pull_max))))
     return tb_rx_enqueue(b, tb0, ntb, true, nullptr, &st);
   hipStream_t s;

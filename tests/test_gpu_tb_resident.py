@@ -211,6 +211,9 @@ def test_device_resident_batches_sharded_over_logical_devices(hip, tmp_path):
                 assert np.array_equal(o[f"caller{rnd}_{what}"], o[f"library{rnd}_{what}"]), (rnd, what)
 
 
+_KEEP_ALIVE = []
+
+
 def test_residency_flags_and_mixed_call_errors(hip):
     """What the new entry points refuse, and the page-locking helpers a C caller without the HIP runtime uses: a soft-buffer
     pointer that is not device memory under NRLDPC_HIP_MEM_HARQ_DEVICE, both residency flags at once, unknown flag bits,
@@ -259,6 +262,7 @@ def test_residency_flags_and_mixed_call_errors(hip):
         for r in range(segs[i]):
             a = (sum(segs[:i]) + r) * m.HARQ_STRIDE
             assert np.array_equal(got[a:a + N], ref[2][a:a + N]), (i, r)
+    _KEEP_ALIVE.append(llr)   # (its pages were handed to the driver once: the allocator does not get the range back)
     assert L.nrLDPC_hip_host_register(llr.ctypes.data, llr.nbytes) == 0
     try:
         pay[:] = 0
