@@ -448,6 +448,15 @@ bool host_ptr_is_pinned(const void *p, size_t bytes = 1)
   return true;
 }
 
+/* [p, p + bytes) is page-locked at one end only: the HIP runtime refuses copies out of such a range (it takes the array for
+ * the registered piece), so the entry points that take host arrays say so instead of failing somewhere inside */
+bool host_range_is_partly_pinned(const void *p, size_t bytes)
+{
+  if (!p || bytes < 2)
+    return false;
+  return host_ptr_is_pinned(p) != host_ptr_is_pinned(static_cast<const uint8_t *>(p) + bytes - 1);
+}
+
 /* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it), with the
  * workgroup shape picked from the launch size; 3 / 4 = fast kernel, throughput / latency shape forced (tests, tuning) */
 int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_blocks, hipStream_t s, uint32_t batch_blocks = 0)

@@ -962,6 +962,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     if (st && st->llr_dev) {
       llr = st->llr_dev;
     } else {
+      if (to_host && host_range_is_partly_pinned(static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * sizeof(int16_t)))
+        return set_error("coded: the array is page-locked in part only (register the whole range the call reads, or none of it)");
       if (to_host && !(st && st->no_pull) && tb_pull_mode() != 0 &&
           host_ptr_is_pinned(static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * sizeof(int16_t))) {
         void *dp = nullptr;

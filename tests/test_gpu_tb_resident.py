@@ -270,6 +270,16 @@ def test_residency_flags_and_mixed_call_errors(hip):
     finally:
         assert L.nrLDPC_hip_host_unregister(llr.ctypes.data) == 0
     m.harq_release()
+    # an array of which only the first pages are page-locked (the library asks about both ends of the range a call reads):
+    # refused with a message -- the runtime would reject the copy out of it anyway -- and usable again once unregistered
+    assert L.nrLDPC_hip_host_register(llr.ctypes.data, 8192) == 0
+    try:
+        assert call(m.MEM_HOST | m.MEM_HARQ_LIBRARY, None) != 0 and b"in part" in L.nrLDPC_hip_last_error()
+    finally:
+        assert L.nrLDPC_hip_host_unregister(llr.ctypes.data) == 0
+    pay[:] = 0
+    assert call(m.MEM_HOST | m.MEM_HARQ_LIBRARY, None) == 0 and ack.all() and np.array_equal(pay, ref[0]) and np.array_equal(itm, ref[1])
+    m.harq_release()
     # mixed code-block calls
     blk = [dict(BG=1, Z=64, R=13, llr=torch.zeros(68 * 64, dtype=torch.int8, device="cuda"),
                 out=torch.zeros(m.out_bytes(1, 64, 13), dtype=torch.uint8, device="cuda")) for _ in range(2)]
