@@ -166,7 +166,23 @@ struct TbPlanCache {
 struct TbCtx {
   TbPlanCache tx, rx, cb; /* cb: mixed code-block batches (dec_jobs.inc.cpp) */
   DevBuf scratch, jobs_d, io_payload, io_coded, io_harq, io_small, trace_d;
-  PinBuf jobs_h, small_h, payload_h;
+  PinBuf jobs_h, small_h, payload_h, coded_h, harq_h;
+  /* Pageable arrays of the caller never meet the runtime's copy functions: they are bounced through this thread's
+   * page-locked areas by the CPU (in: before the copy is enqueued; out: in the finish call, after the stream has drained).
+   * Handing pageable memory to hipMemcpy*Async makes the runtime page-lock the caller's pages behind the scenes, and a
+   * process that allocates and frees such arrays call after call eventually took a GPU memory fault inside a soft-buffer
+   * copy -- once in ten runs of the test suite, all kernels of the call already finished (profiles/r04/README.md). */
+  struct FinCopy { uint8_t *dst; const uint8_t *src; size_t width, rows, dpitch, spitch; };
+  std::vector<FinCopy> fin_copies;
+  size_t harq_h_used = 0; /* bytes of harq_h the pieces of the call in flight have taken (a call may come in several pieces) */
+  void finish_copies()
+  {
+    harq_h_used = 0;
+    for (const FinCopy &f : fin_copies)
+      for (size_t r = 0; r < f.rows; r++)
+        memcpy(f.dst + r * f.dpitch, f.src + r * f.spitch, f.width);
+    fin_copies.clear();
+  }
   /* the host-buffer decode in flight: what tb_rx_finish has to hand over from payload_h (0 bytes: the kernels wrote the
    * caller's page-locked array themselves) */
   size_t fin_pay_lo = 0, fin_pay_n = 0;
@@ -191,6 +207,8 @@ struct TbCtx {
     if (own)
       (void)hipStreamSynchronize(own);
     pending = false;
+    fin_copies.clear();
+    harq_h_used = 0;
   }
 };
 thread_local CtxHolder<TbCtx> tls_tb_holder[NRLDPC_HIP_MAX_DEVICES]; /* pooled like ThreadCtx, one per logical device */
@@ -349,6 +367,19 @@ struct TbExtent {
  * staged (host buffers, or another GPU's memory -- a device-resident batch cut over several GPUs): the device works on copies
  * of exactly the byte ranges its blocks touch (job offsets stay the caller's: the device pointers are biased by the range
  * start); enqueue only, tb_tx_finish() waits for the copies back to the host */
+/* diagnostics: NRLDPC_HIP_DEBUG_SYNC=1 waits after every stage of a receive call and names the stage that failed */
+#define TB_DEBUG_STAGE(label)                                                                \
+  do {                                                                                       \
+    static const int dbg_ = [] { const char *e = getenv("NRLDPC_HIP_DEBUG_SYNC"); return e ? atoi(e) : 0; }(); \
+    hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone;                                 \
+    if (dbg_ && hipStreamIsCapturing(s, &cs_) == hipSuccess && cs_ == hipStreamCaptureStatusNone) { \
+      const hipError_t e_ = hipStreamSynchronize(s);                                        \
+      if (e_ != hipSuccess)                                                                  \
+        return set_error("stage failed: " label, e_);                                       \
+      fprintf(stderr, "[tb_rx dbg] ok: %s (tb0 %u ntb %u staged %d)\n", label, tb0, ntb, (int)staged);                \
+    }                                                                                        \
+  } while (0)
+
 int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bool staged, hipStream_t s_direct)
 {
   hipStream_t s;
@@ -473,13 +504,21 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
     if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n) != 0)
       return -1;
-    HIP_TRY(hipMemcpyAsync(c.io_payload.p, b->payload + pay_lo, pay_n, hipMemcpyDefault, s));
+    const uint8_t *pay_src = b->payload + pay_lo;
+    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && !host_ptr_is_pinned(pay_src, pay_n)) { /* pageable: bounced (TbCtx::fin_copies) */
+      if (c.payload_h.ensure(pay_n) != 0)
+        return -1;
+      memcpy(c.payload_h.p, pay_src, pay_n);
+      pay_src = c.payload_h.p;
+    }
+    HIP_TRY(hipMemcpyAsync(c.io_payload.p, pay_src, pay_n, hipMemcpyDefault, s));
     payload = c.io_payload.p - pay_lo;
     coded = c.io_coded.p - cod_lo;
   }
   const tb_tx_tb_job *d_tb = reinterpret_cast<const tb_tx_tb_job *>(pl.jobs_d.p + o_tb);
   const tb_tx_seg_job *d_seg = reinterpret_cast<const tb_tx_seg_job *>(pl.jobs_d.p + o_seg);
   uint32_t *d_acc = reinterpret_cast<uint32_t *>(pl.jobs_d.p + o_acc);
+  TB_DEBUG_STAGE("tx: entry + copies in");
   HIP_TRY(tb_launch_tx_crc(d_tb, ntb, reinterpret_cast<const tb_crc_chunk_job *>(pl.jobs_d.p + o_chk), (uint32_t)pl.n_aux,
                            payload, c.scratch.p, d_acc, G().crc_pow_24a_long, G().crc_pow[NR_HIP_CRC16], fused ? 0 : 1, s));
   const ldpc_enc_job *d_enc = reinterpret_cast<const ldpc_enc_job *>(pl.jobs_d.p + o_enc);
@@ -487,8 +526,10 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     /* workgroup size: 256 threads let every CU hold eight segments (a whole 1664-segment slot is resident at once);
      * a launch that does not even fill the GPU four deep takes 512 and halves the rounds of its long stages */
     const int fused_threads = n_seg <= (size_t)4 * (size_t)G().n_cus ? 512 : enc_threads;
+    TB_DEBUG_STAGE("tx: TB CRC launch");
     HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, fused_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
                                G().crc_pow[NR_HIP_CRC24_B], d_acc, s));
+    TB_DEBUG_STAGE("tx: fused segment launch");
   } else {
     HIP_TRY(tb_launch_tx_segment(d_seg, (uint32_t)n_seg, c.scratch.p, G().crc_pow[NR_HIP_CRC24_B], s));
     ldpc_enc_args ea;
@@ -498,14 +539,28 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     ea.jobs = d_enc;
     HIP_TRY(ldpc_launch_enc_jobs(ea, enc_threads, enc_lds, (uint32_t)n_seg, s));
     HIP_TRY(tb_launch_tx_ratematch(d_seg, (uint32_t)n_seg, c.scratch.p, coded, s));
+    TB_DEBUG_STAGE("tx: segment + rate matching launches");
   }
   if (staged) {
     uint8_t *hc = static_cast<uint8_t *>(b->coded);
+    const size_t cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
+    uint8_t *out = hc; /* where the copies go: the caller's array, or (pageable array) this thread's page-locked mirror of it */
+    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && !host_ptr_is_pinned(hc + cod_lo, cod_n)) {
+      if (c.coded_h.ensure(cod_n) != 0)
+        return -1;
+      out = c.coded_h.p - cod_lo;
+      if (pl.out_dense) {
+        c.fin_copies.push_back(TbCtx::FinCopy{hc + cod_lo, c.coded_h.p, cod_n, 1, 0, 0});
+      } else {
+        for (const TbPlan::OutRun &r : pl.out_runs)
+          c.fin_copies.push_back(TbCtx::FinCopy{hc + r.first, out + r.first, r.width, r.rows, r.pitch, r.pitch});
+      }
+    }
     if (pl.out_dense) {
-      HIP_TRY(hipMemcpyAsync(hc + pl.ext[2], c.io_coded.p, pl.ext[3] - pl.ext[2], hipMemcpyDefault, s));
+      HIP_TRY(hipMemcpyAsync(out + cod_lo, c.io_coded.p, cod_n, hipMemcpyDefault, s));
     } else {
       for (const TbPlan::OutRun &r : pl.out_runs)
-        HIP_TRY(hipMemcpy2DAsync(hc + r.first, r.pitch, c.io_coded.p + (r.first - pl.ext[2]), r.pitch, r.width, r.rows, hipMemcpyDefault, s));
+        HIP_TRY(hipMemcpy2DAsync(out + r.first, r.pitch, c.io_coded.p + (r.first - cod_lo), r.pitch, r.width, r.rows, hipMemcpyDefault, s));
     }
   }
   return 0;
@@ -515,7 +570,9 @@ int tb_tx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t ntb)
 {
   if ((b->mem & NRLDPC_HIP_MEM_DEVICE) || ntb == 0)
     return 0;
-  HIP_TRY(hipStreamSynchronize(tls_tb.own));
+  TbCtx &c = tls_tb;
+  HIP_TRY(hipStreamSynchronize(c.own));
+  c.finish_copies();
   return 0;
 }
 
@@ -955,6 +1012,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   const size_t stride2 = (size_t)b->harq_stride * sizeof(int16_t);
   const bool to_host = staged && !(b->mem & NRLDPC_HIP_MEM_DEVICE);
   const bool payload_direct = false;
+  bool harq_bounce = false;
+  uint8_t *harq_mirror = nullptr;
   if (staged) {
     const size_t pay_lo = pl.ext[0], pay_n = pl.ext[1] - pl.ext[0], cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
     /* LLRs in page-locked host memory are read in place (the device address of the caller's array); anything else is copied */
@@ -977,7 +1036,14 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       } else {
         if (c.io_coded.ensure(cod_n * 2) != 0)
           return -1;
-        HIP_TRY(hipMemcpyAsync(c.io_coded.p, static_cast<const int16_t *>(b->coded) + cod_lo, cod_n * 2, hipMemcpyDefault, s));
+        const void *cod_src = static_cast<const int16_t *>(b->coded) + cod_lo;
+        if (to_host && !host_ptr_is_pinned(cod_src, cod_n * 2)) { /* pageable: bounced (TbCtx::fin_copies) */
+          if (c.coded_h.ensure(cod_n * 2) != 0)
+            return -1;
+          memcpy(c.coded_h.p, cod_src, cod_n * 2);
+          cod_src = c.coded_h.p;
+        }
+        HIP_TRY(hipMemcpyAsync(c.io_coded.p, cod_src, cod_n * 2, hipMemcpyDefault, s));
         llr = reinterpret_cast<const int16_t *>(c.io_coded.p) - cod_lo;
       }
     }
@@ -985,10 +1051,25 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       const size_t harq_lo = pl.ext[4], harq_n = pl.ext[5] - pl.ext[4];
       if (c.io_harq.ensure(harq_n * 2) != 0)
         return -1;
+      /* a pageable array of the caller's is mirrored in page-locked memory: rows that travel up are copied into the mirror
+       * by the CPU first, rows that come back are handed over by tb_rx_finish (TbCtx::fin_copies) */
+      harq_bounce = to_host && !host_ptr_is_pinned(b->harq + harq_lo, harq_n * 2);
+      if (harq_bounce) { /* this piece's share of the mirror (growing it parks the old area: earlier pieces keep theirs) */
+        const size_t at = align_up(c.harq_h_used, 64);
+        if (c.harq_h.ensure(at + harq_n * 2) != 0)
+          return -1;
+        harq_mirror = c.harq_h.p + at;
+        c.harq_h_used = at + harq_n * 2;
+      }
+      const int16_t *harq_src = harq_bounce ? reinterpret_cast<const int16_t *>(harq_mirror) - harq_lo : b->harq;
       for (const TbPlan::HarqRun &r : pl.harq_runs)
-        if (r.upload)
-          HIP_TRY(hipMemcpy2DAsync(c.io_harq.p + (r.first - harq_lo) * 2, stride2, b->harq + r.first, stride2, (size_t)r.width * 2, r.rows,
+        if (r.upload) {
+          if (harq_bounce)
+            for (uint32_t q = 0; q < r.rows; q++)
+              memcpy(harq_mirror + (r.first - harq_lo) * 2 + q * stride2, b->harq + r.first + (size_t)q * b->harq_stride, (size_t)r.width * 2);
+          HIP_TRY(hipMemcpy2DAsync(c.io_harq.p + (r.first - harq_lo) * 2, stride2, harq_src + r.first, stride2, (size_t)r.width * 2, r.rows,
                                    hipMemcpyDefault, s));
+        }
       harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     }
     if (to_host) {
@@ -1036,8 +1117,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(c.tev[0], s));
   }
+  TB_DEBUG_STAGE("entry + copies in (job upload, LLRs, soft buffers)");
   HIP_TRY(tb_launch_rx_dematch(d_leg, (uint32_t)pl.n_legacy_seg, pl.rx_lds_elems, llr, harq, reinterpret_cast<int8_t *>(c.scratch.p), s,
                                n_seg <= (size_t)G().n_cus));
+  TB_DEBUG_STAGE("de-matching launch (segments outside the fused kernel)");
   if (c.timing)
     HIP_TRY(hipEventRecord(c.tev[1], s));
   ldpc_dec_args da;
@@ -1106,6 +1189,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         fx.trace = reinterpret_cast<unsigned long long *>(c.trace_d.p);
       }
       HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
+      TB_DEBUG_STAGE("fused segment kernel");
       if (fx.trace) {
         std::vector<unsigned long long> h((size_t)dl.n * 16);
         HIP_TRY(hipStreamSynchronize(s));
@@ -1118,7 +1202,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       }
     }
     else if (dl.kind == 0)
+    {
       HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s));
+      TB_DEBUG_STAGE("decoder launch (fast kernel, job array)");
+    }
     else if (dl.kind == 1)
       HIP_TRY(ldpc_launch_dec_generic_jobs(da, dl.threads, dl.lds, dl.n, s));
     else
@@ -1137,6 +1224,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     HIP_TRY(hipEventRecord(c.tev[3], s));
     c.timed = true;
   }
+  TB_DEBUG_STAGE("remaining decoder launches + reassembly / verdict");
   if (staged) {
     /* payload back: to the caller's array, or (host call, pageable array) to this thread's page-locked staging area */
     uint8_t *pay_dst = (to_host && c.fin_pay_n) ? c.payload_h.p - c.fin_pay_lo : b->payload;
@@ -1148,9 +1236,13 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
                                  hipMemcpyDefault, s));
     }
     if (harq_staged)
-      for (const TbPlan::HarqRun &r : pl.harq_runs)
-        HIP_TRY(hipMemcpy2DAsync(b->harq + r.first, stride2, c.io_harq.p + (r.first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, r.rows,
+      for (const TbPlan::HarqRun &r : pl.harq_runs) {
+        uint8_t *dst = harq_bounce ? harq_mirror + (r.first - pl.ext[4]) * 2 : reinterpret_cast<uint8_t *>(b->harq + r.first);
+        HIP_TRY(hipMemcpy2DAsync(dst, stride2, c.io_harq.p + (r.first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, r.rows,
                                  hipMemcpyDefault, s));
+        if (harq_bounce)
+          c.fin_copies.push_back(TbCtx::FinCopy{reinterpret_cast<uint8_t *>(b->harq + r.first), dst, (size_t)r.width * 2, r.rows, stride2, stride2});
+      }
     if (!to_host) { /* a peer GPU's share of a device-resident batch: the verdicts go to the owner's arrays */
       HIP_TRY(hipMemcpyAsync(b->iter_max + tb0, c.io_small.p, (size_t)ntb * 4, hipMemcpyDefault, s));
       HIP_TRY(hipMemcpyAsync(b->ack + tb0, c.io_small.p + (size_t)ntb * 4, ntb, hipMemcpyDefault, s));
@@ -1172,6 +1264,7 @@ int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       memcpy(b->payload + b->tb[i].payload_off, c.payload_h.p + (b->tb[i].payload_off - c.fin_pay_lo), b->tb[i].A / 8);
     c.fin_pay_n = 0;
   }
+  c.finish_copies();
   return 0;
 }
 
@@ -1244,6 +1337,8 @@ int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t nt
   }
   if (c.io_coded.ensure(bytes) != 0)
     return -1;
+  if (!pinned && c.coded_h.ensure(bytes) != 0) /* pageable: every chunk is bounced through the page-locked mirror by the CPU */
+    return -1;
   /* the staging buffer may still be read by the previous call's kernels on the compute stream */
   HIP_TRY(hipEventRecord(c.chunk_ev[K], s));
   HIP_TRY(hipStreamWaitEvent(c.aux, c.chunk_ev[K], 0));
@@ -1258,8 +1353,14 @@ int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t nt
       a = std::min(a, (size_t)b->tb[i].coded_off);
       e = std::max(e, (size_t)b->tb[i].coded_off + b->tb[i].G);
     }
-    if (e > a)
-      HIP_TRY(hipMemcpyAsync(c.io_coded.p + (a - lo) * 2, src + a, (e - a) * 2, hipMemcpyHostToDevice, c.aux));
+    if (e > a) {
+      const void *from = src + a;
+      if (!pinned) {
+        memcpy(c.coded_h.p + (a - lo) * 2, from, (e - a) * 2);
+        from = c.coded_h.p + (a - lo) * 2;
+      }
+      HIP_TRY(hipMemcpyAsync(c.io_coded.p + (a - lo) * 2, from, (e - a) * 2, hipMemcpyHostToDevice, c.aux));
+    }
     HIP_TRY(hipEventRecord(c.chunk_ev[k], c.aux));
     return 0;
   };

@@ -192,8 +192,12 @@ int offload_encode(const uint8_t *in, uint8_t *out, const encoder_implemparams_t
                              reinterpret_cast<const ldpc_enc_job *>(c.jobs_d.p + o_enc), 1, 512, nlds + TB_TX_FUSED_EXTRA_LDS,
                              c.jobs_d.p + o_in, c.io_coded.p, G().crc_pow[NR_HIP_CRC24_B],
                              reinterpret_cast<uint32_t *>(c.jobs_d.p + o_acc), s));
-  HIP_TRY(hipMemcpyAsync(out, c.io_coded.p, ip->E, hipMemcpyDeviceToHost, s));
+  /* (the caller's array never meets the runtime's copy functions: TbCtx::fin_copies) */
+  if (c.coded_h.ensure(ip->E) != 0)
+    return -1;
+  HIP_TRY(hipMemcpyAsync(c.coded_h.p, c.io_coded.p, ip->E, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  memcpy(out, c.coded_h.p, ip->E);
   c.pending = false;
   return 0;
 }
