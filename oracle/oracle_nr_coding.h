@@ -7,15 +7,21 @@
  * (libldpc_hip.so, openairinterface5g_amd/) never does.
  *
  * PARITY PIN STATUS -- read this before trusting it:
- *   The reference path cannot be compiled in the development image: every source file on it
- *   includes the un-vendored SIMDE headers (openair1/PHY/sse_intrin.h:52-60), the decoder hot loops
- *   are generated at build time by the reference's CMake, and writing stand-in headers is not
- *   allowed.  The reference's own tests hold no golden vectors for this path.
- *   => decoder parity against a reference BINARY is **unpinned**.  What pins the oracle instead is
- *   listed in DESIGN.md section "Oracle": (1) the 38.212 tables are cross-checked against both
- *   copies held as data in the reference tree, (2) the encoder is pinned by H*c = 0 (the systematic
- *   code word is unique), (3) every decoder rule below cites the reference file:line it restates,
- *   (4) the reference's own acceptance test (ldpctest: BLER 0 at -s10 for BG1 R=1/3) is reproduced.
+ *   Pinned by reference-COMPILED code (oracle/_ref, recipe oracle/ref_pin/, no SIMDE, no stand-in headers, nothing but the
+ *   reference's own sources where they lie; outputs committed as tests/golden/ref_*.npz by tools/make_ref_fixtures.py):
+ *     - the encoder: encode_parity_check_part_orig + the generator tables (ldpc_generate_coefficient.c, Gen_shift_value.h)
+ *       give this oracle's code words for all 51 x 2 codes, Kb < 10 and bit-sliced 8-segment input included;
+ *     - the decoder's code set-up (nrLDPC_init.h: LUT selection, numLLR) and ALL of its data movement (nrLDPC_mPass.h:
+ *       circular shifts, CN/BN buffer addressing, the degree-1 columns [D1][D6], output reordering): a decoder made of
+ *       those compiled functions + a second, independent restatement of the node arithmetic on the reference's own
+ *       buffer layouts (oracle/ref_pin/ref_hybrid_decoder.c) gives this oracle's pass counts and output bytes for every
+ *       (BG, Zc, R), every output mode, parity and CRC stop (tests/test_ref_pin.py).
+ *   NOT pinnable in this image: the bodies of cnProc / cnProcPc / bnProcPc / bnProc / llr2bit are SIMDE intrinsics
+ *   (openair1/PHY/sse_intrin.h:52-60 -> un-vendored SIMDE; the shipped variants are generated at build time by the
+ *   reference's CMake).  Their per-element rules [D2][D3][D5][D7][D9] are restated twice (here per (edge, lane), there
+ *   per reference buffer) from the same file:line, and agree; CRC, segmentation, rate matching and the RNG
+ *   (crc_byte.c, nr_segmentation.c, nr_rate_matching.c, rangen_double.c) all reach SIMDE through tools_defs.h and are
+ *   pinned only by catalogue values, tables and the properties listed in DESIGN.md section 2.
  *
  * Every function cites the reference file:line it follows (paths relative to the reference root,
  * openair1/PHY/CODING/ unless stated otherwise).

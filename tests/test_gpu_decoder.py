@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import ALL_RATES, kbits, load_survey_decoder_vectors, make_llr, random_info
+from common import (ALL_RATES, kbits, load_ref_code_words, load_ref_decoder_vectors, load_survey_decoder_vectors, make_llr,
+                    random_info)
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +92,50 @@ def test_survey_stage_vectors(hip):
                                            crc_type=v["crc_type"], out=pre, kernel=kern)
             assert n[0] == v["n_iter"], (kern, v)
             assert np.array_equal(out[0], v["out"]), (kern, v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"])
+
+
+def test_reference_hybrid_decoder_vectors(hip):
+    """tests/golden/ref_decoder.npz: runs of oracle/_ref's decoder -- set-up (nrLDPC_init) and every data-movement step
+    (nrLDPC_mPass.h) reference-COMPILED, node arithmetic restated on the reference's buffer layouts -- on 17 codes,
+    converging and failing inputs, iteration caps 1 / 2 / 8, the three output modes, parity and CRC stop: pass counts and
+    every output byte, on every kernel that serves the code."""
+    n = 0
+    for v in load_ref_decoder_vectors():
+        for kern in kernels_for(v["Z"]):
+            pre = np.full((1, (v["out"].size + 3) // 4 * 4), v["out_init"], dtype=np.uint8)
+            n_it, out = hip.decode_batch_host(v["BG"], v["Z"], v["R"], v["llr"][None, :], numMaxIter=v["numMaxIter"],
+                                              outMode=v["outMode"], check_crc=v["use_crc"], E=v["E"],
+                                              crc_type=v["crc_type"], out=pre, kernel=kern)
+            assert n_it[0] == v["n_iter"], (kern, v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"], v["use_crc"])
+            assert np.array_equal(out[0], v["out"]), (kern, v["BG"], v["Z"], v["R"], v["numMaxIter"], v["outMode"])
+        n += 1
+    assert n >= 400
+    # the by-name symbol (resident server) on the parity-stop runs
+    for v in load_ref_decoder_vectors():
+        if v["use_crc"] or v["outMode"] != 0:
+            continue
+        p = hip.make_dec_params(v["BG"], v["Z"], v["R"], v["numMaxIter"])
+        n_it, out = hip.LDPCdecoder(p, v["llr"], p_out=np.full(v["out"].size, v["out_init"], np.uint8))
+        assert n_it == v["n_iter"] and np.array_equal(out, v["out"]), (v["BG"], v["Z"], v["R"], v["numMaxIter"])
+
+
+def test_reference_code_words_are_accepted_by_every_kernel(hip):
+    """Every code word of the reference-COMPILED encoder (tests/golden/ref_encoder.npz), sent noiselessly (punctured
+    columns 0, the rest +-16), satisfies the parity checks of every HIP decoder kernel in every decoder-rate mode within
+    a few passes and gives its information bits back: the decoders' graphs (rows, columns, shifts mod Zc) are the
+    reference encoder's."""
+    for v in load_ref_code_words():
+        BG, Z = v["BG"], v["Z"]
+        K = kbits(BG, Z)
+        bits = np.concatenate([np.unpackbits(v["info"])[:2 * Z], v["coded"]])
+        for R in ALL_RATES[BG]:
+            n = O.NCOLS[(BG, R)] * Z
+            llr = (16 * (1 - 2 * bits[:n].astype(np.int16))).astype(np.int8)
+            llr[:2 * Z] = 0
+            for kern in kernels_for(Z):
+                n_it, out = hip.decode_batch_host(BG, Z, R, llr[None, :], numMaxIter=8, kernel=kern)
+                assert n_it[0] <= 4, (kern, BG, Z, R, int(n_it[0]))
+                assert np.array_equal(np.unpackbits(out[0])[:K], bits[:K]), (kern, BG, Z, R)
 
 
 def test_reference_entry_point_and_abort(hip):

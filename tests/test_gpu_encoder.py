@@ -76,7 +76,7 @@ def test_byte_per_lane_kernel_too():
     env = dict(os.environ, NRLDPC_HIP_ENC_KERNEL="bytes")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_encoder.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "every_lifting_size or survey_stage"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+                        "-k", "every_lifting_size or survey_stage or reference_compiled"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -117,3 +117,23 @@ def test_reference_entry_point_without_the_resident_kernel():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_encoder.py"), "-m", "gpu", "-q", "-x",
                         "-k", "reference_entry_point_macro or meters"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_compiled_code_words(hip):
+    """tests/golden/ref_encoder.npz: code words of the reference-COMPILED encoder (oracle/_ref: ldpc_encoder.c's assembly
+    around encode_parity_check_part_orig of ldpc_generate_coefficient.c with the reference's generator tables) -- every
+    (BG, Zc) twice, BG2 with Kb = 6, 8, 9.  Through the batch entry and the by-name LDPCencoder."""
+    from common import load_ref_code_words
+    words = list(load_ref_code_words())
+    assert len(words) >= 204
+    for v in words:                                           # (the byte-per-lane kernel: test_byte_per_lane_kernel_too)
+        out = hip.encode_batch_host(v["BG"], v["Z"], v["info"][None, :], v["Kb"])
+        assert np.array_equal(out[0], v["coded"]), (v["BG"], v["Z"], v["Kb"])
+    by_code = {}
+    for v in words:
+        if v["Kb"] == (22 if v["BG"] == 1 else 10):
+            by_code.setdefault((v["BG"], v["Z"]), []).append(v)
+    for (BG, Z), vs in by_code.items():                       # the symbol the reference's loader binds
+        outs = hip.LDPCencoder([v["info"] for v in vs], BG, Z, n_segments=len(vs), macro_num=0)
+        for v, o in zip(vs, outs):
+            assert np.array_equal(o, v["coded"]), (BG, Z)

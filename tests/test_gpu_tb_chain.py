@@ -53,6 +53,33 @@ def test_dlsch_encode_matches_reference_chain(hip):
         assert np.array_equal(f, ref), t
 
 
+def test_reference_compiled_code_words_through_both_chains(hip):
+    """tests/golden/ref_encoder.npz, transport blocks: every segment's code word comes from the reference-COMPILED encoder
+    (oracle/_ref).  TX: the DL-SCH chain's output (rv 0, QPSK, every transmittable bit once) equals the one derived from
+    those code words.  RX: that output as noiseless LLRs comes back through the UL-SCH chain -- fused segment kernel and the
+    four-launch path's kernels alike -- as the payload, ACK, within three passes."""
+    from common import load_ref_transport_blocks
+    cases = list(load_ref_transport_blocks())
+    tbs = [c["tb"] for c in cases]
+    coded = hip.ldpc.dlsch_encode_host(tbs, [c["payload"] for c in cases])
+    for c, f in zip(cases, coded):
+        assert f.size == c["coded"].size and np.array_equal(f, c["coded"]), c["tb"]
+    stride = hip.ldpc.HARQ_STRIDE
+    llrs = [(10 * (1 - 2 * c["coded"].astype(np.int16))).astype(np.int16) for c in cases]
+    for fused in ("1", "0"):
+        os.environ["NRLDPC_HIP_TB_FUSED"] = fused
+        try:
+            harq = np.zeros((sum(c["C"] for c in cases), stride), np.int16)
+            for t in tbs:
+                t.pop("llrLen", None)
+                t["round"] = 0
+            out, ack, itm = hip.ldpc.ulsch_decode_host(tbs, llrs, harq, numMaxIter=8)
+        finally:
+            os.environ.pop("NRLDPC_HIP_TB_FUSED", None)
+        for c, o, a, it in zip(cases, out, ack, itm):
+            assert a and it <= 3 and np.array_equal(o, c["payload"]), (fused, c["tb"], int(it))
+
+
 def test_dlsch_encode_random_sweep(hip):
     """Seeded random transport blocks (size, base graph, modulation, layers, rv, LBRM, code rate from 0.15 to 0.95 incl.
     repetition) in ONE heterogeneous call: every output bit equals the oracle chain's."""
