@@ -47,9 +47,17 @@ typedef struct nrLDPC_dec_params {
   int E;              /* number of leading output bits covered by the CRC check */
   e_nrLDPC_outMode outMode;
   int crc_type;       /* CRC24_A 0, CRC24_B 1, CRC16 2, CRC8 3 (coding_defs.h:33-36) */
-  /* NULL: stop on parity check.  Non-NULL: stop on CRC.  The reference calls this pointer on the host
-   * after every pass >= 3; this library evaluates the same CRC (crc_byte.c:314-380 check_crc) on the GPU
-   * from crc_type/E and never calls the pointer. */
+  /* NULL: stop on parity check.  Non-NULL: stop on CRC from pass 3 on, the predicate applied to (p_out, E, crc_type) after
+   * every such pass exactly as nrLDPC_decoder.c:849-861 applies it.
+   *   - The library's own nrLDPC_hip_check_crc, or the host executable's `check_crc` (looked up once with
+   *     dlsym(RTLD_DEFAULT) -- what nr_ulsch_decoding.c:216 / nr_dlsch_decoding.c:253 pass): the same CRC
+   *     (crc_byte.c:314-380) is evaluated ON THE GPU from crc_type / E; the pointer is not called.  Needs outMode BIT,
+   *     E % 8 == 0, 0 < E <= K; any other combination takes the next path.
+   *   - Any other pointer (LDPCdecoder and host-memory LDPCdecoder_batch): it IS called on the host, on p_out, after every
+   *     pass >= 3 in order until it returns non-zero -- the decoder runs all its passes without stopping and keeps every
+   *     pass' output, so this path costs the full iteration count (slow, exact).
+   *   - Device-memory batches, LDPCdecoder_jobs and the transport-block chain evaluate the CRC on the GPU whatever the
+   *     pointer (there it is a mode flag) and refuse the combinations the GPU cannot serve. */
   int (*check_crc)(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type);
   uint8_t setCombIn;
 } t_nrLDPC_dec_params;
@@ -294,6 +302,10 @@ int32_t nrLDPC_hip_server_stats(int64_t out[8]);
  * the last recorded call's {de-matching kernel, decoder launches (the fused segment kernel), reassembly + verdict kernels,
  * their sum} in microseconds (waits for that call).  What bench.py's chain_roofline is computed from.  0 / -1. */
 int32_t nrLDPC_hip_chain_timing(int32_t enable, float out_us[4]);
+/* check_crc() of openair1/PHY/CODING/crc_byte.c:314-380 (same arguments, same result): the predicate to put into
+ * t_nrLDPC_dec_params::check_crc by callers that do not carry OAI's own -- it selects the CRC evaluated on the GPU -- and a
+ * correct host implementation for whoever calls it. */
+int nrLDPC_hip_check_crc(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type);
 const char *nrLDPC_hip_last_error(void);
 const char *nrLDPC_hip_version(void);
 

@@ -88,6 +88,10 @@ struct Library {
   int n_shard = 1;   /* the first n_shard of them take part in sharding host-buffer batches */
   Device dev[NRLDPC_HIP_MAX_DEVICES];
   const int *opp_enabled = nullptr;           /* the host executable's meter switch (common/utils/time_meas.h), if it has one */
+  /* the host executable's own check_crc (crc_byte.c:314), if it exports one: the pointer the reference's callers put into
+   * t_nrLDPC_dec_params (nr_ulsch_decoding.c:216).  That predicate -- and the library's nrLDPC_hip_check_crc -- is the one
+   * the GPU evaluates; any other pointer is called on the host (dec_host_predicate) */
+  int (*host_check_crc)(uint8_t *, uint32_t, uint8_t) = nullptr;
 } g;
 
 /* the device the calling thread is working on (set by the entry points through UseDevice) */
@@ -187,6 +191,7 @@ int ensure_ready_locked()
       return -1;
   g.n_dev = g.n_shard = n;
   g.opp_enabled = static_cast<const int *>(dlsym(RTLD_DEFAULT, "opp_enabled"));
+  g.host_check_crc = reinterpret_cast<int (*)(uint8_t *, uint32_t, uint8_t)>(dlsym(RTLD_DEFAULT, "check_crc"));
   g.ready = true;
   return 0;
 }
@@ -487,6 +492,15 @@ int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_
   return 0;
 }
 
+/* CRC stop: can the GPU evaluate this call's predicate (see t_nrLDPC_dec_params::check_crc in nrLDPC_hip.h)?  false = the
+ * predicate has to be called on the host, on p_out, as nrLDPC_decoder.c:857 calls it. */
+bool crc_on_device(const t_nrLDPC_dec_params &p, const CodeEntry *ce)
+{
+  const bool known = p.check_crc == &nrLDPC_hip_check_crc || (g.host_check_crc && p.check_crc == g.host_check_crc);
+  return known && p.outMode == nrLDPC_outMode_BIT && p.E > 0 && (p.E & 7) == 0 && p.E <= ce->host.kb_full * ce->host.Z &&
+         p.E <= LDPC_CRC_POW_LEN && p.crc_type >= 0 && p.crc_type <= 3;
+}
+
 int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_args &a)
 {
   a.code = ce->dev;
@@ -567,6 +581,7 @@ int32_t lib_init()
 
 extern "C" {
 
+int nrLDPC_hip_check_crc(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type) { return nr_hip_check_crc(decoded_bytes, n, crc_type); }
 const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
 const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.4 (gfx950)"; }
 
@@ -860,6 +875,65 @@ int dec_host_finish(const nrLDPC_hip_dec_batch_t *b, uint32_t i0, uint32_t n_par
   return 0;
 }
 
+/* CRC stop with a predicate the GPU cannot evaluate (a caller's own function; or E % 8 != 0, an output mode other than BIT:
+ * see t_nrLDPC_dec_params::check_crc).  The decoder is deterministic and the predicate only decides WHERE it stops, so the
+ * blocks run all their passes on the GPU, the hard decisions of every pass >= 3 come back, and the predicate is applied on
+ * the host exactly as nrLDPC_decoder.c:849-861 applies it: to p_out, after every such pass in order, until it holds.  p_out
+ * ends up holding the last pass that was checked, the return value is that pass.  Host buffers, primary device; slow (the
+ * full iteration count + one output row per pass over the link) and exact. */
+int dec_host_predicate(const nrLDPC_hip_dec_batch_t *b)
+{
+  const t_nrLDPC_dec_params &p = b->params;
+  UseDevice use(g.dev[0]);
+  const CodeEntry *ce = get_code(p.BG, p.Z, p.R);
+  if (!ce)
+    return -1;
+  const ldpc_code_desc_t &hc = ce->host;
+  const int mode = p.outMode == nrLDPC_outMode_BIT ? 0 : 1;
+  const int ob = out_bytes_of(hc, mode), max_pass = p.numMaxIter + 1;
+  if (max_pass < 3) { /* decoder.c:849: never checked, p_out never written, every pass runs */
+    for (uint32_t i = 0; i < b->n_blocks; i++)
+      b->n_iter[i] = max_pass;
+    return 0;
+  }
+  const uint32_t n_trace = (uint32_t)max_pass - 2, tstride = (uint32_t)align_up(ob, 16);
+  const size_t in_stride = align_up(hc.num_llr, 16), per_block = (size_t)n_trace * tstride;
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)64 << 20) / per_block);
+  ThreadCtx &c = tls_ctx;
+  ldpc_dec_args a;
+  memset(&a, 0, sizeof(a));
+  a.code = ce->dev;
+  a.num_max_iter = p.numMaxIter;
+  a.out_mode = mode;
+  a.use_crc = 1;
+  for (uint32_t k0 = 0; k0 < b->n_blocks; k0 += chunk) {
+    const uint32_t n = std::min(chunk, b->n_blocks - k0);
+    if (c.ensure(in_stride * n, per_block * n + sizeof(int32_t) * n) != 0)
+      return -1;
+    for (uint32_t i = 0; i < n; i++) /* through the page-locked staging area (pageable arrays never meet the copy functions) */
+      memcpy(c.h_in + i * in_stride, b->llr + (size_t)(k0 + i) * b->llr_stride, hc.num_llr);
+    HIP_TRY(hipMemcpyAsync(c.d_in, c.h_in, in_stride * n, hipMemcpyHostToDevice, c.stream));
+    a.llr = reinterpret_cast<const int8_t *>(c.d_in); a.llr_stride = (uint32_t)in_stride;
+    a.n_iter = reinterpret_cast<int32_t *>(c.d_out + per_block * n);
+    HIP_TRY(ldpc_launch_dec_generic_trace(a, hc, n, reinterpret_cast<int8_t *>(c.d_out), tstride, n_trace, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.h_out, c.d_out, per_block * n + sizeof(int32_t) * n, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    for (uint32_t i = 0; i < n; i++) {
+      int8_t *out = b->out + (size_t)(k0 + i) * b->out_stride;
+      int32_t n_iter = max_pass;
+      for (int pass = 3; pass <= max_pass; pass++) {
+        memcpy(out, c.h_out + (size_t)i * per_block + (size_t)(pass - 3) * tstride, ob);
+        if (p.check_crc(reinterpret_cast<uint8_t *>(out), (uint32_t)p.E, (uint8_t)p.crc_type)) {
+          n_iter = pass;
+          break;
+        }
+      }
+      b->n_iter[k0 + i] = n_iter;
+    }
+  }
+  return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -897,6 +971,7 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
   }
   if (ensure_ready() != 0)
     return -1;
+  bool host_predicate = false;
   {
     /* parameter checks once, against the primary device's descriptor */
     UseDevice use(g.dev[0]);
@@ -907,10 +982,13 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
     const int ob = out_bytes_of(ce->host, p.outMode == nrLDPC_outMode_BIT ? 0 : 1);
     if (b->llr_stride < (uint32_t)ce->host.num_llr || b->out_stride < (uint32_t)ob || (b->out_stride & 3))
       return set_error("bad stride");
+    host_predicate = p.check_crc && !crc_on_device(p, ce);
     ldpc_dec_args a;
-    if (fill_dec_args(p, ce, a) != 0)
+    if (!host_predicate && fill_dec_args(p, ce, a) != 0)
       return -1;
   }
+  if (host_predicate)
+    return b->n_blocks ? dec_host_predicate(b) : 0;
   if (b->n_blocks == 0)
     return 0;
   /* host buffers: contiguous block ranges over the sharding devices (code blocks are independent, nothing is
@@ -959,7 +1037,9 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
     set_error("null argument");
   if (ce) {
     rc = 1;
-    if (srv_ready(srv) == 0) /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp) */
+    /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp); a CRC predicate that has to run on
+     * the host goes through the batch entry point (dec_host_predicate) */
+    if (!(p_decParams->check_crc && !crc_on_device(*p_decParams, ce)) && srv_ready(srv) == 0)
       rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter, ab);
     if (rc == 1) { /* server switched off, or a code it cannot hold: one launch per call on this thread's stream */
       const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);

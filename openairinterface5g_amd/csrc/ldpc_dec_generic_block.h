@@ -19,7 +19,26 @@ struct ldpc_gblock_io {
   const uint32_t *crc_pow;
   int out_mode;
   int *tb_abort;           /* optional transport-block wide failure flag (decoder.c:190-193, 556-559) */
+  /* CRC stop decided by a predicate on the HOST (ldpc_api.cpp dec_host_predicate): with use_crc and trace != NULL no CRC is
+   * evaluated here and nothing stops the passes; the hard decisions of every pass p >= 3 -- what the reference hands to
+   * check_crc after that pass (decoder.c:849-861) -- are stored at trace + (p - 3) * trace_stride in out_mode's format */
+  int8_t *trace;
+  uint32_t trace_stride;
 };
+
+/* nrLDPC_llrRes2llrOut + llr2bitPacked / llr2bit (decoder.c:851-856, 866-877): columns behind the core report 0 [F5] */
+__device__ __forceinline__ void ldpc_gblock_store(int out_mode, int8_t *out, const int8_t *app, int num_llr, int ncz, int tid, int nt)
+{
+  if (out_mode == 0) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(out);
+    const int nwords = (num_llr + 31) >> 5;
+    for (int w = tid; w < nwords; w += nt)
+      o[w] = (32 * w < ncz) ? ldpc_pack_word(app, w, ncz) : 0u;
+  } else {
+    for (int i = tid; i < num_llr; i += nt)
+      out[i] = (i < ncz) ? (int8_t)(app[i] < 0) : (int8_t)0;
+  }
+}
 
 __device__ __forceinline__ int ldpc_dec_generic_block(int8_t *smem, ldpc_code_ptr_t code, const ldpc_gblock_io &io)
 {
@@ -123,7 +142,9 @@ __device__ __forceinline__ int ldpc_dec_generic_block(int8_t *smem, ldpc_code_pt
     /* CRC stop from the third pass on (decoder.c:849-861).  check_crc(p_out, E, type) (crc_byte.c:314-380)
      * holds iff the E-bit word [data | crc] is divisible by g(x); the remainder is linear in the bits:
      * XOR over the set bits i of x^(E-1-i) mod g. */
-    if (io.use_crc && p >= 3) {
+    if (io.use_crc && p >= 3 && io.trace) { /* (the next check-node phase only reads app: no barrier needed behind this) */
+      ldpc_gblock_store(io.out_mode, io.trace + (size_t)(p - 3) * io.trace_stride, app, num_llr, ncz, tid, nt);
+    } else if (io.use_crc && p >= 3) {
       uint32_t x = 0;
       for (int i = tid; i < crcE; i += nt)
         if (app[i] < 0)
@@ -145,18 +166,8 @@ __device__ __forceinline__ int ldpc_dec_generic_block(int8_t *smem, ldpc_code_pt
   if (io.tb_abort && n_iter == max_pass && tid == 0) /* decoder.c:190-193 */
     __hip_atomic_store(io.tb_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   /* ---- hard decision (decoder.c:864-879; in CRC mode p_out is only written from pass 3 on) ----------- */
-  if ((!io.use_crc || n_iter >= 3) && n_iter <= max_pass) {
-    if (io.out_mode == 0) {
-      uint32_t *o = reinterpret_cast<uint32_t *>(io.out);
-      const int nwords = (num_llr + 31) >> 5;
-      for (int w = tid; w < nwords; w += nt)
-        o[w] = (32 * w < ncz) ? ldpc_pack_word(app, w, ncz) : 0u;
-    } else {
-      int8_t *o = io.out;
-      for (int i = tid; i < num_llr; i += nt)
-        o[i] = (i < ncz) ? (int8_t)(app[i] < 0) : (int8_t)0;
-    }
-  }
+  if ((!io.use_crc || n_iter >= 3) && n_iter <= max_pass && !(io.use_crc && io.trace))
+    ldpc_gblock_store(io.out_mode, io.out, app, num_llr, ncz, tid, nt);
   return n_iter;
 }
 #endif

@@ -32,15 +32,53 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   io.crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
   io.out_mode = a.out_mode;
   io.tb_abort = (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
+  io.trace = nullptr;
+  io.trace_stride = 0;
   const int n_iter = ldpc_dec_generic_block(smem, code, io);
   if (threadIdx.x == 0)
     a.n_iter[job ? (uint32_t)job->iter_idx : blk] = n_iter;
 }
 
+/* CRC stop with the predicate on the host: all passes, the output of every pass >= 3 kept (block b, pass p at
+ * trace + (b * n_trace + p - 3) * trace_stride).  A kernel of its own so that the hot kernels' argument block stays as it is. */
+__global__ void __launch_bounds__(1024) ldpc_dec_generic_trace_kernel(const ldpc_dec_args a, int8_t *trace, uint32_t trace_stride, uint32_t n_trace)
+{
+  extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  const uint32_t blk = blockIdx.x;
+  ldpc_gblock_io io;
+  io.llr = a.llr + (size_t)blk * a.llr_stride;
+  io.out = nullptr;
+  io.max_pass = a.num_max_iter + 1;
+  io.use_crc = 1;
+  io.crcE = 0;
+  io.crc_pow = nullptr;
+  io.out_mode = a.out_mode;
+  io.tb_abort = nullptr;
+  io.trace = trace + (size_t)blk * n_trace * trace_stride;
+  io.trace_stride = trace_stride;
+  const int n_iter = ldpc_dec_generic_block(smem, code, io);
+  if (threadIdx.x == 0)
+    a.n_iter[blk] = n_iter;
+}
+
 hipError_t ldpc_kernels_init(void)
 {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_generic_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_generic_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess)
+    return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_dec_generic_trace_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t ldpc_launch_dec_generic_trace(const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks, int8_t *trace,
+                                         uint32_t trace_stride, uint32_t n_trace, hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(ldpc_dec_generic_trace_kernel, dim3(n_blocks), dim3(hc.n_threads), hc.lds_total, stream, a, trace, trace_stride, n_trace);
+  return hipGetLastError();
 }
 
 hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_t &hc, uint32_t n_blocks,

@@ -77,6 +77,10 @@ hipError_t ldpc_kernels_init(void);
 /* generic flooding min-sum decoder: one workgroup per code block, any (BG, Z, R) */
 hipError_t ldpc_launch_dec_generic(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                    hipStream_t stream);
+/* the same decoder with the CRC stop left to a predicate on the host: every pass runs, the hard decisions of block b after
+ * pass p >= 3 go to trace + (b * n_trace + p - 3) * trace_stride in a.out_mode's format; a.out is not written */
+hipError_t ldpc_launch_dec_generic_trace(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks, int8_t *trace,
+                                         uint32_t trace_stride, uint32_t n_trace, hipStream_t stream);
 /* job-array launches: explicit workgroup size and dynamic LDS (maxima over the jobs) */
 hipError_t ldpc_launch_dec_generic_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
 hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);

@@ -230,6 +230,8 @@ __global__ void __launch_bounds__(SRV_THREADS) ldpc_server_kernel(const srv_args
       io.crc_pow = a->crc_pow_tbl[LDPC_UNIFORM(rq->kind_mode >> 24) & 3u];
       io.out_mode = LDPC_UNIFORM((int)((rq->kind_mode >> 8) & 0xffu));
       io.tb_abort = nullptr;
+      io.trace = nullptr;
+      io.trace_stride = 0;
       n_iter = ldpc_dec_generic_block(reinterpret_cast<int8_t *>(fsm), code, io);
     } else if (ENC && kind == SRV_KIND_ENC) {
       /* up to 8 segments of one code side by side, SRV_ENC_GROUP threads each, in lockstep through the phases.  The segment

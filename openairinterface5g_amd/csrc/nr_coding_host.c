@@ -114,3 +114,24 @@ int nr_hip_rate_match_geometry(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_t C
   g->rank0 = ind < Foffset ? ind : ind - F;
   return g->V > 0 ? 0 : -1;
 }
+
+/* crc_byte.c:314-380.  Polynomials crc_byte.c:46-54 (left aligned); bit-serial, the host only gets here on the slow path of
+ * LDPCdecoder (a caller-supplied predicate is a different function; this one is the library's own, see nrLDPC_hip.h). */
+int nr_hip_check_crc(const uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type)
+{
+  static const uint32_t poly[4] = {0x864CFB00u, 0x80006300u, 0x10210000u, 0x9B000000u};
+  static const uint32_t len[4] = {3, 3, 2, 1};
+  if (crc_type > 3 || n < 8 * len[crc_type])
+    return 0;
+  const uint32_t L = len[crc_type], nbits = n - 8 * L;
+  uint32_t reg = 0;
+  for (uint32_t i = 0; i < nbits; i++) {
+    const uint32_t bit = (decoded_bytes[i >> 3] >> (7 - (i & 7))) & 1u;
+    const uint32_t top = (reg >> 31) ^ bit;
+    reg = (reg << 1) ^ (top ? poly[crc_type] : 0u);
+  }
+  uint32_t stored = 0;
+  for (uint32_t i = 0; i < L; i++)
+    stored = (stored << 8) | decoded_bytes[(n >> 3) - L + i];
+  return (reg >> (32 - 8 * L)) == stored;
+}

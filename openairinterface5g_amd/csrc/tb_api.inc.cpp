@@ -662,12 +662,18 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   bool harq_here = false;
   if (!harq_lib && (!staged || (b->mem & (NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_DEVICE)))) {
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, b->harq) == hipSuccess && at.type == hipMemoryTypeDevice)
+    bool harq_is_dev = false;
+    if (hipPointerGetAttributes(&at, b->harq) == hipSuccess && at.type == hipMemoryTypeDevice) {
+      harq_is_dev = true;
       harq_here = at.device == G().id;
-    else
+    } else {
       (void)hipGetLastError();
+    }
     if (!staged && !harq_here)
       return set_error("soft buffers must be memory of the GPU that holds the LLRs");
+    /* whatever the number of GPUs the call is cut over: a host pointer under this flag would be handed to peer copies */
+    if ((b->mem & NRLDPC_HIP_MEM_HARQ_DEVICE) && !harq_is_dev)
+      return set_error("NRLDPC_HIP_MEM_HARQ_DEVICE: harq is not device memory");
     /* test hook: logical devices that alias one GPU (the GPU box has one) treat the owner's soft buffers as a peer's */
     static const bool stage_env = [] { const char *e = getenv("NRLDPC_HIP_TEST_STAGE_HARQ"); return e && atoi(e) != 0; }();
     if (staged && stage_env)
@@ -1053,7 +1059,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         return -1;
       /* a pageable array of the caller's is mirrored in page-locked memory: rows that travel up are copied into the mirror
        * by the CPU first, rows that come back are handed over by tb_rx_finish (TbCtx::fin_copies) */
-      harq_bounce = to_host && !host_ptr_is_pinned(b->harq + harq_lo, harq_n * 2);
+      /* ... and only a HOST array is: device soft buffers of another GPU (a call cut over several GPUs, this part not the
+       * owner's) take the strided copies directly -- peer copies --, the CPU must never touch them */
+      const bool harq_is_host = !(b->mem & (NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_DEVICE));
+      harq_bounce = to_host && harq_is_host && !host_ptr_is_pinned(b->harq + harq_lo, harq_n * 2);
       if (harq_bounce) { /* this piece's share of the mirror (growing it parks the old area: earlier pieces keep theirs) */
         const size_t at = align_up(c.harq_h_used, 64);
         if (c.harq_h.ensure(at + harq_n * 2) != 0)
@@ -1228,7 +1237,12 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   if (staged) {
     /* payload back: to the caller's array, or (host call, pageable array) to this thread's page-locked staging area */
     uint8_t *pay_dst = (to_host && c.fin_pay_n) ? c.payload_h.p - c.fin_pay_lo : b->payload;
-    if (pl.out_dense || pay_dst != b->payload) { /* (the staging area is ours: one copy of the whole range) */
+    /* one copy of the whole range when the piece's blocks fill it, or when the destination is the staging area of a call that
+     * comes in ONE piece (the area is ours, what lies between the blocks is never handed over).  A call in several pieces
+     * shares the staging area: with payload offsets that do not grow with the block index a later piece's range can span
+     * blocks an earlier piece has already delivered, so there only the blocks themselves are copied, run by run */
+    const bool several_pieces = st && st->call_ntb != ntb;
+    if (pl.out_dense || (pay_dst != b->payload && !several_pieces)) {
       HIP_TRY(hipMemcpyAsync(pay_dst + pl.ext[0], c.io_payload.p, pl.ext[1] - pl.ext[0], hipMemcpyDefault, s));
     } else {
       for (const TbPlan::OutRun &r : pl.out_runs)
@@ -1320,7 +1334,7 @@ int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t nt
   static const int chunks_env = [] { const char *e = getenv("NRLDPC_HIP_TB_HOST_CHUNKS"); return e ? atoi(e) : 0; }(); /* tuning knob */
   const int mode = tb_pull_mode();
   int K = chunks_env > 0 ? chunks_env : (int)std::min<size_t>(8, bytes / ((size_t)5 << 20));
-  K = std::min<int>(K, (int)ntb / 2);
+  K = std::min<int>(std::min<int>(K, 8), (int)ntb / 2); /* cut[] below holds 8 chunks; the knob is not trusted */
   const bool pinned = host_ptr_is_pinned(static_cast<const int16_t *>(b->coded) + lo, bytes);
   if (K < 2 || (pinned && (mode == 2 || (mode == 1 && bytes < pull_max))))
     return tb_rx_enqueue(b, tb0, ntb, true, nullptr, &st);
@@ -1530,7 +1544,7 @@ int32_t nrLDPC_hip_harq_read(uint64_t id, int16_t *dst, uint64_t first, uint64_t
       return set_error("unknown soft-buffer id");
     e = it->second;
   }
-  if (!dst || first + n > e.n)
+  if (!dst || first > e.n || n > e.n - first) /* (written so that huge arguments cannot wrap) */
     return set_error("range outside the soft buffers");
   /* (no device-wide wait: the resident server kernels of the per-segment entry points may be running for as long as
    * requests keep coming.  A host-memory decode call has finished when it returns; after a device-memory call the caller

@@ -80,11 +80,16 @@ class nrLDPC_hip_enc_batch_t(C.Structure):
                 ("mem", C.c_int32), ("stream", C.c_void_p)]
 
 
-# any non-NULL pointer selects CRC early stop; the library never calls it (include/nrLDPC_hip.h)
-_CRC_SENTINEL = CHECK_CRC_T(lambda p, n, t: 0)
+_user_predicates = []   # CFUNCTYPE objects of caller-supplied predicates must outlive the parameter blocks that hold them
+
+
+def device_crc_pointer():
+    """Address of the library's nrLDPC_hip_check_crc: in t_nrLDPC_dec_params.check_crc it selects the CRC stop that the GPU
+    evaluates (as the host executable's own `check_crc` does); any other pointer is called on the host (nrLDPC_hip.h)."""
+    return C.cast(load_library().nrLDPC_hip_check_crc, C.c_void_p).value
 
 EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "LDPCdecoder_batch", "LDPCencoder_batch",
-           "LDPCdecoder_jobs", "nrLDPC_hip_checkbuildver",
+           "LDPCdecoder_jobs", "nrLDPC_hip_checkbuildver", "nrLDPC_hip_check_crc",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
 
@@ -175,8 +180,13 @@ def out_bytes(BG, Z, R, outMode=nrLDPC_outMode_BIT):
 
 def make_dec_params(BG, Z, R, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_crc=False, E=0, crc_type=CRC24_B):
     p = t_nrLDPC_dec_params(BG=BG, Z=Z, R=R, numMaxIter=numMaxIter, outMode=outMode, E=E, crc_type=crc_type)
-    if check_crc:
-        p.check_crc = C.cast(_CRC_SENTINEL, C.c_void_p)
+    if callable(check_crc):      # a caller's own predicate (decoded_bytes_ptr, n, crc_type) -> int: called on the host
+        cb = CHECK_CRC_T(check_crc)
+        _user_predicates.append(cb)
+        del _user_predicates[:-64]
+        p.check_crc = C.cast(cb, C.c_void_p)
+    elif check_crc:
+        p.check_crc = device_crc_pointer()
     return p
 
 

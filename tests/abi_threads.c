@@ -29,7 +29,8 @@ static const int cases[NCASE][4] = { /* BG, Z, R, numMaxIter */
   {1, 384, 13, 8}, {1, 384, 13, 8}, {1, 384, 23, 8}, {1, 352, 89, 5}, {2, 64, 15, 8}, {2, 208, 13, 8},
   {1, 96, 13, 8},  {1, 384, 13, 2}, {2, 6, 15, 8},   {1, 18, 13, 8},  {2, 384, 23, 8}, {1, 384, 13, 8}};
 static int ncols(int BG, int R) { return BG == 1 ? (R == 13 ? 68 : R == 23 ? 35 : 27) : (R == 15 ? 52 : R == 13 ? 32 : 17); }
-static int crc_cb(uint8_t *b, uint32_t n, uint8_t t) { (void)b; (void)n; (void)t; return 0; } /* mode flag only */
+typedef int (*crc_t)(uint8_t *, uint32_t, uint8_t);
+static crc_t crc_cb; /* the library's nrLDPC_hip_check_crc: the CRC stop that is evaluated on the GPU (a caller's own predicate would be called on the host) */
 
 static dec_t dec;
 static int8_t *llr[NCASE];
@@ -77,7 +78,8 @@ int main(int argc, char **argv)
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   init_t init = (init_t)dlsym(h, "LDPCinit");
   dec = (dec_t)dlsym(h, "LDPCdecoder");
-  if (!init || !dec || init() != 0) { fprintf(stderr, "LDPCinit failed\n"); return 2; }
+  crc_cb = (crc_t)dlsym(h, "nrLDPC_hip_check_crc");
+  if (!init || !dec || !crc_cb || init() != 0) { fprintf(stderr, "LDPCinit failed\n"); return 2; }
   progress = getenv("ABI_PROGRESS") != NULL;
   allow_nack = getenv("ABI_ALLOW_NACK") != NULL;
   clock_gettime(CLOCK_MONOTONIC, &t_start);

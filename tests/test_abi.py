@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def declared_functions():
     txt = (ROOT / "include" / "nrLDPC_hip.h").read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|uint32_t|char|void)\s*\*?\s*(\w+)\s*\(", txt, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|uint32_t|int|char|void)\s*\*?\s*(\w+)\s*\(", txt, flags=re.M)
     return sorted(set(names))
 
 

@@ -138,6 +138,48 @@ def test_reference_code_words_are_accepted_by_every_kernel(hip):
                 assert np.array_equal(np.unpackbits(out[0])[:K], bits[:K]), (kern, BG, Z, R)
 
 
+def test_caller_supplied_crc_predicate_is_called_like_the_reference_calls_it(hip, tmp_path):
+    """t_nrLDPC_dec_params.check_crc that is neither the library's nrLDPC_hip_check_crc nor the host executable's
+    `check_crc`: called on the host with (p_out, E, crc_type) after every pass >= 3 until it holds
+    (nrLDPC_decoder.c:849-861).  First from C, without an oracle (tests/abi_check_crc.c); then with the oracle's CRC as the
+    caller's predicate: pass counts and outputs of the oracle's CRC-stop decode, also where the GPU's own CRC cannot
+    serve (E % 8 != 0, byte-per-bit output)."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_check_crc"
+    subprocess.run(["gcc", "-O2", "-I", str(root / "include"), str(root / "tests" / "abi_check_crc.c"), "-o", str(exe), "-ldl"],
+                   check=True)
+    r = subprocess.run([str(exe), str(hip.ldpc.LIB_PATH)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "abi_check_crc: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+    rng = np.random.default_rng(404)
+    for BG, Z, R in ((1, 384, 13), (2, 208, 13), (1, 30, 89), (2, 64, 15)):
+        K = kbits(BG, Z)
+        llrs = [make_llr(rng, BG, Z, R, snr, random_info(rng, BG, Z, with_crc24b=True)) for snr in (3.0, 0.5, -5.0)]
+        for mode, E in ((0, K), (1, K), (0, K - 5), (2, K - 16)):
+            seen = []
+
+            def pred(ptr, n, t):
+                seen.append((n, t))
+                return O.check_crc(np.ctypeslib.as_array(ptr, shape=(n // 8 + 4,)), n, t)
+            for llr in llrs:
+                n_ref, out_ref = O.decode(BG, Z, R, llr, 8, mode, True, E, O.CRC24_B, out_init=0x77)
+                pre = np.full((1, (out_ref.size + 3) // 4 * 4), 0x77, np.uint8)
+                seen.clear()
+                n_it, out = hip.decode_batch_host(BG, Z, R, llr[None, :], numMaxIter=8, outMode=mode, check_crc=pred, E=E,
+                                                  crc_type=O.CRC24_B, out=pre)
+                assert n_it[0] == n_ref and np.array_equal(out[0], out_ref), (BG, Z, R, mode, E, int(n_it[0]), n_ref)
+                assert len(seen) == n_ref - 2 and all(c == (E, O.CRC24_B) for c in seen)
+                # the by-name symbol; and the library's own predicate where the GPU's CRC cannot serve (falls to the host path)
+                p = hip.make_dec_params(BG, Z, R, 8, mode, pred, E, O.CRC24_B)
+                n1, out1 = hip.LDPCdecoder(p, llr, p_out=np.full(out_ref.size, 0x77, np.uint8))
+                assert n1 == n_ref and np.array_equal(out1, out_ref)
+                p = hip.make_dec_params(BG, Z, R, 8, mode, True, E, O.CRC24_B)
+                n2, out2 = hip.LDPCdecoder(p, llr, p_out=np.full(out_ref.size, 0x77, np.uint8))
+                assert n2 == n_ref and np.array_equal(out2, out_ref), (BG, Z, R, mode, E)
+
+
 def test_reference_entry_point_and_abort(hip):
     """LDPCdecoder(), the symbol the reference's callers use, incl. the TB abort protocol (decoder.c:190-193,556-559)."""
     BG, Z, R = 1, 176, 13

@@ -286,7 +286,7 @@ def test_residency_flags_and_mixed_call_errors(hip):
     n_it = torch.zeros(2, dtype=torch.int32, device="cuda")
     jobs = m.PreparedDecJobs(blk, n_it)
     assert L.LDPCdecoder_jobs(jobs.arr, 2, n_it.data_ptr(), m.MEM_HOST, None) != 0
-    jobs.arr[1].params.check_crc = C.cast(m._CRC_SENTINEL, C.c_void_p).value      # two stop modes in one call
+    jobs.arr[1].params.check_crc = m.device_crc_pointer()      # two stop modes in one call
     jobs.arr[1].params.E, jobs.arr[1].params.crc_type = 22 * 64, 1
     assert L.LDPCdecoder_jobs(jobs.arr, 2, n_it.data_ptr(), m.MEM_DEVICE, None) != 0
     assert L.LDPCdecoder_jobs(jobs.arr, 0, n_it.data_ptr(), m.MEM_DEVICE, None) == 0
