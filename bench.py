@@ -142,7 +142,7 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
     # a process group of ONE rank (BENCH_FORCE_DIST=1 on a one-GPU box): the slot is cut for 4 virtual ranks and the virtual
     # peers' LLRs and results go through real RCCL send / receive pairs to this rank itself (parallel.ShardedUlsch
     # loopback) -- the N > 1 protocol on hardware, not a measurement of N > 1
-    loop = 4 if (dist is not None and world == 1) else 0
+    loop = int(os.environ.get("BENCH_LOOPBACK_RANKS", "4")) if (dist is not None and world == 1) else 0
     sh = parallel.ShardedUlsch(tbs, device=dev, numMaxIter=MAX_ITER, loopback=loop)
     if dist is not None:
         # every rank reached the collective section with its inputs built (a rank that raised above never gets here and
@@ -157,15 +157,33 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
+    # (a) the slot as a latency: one slot, wait, next slot -- the host's synchronize() per step is inside the figure;
     t0 = time.perf_counter()
     for _ in range(steps):
         out = sh.decode(llr)
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_each = time.perf_counter() - t0
+    # (b) the slots back to back: K slots enqueued, ONE pair of events on the stream the chain runs on around them (what a
+    # profile of the kernels shows; the driver's clock around (a) reads 10 % longer than the kernels take)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dist.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        out = sh.decode(llr)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    share_ms = [dt / steps * 1e3]
+    if dist is not None:
+        t = torch.tensor([dt, dt_each], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                      # every rank's own time: a slow rank is visible in the line
+        share_ms = [float(x[0].item()) / steps * 1e3 for x in every]
+        dt, dt_each = max(float(x[0].item()) for x in every), max(float(x[1].item()) for x in every)
     if rank != 0:
         return None
     pay, ack, itm = out
@@ -175,6 +193,13 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
                         "segments) arriving on rank 0: scatter LLRs -> UL-SCH chain on every rank -> gather payloads/ACKs",
             "scaling": "strong", "n_gpus": world, "transport_blocks_per_rank": [int(b - a) for a, b in sh.tb_ranges],
             "pipeline_chunks_per_rank": [len(c) - 1 for c in sh.chunk_cut],
+            "segments_per_rank": [int(sum(segs[a:b])) for a, b in sh.tb_ranges],
+            "llr_bytes_per_rank": [int(co[b] - co[a]) * 2 for a, b in sh.tb_ranges],
+            "ms_per_slot_per_rank": share_ms,
+            "timing": "ms_per_slot: K slots enqueued back to back, one synchronize (max over ranks of the host clock); "
+                      "ms_per_slot_events_rank0: a HIP event pair on the chain's stream around the same K slots; "
+                      "ms_per_slot_synchronised_each: one slot, synchronize, next slot",
+            "ms_per_slot_events_rank0": ev_ms / steps, "ms_per_slot_synchronised_each": dt_each / steps * 1e3,
             "steps": steps, "ms_per_slot": dt / steps * 1e3, "info_gbps": n_tb * A * steps / dt / 1e9,
             "coded_gbps": n_tb * G * steps / dt / 1e9, "llr_bytes_scattered": int(co[-1]) * 2,
             "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
@@ -342,11 +367,15 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        per_rank = [dt]
         if dist is not None:
             dist.barrier()
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)                       # the job time is the MAX; the others are kept for the line
+            per_rank = [float(x.item()) for x in every]
+            dt = max(per_rank)
+        timed.per_rank_ms = [x / steps * 1e3 for x in per_rank]
         return dt, kern_ms
 
     if dist is not None:   # first collectives set up the communicator: keep that out of every timed region
@@ -355,6 +384,7 @@ def main():
 
     # ---- headline: fixed work (all 9 passes) ----------------------------------------------------------
     dt, kern_ms = timed(llr_fixed, args.steps, args.warmup)
+    per_rank_ms_per_step = list(timed.per_rank_ms)
     passes_fixed = float(n_iter.float().mean().item())
     value = world * args.steps * BATCH * N_TX / dt / 1e9
     kern_avg_s = float(np.mean(kern_ms)) / 1e3
@@ -421,11 +451,18 @@ def main():
             # micro-benchmarked per-opcode rates), recorded with the counters by tools/make_traffic_json.py
             avg_ns = pmc.get("valu_avg_ns_per_wave_inst_per_simd") or 1.43
             t_issue = pmc["valu_wave_insts_per_launch"] / n_simd * avg_ns * 1e-9
+            # of the issued VALU wave-instructions, the part that is check-node / bit-node arithmetic: 32 per (edge, 4-lane
+            # item, pass) = the instruction count of the two bodies (profiles/r04/README.md (b)); the rest is item decoding,
+            # task / record unpacking, masks, partly filled tasks, prologue, hard decision -- the target of any further work
+            arith = EDGES * (Z // 4) * 32 // 64 * PASSES_FIXED * BATCH      # (wave-instructions: 64 items per wave)
             binding.update({"valu_wave_insts_per_launch": pmc["valu_wave_insts_per_launch"],
-                            "issue_time_at_measured_opcode_rates_ms": t_issue * 1e3, "frac": t_issue / kern_avg_s})
+                            "issue_time_at_measured_opcode_rates_ms": t_issue * 1e3, "frac": t_issue / kern_avg_s,
+                            "cn_bn_arithmetic_wave_insts_per_launch": arith,
+                            "overhead_frac": 1.0 - arith / pmc["valu_wave_insts_per_launch"]})
         line = {
             "metric": "ldpc_decoder_coded_throughput", "value": value, "unit": "Gb/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_per_rank": per_rank_ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "BG1 Zc=384 R=1/3 numMaxIter=8 flooding min-sum, 1024 code blocks per GPU per step, "
                                    "fixed work (Es/N0=-12 dB: all 9 passes run), parity-check stop mode",
@@ -433,6 +470,11 @@ def main():
                        "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # `traffic` and binding_resource's counter figures are NOT measured in this run: rocprofv3 PMC
+                         # passes cannot run inside it.  They come from the tracked file named here, collected on the
+                         # build that binding_resource.counters_measured_on identifies (`stale` says if that is this one)
+                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                                           "tools/gpu_pmc.sh + tools/make_traffic_json.py)" if traffic is not None else None,
                          "model": "A_min: compulsory bytes = LLR in + bits out = 27 168 B/block (SURVEY 8d); the kernel is "
                                   "LDS-resident and NOT HBM bound -- see binding_resource",
                          "bytes_per_launch": BATCH * A_MIN, "kernel_avg_ms": kern_avg_s * 1e3,

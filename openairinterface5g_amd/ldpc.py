@@ -524,7 +524,7 @@ def dlsch_encode_host(tbs, payloads):
     return [coded[co[i]:co[i] + tbs[i]["G"]].copy() for i in range(len(tbs))]
 
 
-def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=None, pinned=False):
+def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=None, pinned=False, payload_off=None):
     """RX chain for a batch of transport blocks, host buffers.  llrs: list of int16[G]; harq: int16 array
     [total segments, HARQ_STRIDE] holding the soft buffers of all TBs back to back (updated in place); each tb dict
     may carry 'round' and 'llrLen' ('llrLen' is updated).  harq_off: explicit int16 offsets of the TBs' soft buffers in
@@ -532,12 +532,16 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=Non
     Soft buffers on the GPU while everything else stays on the host (what nr_ulsch_decoding's caller needs: the LLRs of a
     slot arrive in host memory, d[r] persists per HARQ process): `harq` a torch int16 CUDA tensor (MEM_HARQ_DEVICE), or
     harq=None with harq_ids = one id per TB (MEM_HARQ_LIBRARY: the library keeps them; harq_read() looks at them).
-    pinned: the LLR array goes into page-locked memory (nrLDPC_hip_host_alloc) and is pulled by the GPU in place."""
+    pinned: the LLR array goes into page-locked memory (nrLDPC_hip_host_alloc) and is pulled by the GPU in place.
+    payload_off: explicit byte offsets of the TBs' payloads in the call's payload array (any order) instead of back to back."""
     L = _tb_lib()
     n = len(tbs)
     if harq_ids is not None or not isinstance(harq, np.ndarray):
-        return _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned)
+        return _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned, payload_off)
     po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    pay_total = int(po[-1])
+    if payload_off is not None:
+        po = list(payload_off)
     co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
     segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
     ho = np.cumsum([0] + [c * HARQ_STRIDE for c in segs])
@@ -545,7 +549,7 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=Non
         ho = list(harq_off)
         assert len(ho) == n and all(o + c * HARQ_STRIDE <= harq.size for o, c in zip(ho, segs))
     assert harq.dtype == np.int16 and harq.flags.c_contiguous and harq.size >= max(o + c * HARQ_STRIDE for o, c in zip(ho, segs))
-    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    pay = np.zeros(pay_total + 16, np.uint8)
     keep = PinnedArray(int(co[-1]) + 16, np.int16) if pinned else None
     llr = keep.a if pinned else np.zeros(int(co[-1]) + 16, np.int16)
     llr[:] = 0
@@ -563,10 +567,13 @@ def ulsch_decode_host(tbs, llrs, harq, numMaxIter=8, harq_off=None, harq_ids=Non
     return [pay[po[i]:po[i] + tbs[i]["A"] // 8].copy() for i in range(n)], ack.astype(bool), itm
 
 
-def _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned):
+def _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_ids, pinned, payload_off=None):
     """host payload / LLRs / verdicts with the soft buffers resident on the GPU (see ulsch_decode_host)"""
     n = len(tbs)
     po = np.cumsum([0] + [(t["A"] // 8 + 15) // 16 * 16 for t in tbs])
+    pay_total = int(po[-1])
+    if payload_off is not None:
+        po = list(payload_off)
     co = np.cumsum([0] + [(t["G"] + 7) // 8 * 8 for t in tbs])
     segs = [nr_segmentation(t["A"] + (24 if t["A"] > 3824 else 16), t["BG"])["C"] for t in tbs]
     if harq_ids is not None:
@@ -576,7 +583,7 @@ def _ulsch_decode_host_resident(L, tbs, llrs, harq, numMaxIter, harq_off, harq_i
         ho = list(harq_off) if harq_off is not None else list(np.cumsum([0] + [c * HARQ_STRIDE for c in segs])[:n])
         assert harq.is_cuda and harq.is_contiguous() and harq.numel() >= max(o + c * HARQ_STRIDE for o, c in zip(ho, segs))
         hp, mem = harq.data_ptr(), MEM_HOST | MEM_HARQ_DEVICE
-    pay = np.zeros(int(po[-1]) + 16, np.uint8)
+    pay = np.zeros(pay_total + 16, np.uint8)
     keep = PinnedArray(int(co[-1]) + 16, np.int16) if pinned else None
     llr = keep.a if pinned else np.zeros(int(co[-1]) + 16, np.int16)
     llr[:] = 0

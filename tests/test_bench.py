@@ -48,6 +48,25 @@ def test_rccl_path_runs_on_one_gpu(hip):
     c = line["chain_roofline"]
     assert "error" not in c and c["all_ack"] and 0.2 < c["frac"] < 1.0 and c["fused_segment_kernel_us"] > 0
     assert line["roofline"]["binding_resource"]["stale"] in (True, False) and line["build"]["version"].startswith("libldpc_hip")
+    assert line["roofline"]["traffic_source"].startswith("profiles/hbm_traffic.json") and 0 < line["roofline"]["binding_resource"]["overhead_frac"] < 1
+    assert len(line["ms_per_step_per_rank"]) == 1 and len(s["ms_per_slot_per_rank"]) == 1
+    assert s["ms_per_slot_events_rank0"] <= s["ms_per_slot"] * 1.05 and s["ms_per_slot_synchronised_each"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_eight_virtual_ranks(hip):
+    """The node's width before the node does it: the slot cut for EIGHT virtual ranks (8 transport blocks each, seven peers'
+    LLRs and results through RCCL send / receive pairs in three chunks per peer), every payload byte compared."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_LOOPBACK_RANKS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-chain",
+                        "--no-operating-point"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    s = line["strong_scaling_slot"]
+    assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["loopback_virtual_ranks"] == 8
+    assert s["transport_blocks_per_rank"] == [8] * 8 and s["segments_per_rank"] == [208] * 8
+    assert s["pipeline_chunks_per_rank"] == [1] + [3] * 7
+    assert s["rccl_p2p_bytes_per_slot"] >= 56 * (245700 * 2 + 213176 // 8 + 5)
 
 
 @pytest.mark.gpu

@@ -211,6 +211,46 @@ def test_device_resident_batches_sharded_over_logical_devices(hip, tmp_path):
                 assert np.array_equal(o[f"caller{rnd}_{what}"], o[f"library{rnd}_{what}"]), (rnd, what)
 
 
+def test_the_64_block_slot_cut_eight_ways(hip, tmp_path):
+    """SURVEY 8e at the width the node has: NRLDPC_HIP_DEVICES=0,0,0,0,0,0,0,0 (eight device contexts that alias the one GPU
+    of the box) on the full slot of BASELINE configs[4] -- 64 transport blocks, 8 per device, the peers' ranges staged seven
+    times -- against the single-device run of the same script: host and device-resident buffers, soft buffers kept by the
+    library (migrating between devices from round 0 to round 1), by the caller on the host, and by the caller in device memory
+    under host LLRs; plus the chunked host call with scrambled payload offsets (tests/multidev_slot_script.py)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "multidev_slot_script.py"
+    outs = []
+    for devs in (None, "0,0,0,0,0,0,0,0"):
+        env = dict(os.environ)
+        env.pop("NRLDPC_HIP_DEVICES", None)
+        if devs:
+            env["NRLDPC_HIP_DEVICES"] = devs
+            env["NRLDPC_HIP_TEST_STAGE_HARQ"] = "1"     # the aliased contexts treat the owner's soft buffers as a peer GPU's
+        f = tmp_path / f"slot_{'8' if devs else '1'}.npz"
+        r = subprocess.run([sys.executable, str(script), str(f)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    A8 = 213176 // 8
+    for o in outs:
+        sent = o["sent"].reshape(64, A8)
+        for tag in ("host_lib", "host_host", "host_dev", "dev_lib", "dev_dev"):
+            ack0, ack1 = o[f"{tag}0_ack"].astype(bool), o[f"{tag}1_ack"].astype(bool)
+            assert 0 < ack0.sum() < 64 and ack1.all(), (tag, int(ack0.sum()), int(ack1.sum()))   # round 0 loses blocks, combining recovers all
+            assert np.array_equal(o[f"{tag}1_pay"].reshape(64, A8), sent), tag
+            assert np.array_equal(o[f"{tag}0_pay"].reshape(64, A8)[ack0], sent[ack0]), tag
+            assert not o[f"{tag}0_pay"].reshape(64, A8)[~ack0].any(), tag                        # a lost block delivers zeros
+            for what in ("ack", "itm", "pay", "llrLen", "harq"):                                  # every arrangement: the same numbers
+                for rnd in (0, 1):
+                    assert np.array_equal(o[f"{tag}{rnd}_{what}"], o[f"host_host{rnd}_{what}"]), (tag, rnd, what)
+        assert o["chunked0_ack"].all() and np.array_equal(o["chunked0_pay"].reshape(64, A8), sent)
+
+
 _KEEP_ALIVE = []
 
 
