@@ -484,6 +484,46 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
       if (!found)
         return -1;
     }
+    /* the same three steps with every known column replaced by its own expression: sums of (source, shift) terms over
+     * the lambdas (sources 0..3) and p0 (source 4) only; a term met twice cancels */
+    {
+      int n[4] = {1, 0, 0, 0}, src[4][32], sh[4][32];
+      src[0][0] = 4;
+      sh[0][0] = 0;
+      for (int step = 0; step < 3; step++) {
+        const int u = d->enc_unk[step], us = d->enc_ushift[step] % Z;
+        int tn = 0, tsrc[32], tsh[32];
+        tsrc[tn] = d->enc_row[step];
+        tsh[tn++] = (Z - us) % Z;
+        for (int k = 0; k < d->enc_nk[step]; k++) {
+          const int kc = d->enc_kcol[step][k], ks = d->enc_kshift[step][k] % Z;
+          for (int m = 0; m < n[kc]; m++) {
+            if (tn >= 32)
+              return -1;
+            tsrc[tn] = src[kc][m];
+            tsh[tn++] = (sh[kc][m] + ks + Z - us) % Z;
+          }
+        }
+        n[u] = 0;
+        for (int a = 0; a < tn; a++) { /* keep the terms that occur an odd number of times */
+          int cnt2 = 0, first = 1;
+          for (int b = 0; b < tn; b++)
+            if (tsrc[b] == tsrc[a] && tsh[b] == tsh[a]) {
+              cnt2++;
+              if (b < a)
+                first = 0;
+            }
+          if (first && (cnt2 & 1)) {
+            src[u][n[u]] = tsrc[a];
+            sh[u][n[u]++] = tsh[a];
+          }
+        }
+        if (n[u] > 8)
+          return -1;
+        for (int m = 0; m < 8; m++)
+          d->enc_x_term[step][m] = m < n[u] ? ((uint32_t)src[u][m] << 16) | (uint32_t)sh[u][m] : 0xffffffffu;
+      }
+    }
   }
 
   /* LDS carve-up of the generic kernel: messages, APP of the core columns, channel LLRs, flags */

@@ -137,6 +137,11 @@ typedef struct ldpc_code_desc {
    * the column records of a ticket -- or the row records of a check-node task -- in its record, instead of looking them
    * up in LDS, was slower: profiles/r04/decoder_ab26_record_carried_lookups.txt) */
   int32_t f_bn_rec[LDPC_F_MAX_BN_TASKS][4];
+  /* encoder, the three solve steps above in CLOSED form: core parity column enc_unk[st] as a sum of shifted copies of the
+   * four lambdas and of p0 alone -- p_unk[u] = XOR_m src_m[(u + shift_m) mod Z], enc_x_term[st][m] = src << 16 | shift with
+   * src 0..3 = lambda of core row src, 4 = p0; unused entries 0xffffffff.  With these the three columns no longer wait for
+   * each other: one step after p0 instead of three (ldpc_enc_packed32.h). */
+  uint32_t enc_x_term[3][8];
 } ldpc_code_desc_t;
 
 #ifdef __cplusplus

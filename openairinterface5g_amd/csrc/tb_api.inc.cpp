@@ -404,7 +404,10 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     size_t total_payload = 0;
     for (uint32_t i = 0; i < ntb; i++)
       total_payload += tbs[i].A / 8;
-    const uint32_t crc_chunk = total_payload <= 256u * 1024u ? TB_CRC_CHUNK_SMALL : TB_CRC_CHUNK; /* tb_chain.h */
+    /* tb_jobs.h; NRLDPC_HIP_TB_CRC_CHUNK = 1 / 2 forces short / long pieces (A/B knob, read when a plan is built) */
+    static const int chunk_env = [] { const char *e = getenv("NRLDPC_HIP_TB_CRC_CHUNK"); return e ? atoi(e) : 0; }();
+    const uint32_t crc_chunk = chunk_env == 1 ? TB_CRC_CHUNK_SMALL : chunk_env == 2 ? TB_CRC_CHUNK
+                               : total_payload <= 256u * 1024u ? TB_CRC_CHUNK_SMALL : TB_CRC_CHUNK;
     for (uint32_t i = 0; i < ntb; i++) {
       const nrLDPC_hip_tb_t &t = tbs[i];
       if (tb_validate(t) != 0)
@@ -425,6 +428,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       ex.add(ex.pay_lo, ex.pay_hi, (size_t)t.payload_off, (size_t)t.payload_off + t.A / 8);
       ex.add(ex.cod_lo, ex.cod_hi, (size_t)t.coded_off, (size_t)t.coded_off + t.G);
       ex.cod_sum += t.G;
+      const uint32_t chunk0 = (uint32_t)cj.size();
       for (uint32_t fb = 0; fb < t.A / 8; fb += crc_chunk)
         cj.push_back(tb_crc_chunk_job{i, fb | (crc_chunk == TB_CRC_CHUNK_SMALL ? 0x80000000u : 0u)});
       const ldpc_code_desc_t &hc = ce->host;
@@ -437,7 +441,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       for (uint32_t r = 0; r < sg.C; r++) {
         tb_tx_seg_job j;
         memset(&j, 0, sizeof(j));
-        j.b_off = tbj[i].b_off;
+        j.b_off = fused ? t.payload_off : tbj[i].b_off; /* fused: the segment's bytes come straight from the payload array */
         if (!fused) { /* the fused kernel keeps c and d in LDS */
           j.c_off = ar.take(sg.K / 8 + 4);
           j.d_off = ar.take(N);
@@ -454,6 +458,8 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         if (r + 1 == sg.C) { /* the TB CRC bytes sit at the end of the last segment's share of b */
           j.crc_len = (B - t.A) / 8;
           j.crc_pos = t.A / 8 - r * ((sg.Kprime - sg.L) >> 3);
+          j.crc_chunk0 = chunk0;
+          j.crc_nchunks = (uint32_t)cj.size() - chunk0;
         }
         r_offset += j.E;
         sj.push_back(j);
@@ -467,7 +473,8 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
                  o_enc = o_seg + align_up(n_seg * sizeof(tb_tx_seg_job), 16),
                  o_chk = o_enc + align_up(n_seg * sizeof(ldpc_enc_job), 16),
                  o_acc = o_chk + align_up(cj.size() * sizeof(tb_crc_chunk_job), 16),
-                 jobs_bytes = o_acc + align_up((size_t)ntb * sizeof(uint32_t), 16); /* CRC accumulators: uploaded as zeros */
+                 /* CRC accumulators, uploaded as zeros: one per block (unfused path, atomics) / one per chunk (fused) */
+                 jobs_bytes = o_acc + align_up(std::max<size_t>(ntb, cj.size()) * sizeof(uint32_t), 16);
     if (tb_wait_upload(c) != 0 || c.jobs_h.ensure(jobs_bytes) != 0 || pl.jobs_d.ensure(jobs_bytes) != 0)
       return -1;
     memset(c.jobs_h.p + o_acc, 0, jobs_bytes - o_acc);
@@ -527,7 +534,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
      * a launch that does not even fill the GPU four deep takes 512 and halves the rounds of its long stages */
     const int fused_threads = n_seg <= (size_t)4 * (size_t)G().n_cus ? 512 : enc_threads;
     TB_DEBUG_STAGE("tx: TB CRC launch");
-    HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, fused_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, c.scratch.p, coded,
+    HIP_TRY(tb_launch_tx_fused(d_seg, d_enc, (uint32_t)n_seg, fused_threads, enc_lds + TB_TX_FUSED_EXTRA_LDS, payload, coded,
                                G().crc_pow[NR_HIP_CRC24_B], d_acc, s));
     TB_DEBUG_STAGE("tx: fused segment launch");
   } else {

@@ -14,6 +14,7 @@
 #include "tb_chain.h"
 #include "ldpc_kernels.h"
 #include "ldpc_enc_packed_core.h"
+#include "ldpc_enc_packed32.h"
 /* the separate de-matching launch holds 8 workgroups per CU (64 VGPRs): their occupancy hides the LLRs' latency, and symbols
  * requested ahead of the clearing would only spill (the fused segment kernel, 126 VGPRs and two workgroups per CU, asks
  * for four: tb_rx_fused.hip) */
@@ -134,7 +135,7 @@ __device__ __forceinline__ uint32_t tb_partial_crc(const uint8_t *__restrict__ d
 /* ---- TX 1: b = payload || CRC24A / CRC16 -- chunk-parallel: copy + partial CRC, then the CRC bytes ----------- */
 __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_tx_tb_job *jobs, const tb_crc_chunk_job *chunks,
                                                                        const uint8_t *payload, uint8_t *scratch, uint32_t *acc,
-                                                                       const uint32_t *pow24a, const uint32_t *pow16)
+                                                                       const uint32_t *pow24a, const uint32_t *pow16, int copy)
 {
   __shared__ uint32_t tab[256];
   tb_crc_chunk_job ch = chunks[blockIdx.x];
@@ -148,7 +149,9 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_
   uint8_t *b = scratch + j.b_off;
   const uint32_t nbytes = j.A >> 3;
   const uint32_t count = ch.first_byte + chunk <= nbytes ? chunk : nbytes - ch.first_byte;
-  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u) == 0) { /* (chunks start at multiples of 16) */
+  /* copy = 0 (the fused segment kernel follows: it takes its bytes from the payload itself): no b, nothing but the CRC */
+  if (!copy) {
+  } else if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u) == 0) { /* (chunks start at multiples of 16) */
     const uint4 *a16 = reinterpret_cast<const uint4 *>(a + ch.first_byte);
     uint4 *b16 = reinterpret_cast<uint4 *>(b + ch.first_byte);
     for (uint32_t q = threadIdx.x; q < (count >> 4); q += blockDim.x)
@@ -167,8 +170,21 @@ __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_partial_kernel(const tb_
   else
     x = j.crc_type == 0 ? tb_partial_crc<32, 24>(a, j.A, ch.first_byte, count, pow, tab)
                         : tb_partial_crc<32, 16>(a, j.A, ch.first_byte, count, pow, tab);
-  if ((threadIdx.x & 63) == 0 && x)
-    atomicXor(&acc[ch.tb], x);
+  /* ONE atomic per workgroup: atomics on one address are served one after the other (~0.35 us each on this stack: the launch
+   * took 8.7 us with 16 per transport block and 21 us with 56, profiles/r05/README.md), so the waves meet in LDS first */
+  __shared__ uint32_t wsum[TB_THREADS / 64];
+  if ((threadIdx.x & 63) == 0)
+    wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < blockDim.x >> 6; w++)
+      t ^= wsum[w];
+    if (!copy)
+      acc[blockIdx.x] = t; /* the fused segment kernel adds the chunks of a block up itself: no atomic at all */
+    else if (t)
+      atomicXor(&acc[ch.tb], t);
+  }
 }
 __global__ void __launch_bounds__(TB_THREADS) tb_tx_crc_final_kernel(const tb_tx_tb_job *jobs, uint32_t n_tb, uint8_t *scratch,
                                                                      uint32_t *acc)
@@ -286,6 +302,7 @@ __device__ __forceinline__ void tb_tx_store_syms(const uint32_t *sel, uint32_t s
 }
 
 typedef uint32_t tb_u32x4_t __attribute__((ext_vector_type(4)));
+template <typename J> __device__ __forceinline__ uint32_t crc_len_of(J j) { return j->crc_len; }
 __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job *jobs, const ldpc_enc_job *ejobs, const uint8_t *scratch,
                                                           uint8_t *coded, const uint32_t *pow24b, uint32_t *acc)
 {
@@ -337,20 +354,27 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
   /* the segment that ends the transport block takes the TB CRC from the accumulator the partial-CRC kernel left (and
    * clears it for the next call): no kernel of its own for three bytes per transport block */
   const uint32_t crc_len = j->crc_len, crc_pos = j->crc_pos;
-  const uint32_t tb_crc = crc_len ? acc[j->tb] : 0u;
+  uint32_t tb_crc = 0;
+  for (uint32_t k = 0; k < j->crc_nchunks; k++) /* (uniform addresses: scalar loads) */
+    tb_crc ^= acc[j->crc_chunk0 + k];
   /* every global load of the stage goes out before anything is consumed (written as separate loops the compiler waited
    * for each one in turn: four round trips for the segment's bytes alone): the segment as aligned dwords -- two per LDS
    * dword, the source is only byte aligned --, the edge table, the row pointers */
   const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u), ndw = (segbytes + 3u) >> 2;
   const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src - a0);
+  /* `scratch` is the caller's PAYLOAD array: no dword is touched that does not hold a byte of this transport block (the TB
+   * CRC bytes, which the last segment's share of b ends with, do not exist there: they come from the accumulator below) */
+  const uint32_t src_bytes = crc_len_of(j) ? j->crc_pos : segbytes, last_dw = (a0 + src_bytes + 3u) >> 2;
   uint32_t g_lo[5], g_hi[5], g_et[5], g_rp = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) {
     const uint32_t w = (uint32_t)tid + (uint32_t)k * (uint32_t)nt;
     g_lo[k] = g_hi[k] = g_et[k] = 0;
     if (w < ndw) {
-      g_lo[k] = src32[w];
-      g_hi[k] = src32[w + 1];
+      if (w < last_dw)
+        g_lo[k] = src32[w];
+      if (w + 1 < last_dw)
+        g_hi[k] = src32[w + 1];
     }
     if (w < (uint32_t)code->nedges)
       g_et[k] = code->enc_et[w];
@@ -376,7 +400,7 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
       L.ET[w] = g_et[k];
   }
   for (uint32_t w = (uint32_t)tid + 5u * (uint32_t)nt; w < ndw; w += nt) { /* (workgroups of fewer than 64 threads: never) */
-    uint32_t v = __builtin_amdgcn_alignbyte(src32[w + 1], src32[w], a0);
+    uint32_t v = __builtin_amdgcn_alignbyte(w + 1 < last_dw ? src32[w + 1] : 0u, w < last_dw ? src32[w] : 0u, a0);
     for (int b = 0; b < 4; b++) {
       const uint32_t q = 4u * w + (uint32_t)b, kk = q - crc_pos;
       if (kk < crc_len)
@@ -404,8 +428,6 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
       L.LB[i] = 0u;
   }
   __syncthreads();
-  if (crc_len && tid == 0)
-    acc[j->tb] = 0; /* (every thread has its copy by now) */
   TB_TLOG();
   if (with_crc) {
     /* CB CRC24B over the segment's bytes in LDS: a thread runs the byte-table recurrence of crc_byte.c:184-218 over its
@@ -434,6 +456,28 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
     __syncthreads();
   }
   TB_TLOG();
+  if (ldpc_encp32_applies(code)) {
+    /* Zc % 32 == 0 (ldpc_enc_packed32.h): the information columns are the segment's dwords with byte and bit order reversed,
+     * every produced word goes straight into its periodic string -- no extension phases, three barriers fewer */
+    const ldpc_encp32 g32 = ldpc_encp32_make(code, ej->Kb);
+    const uint32_t nd = (uint32_t)(g32.kbf * g32.W);
+    for (uint32_t i = (uint32_t)tid; i < nd; i += nt)
+      ldpc_encp32_info(L, g32, i, reinterpret_cast<const uint32_t *>(c)[i]);
+    __syncthreads();
+    TB_TLOG();
+    TB_TLOG();
+    ldpc_encp32_lambda(L, g32, tid, nt);
+    __syncthreads();
+    TB_TLOG();
+    TB_TLOG();
+    if (tid < 64)
+      ldpc_encp32_core_parity_wave(code, L, g32, tid);
+    __syncthreads();
+    TB_TLOG();
+    ldpc_encp32_extension(code, L, g32, tid, nt);
+    __syncthreads();
+    TB_TLOG();
+  } else {
   {
     /* the rest of the encoder's phase 0: information columns from the MSB-first bytes */
     const int kbf = code->kb_full, W = ldpc_encp_W(Z), bs = W + 1, nin = (kbf * Z + 7) >> 3;
@@ -463,6 +507,7 @@ __global__ void __launch_bounds__(512, 8) tb_tx_fused_kernel(const tb_tx_seg_job
   ldpc_encp_phase(12, code, ej->Kb, c, L, nullptr, tid, nt);
   __syncthreads();
   TB_TLOG();
+  }
   /* Bit selection + interleaving (nr_rate_matching.c:424-501, :240-303): f[i + jj*Qm] = e[i*E/Qm + jj],
    * e[k] = d[position of rank (rank0 + k) mod V], d[p] = code word bit p + 2Z.  In two steps per chunk of TB_TX_SEL_SYMS
    * modulation symbols: (1) the Qm sub-streams e[i*E/Qm + jj0 ..] are packed into LDS, 32 bits per item, gathered from
@@ -623,7 +668,8 @@ hipError_t tb_launch_tx_crc(const tb_tx_tb_job *jobs, uint32_t n_tb, const tb_cr
 {
   if (n_tb == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(tb_tx_crc_partial_kernel, dim3(n_chunks), dim3(TB_THREADS), 0, s, jobs, chunks, payload, scratch, acc, pow24a, pow16);
+  hipLaunchKernelGGL(tb_tx_crc_partial_kernel, dim3(n_chunks), dim3(TB_THREADS), 0, s, jobs, chunks, payload, scratch, acc, pow24a, pow16,
+                     with_final /* the unfused path reads b; the fused segment kernel reads the payload */);
   if (with_final)
     hipLaunchKernelGGL(tb_tx_crc_final_kernel, dim3((n_tb + TB_THREADS - 1) / TB_THREADS), dim3(TB_THREADS), 0, s, jobs, n_tb, scratch, acc);
   return hipGetLastError();

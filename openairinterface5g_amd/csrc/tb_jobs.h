@@ -40,6 +40,9 @@ struct tb_tx_seg_job {     /* one per code block */
   /* fused kernel, segment that carries the TB CRC (the last one): crc_pos = byte of the segment where the CRC starts,
    * crc_len = 3 (CRC24A) / 2 (CRC16); crc_len = 0: no TB CRC bytes in this segment */
   uint32_t crc_pos, crc_len;
+  /* ... whose value that segment's workgroup puts together itself: the XOR of the partial registers the CRC kernel's
+   * workgroups crc_chunk0 .. crc_chunk0 + crc_nchunks - 1 left (one plain store each: no atomics, nothing to reset) */
+  uint32_t crc_chunk0, crc_nchunks;
   uint32_t pad;
 };
 struct tb_rx_seg_job {
