@@ -12,10 +12,12 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nrLDPC_hip.h"
@@ -453,6 +455,132 @@ bool host_ptr_is_pinned(const void *p, size_t bytes = 1)
   return true;
 }
 
+/* The CPU side of the pageable-array policy (tb_api.inc.cpp TbCtx): large bounce copies are cut over a few helper threads --
+ * one memcpy stream moves 8-10 GB/s, the link 50+, and a slot with host soft buffers bounces 84-170 MB per call.  The pool is
+ * created on first use (NRLDPC_HIP_BOUNCE_THREADS helpers, default min(8, hardware threads / 2); 0 / 1: the caller copies
+ * alone), shared by all calling threads (one job at a time) and torn down at exit. */
+struct BouncePool {
+  struct Job { uint8_t *dst; const uint8_t *src; size_t width, rows, dpitch, spitch; };
+  std::mutex use, mu;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> workers;
+  Job job{};
+  size_t next_row = 0, chunk_rows = 1;
+  int pending = 0;
+  uint64_t generation = 0;
+  bool quit = false;
+  int n_threads = -1;
+  static void copy_rows(const Job &j, size_t r0, size_t r1)
+  {
+    if (j.width == j.dpitch && j.width == j.spitch) {
+      memcpy(j.dst + r0 * j.dpitch, j.src + r0 * j.spitch, (r1 - r0) * j.width);
+      return;
+    }
+    for (size_t r = r0; r < r1; r++)
+      memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
+  }
+  void work()
+  {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_go.wait(lk, [&] { return quit || generation != seen; });
+      if (quit)
+        return;
+      seen = generation;
+      while (next_row < job.rows) {
+        const size_t r0 = next_row, r1 = std::min(job.rows, r0 + chunk_rows);
+        next_row = r1;
+        lk.unlock();
+        copy_rows(job, r0, r1);
+        lk.lock();
+      }
+      if (--pending == 0)
+        cv_done.notify_all();
+    }
+  }
+  void run(uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t width, size_t rows)
+  {
+    Job j{dst, src, width, rows, dpitch, spitch};
+    const size_t bytes = width * rows;
+    if (n_threads < 0) {
+      std::lock_guard<std::mutex> lk(use);
+      if (n_threads < 0) {
+        const char *e = getenv("NRLDPC_HIP_BOUNCE_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        int n = e ? atoi(e) : (int)std::min<unsigned>(8, hw / 2);
+        n = n < 2 ? 0 : std::min(n, 32);
+        for (int i = 0; i < n; i++)
+          workers.emplace_back([this] { work(); });
+        n_threads = n;
+      }
+    }
+    if (n_threads == 0 || bytes < ((size_t)2 << 20)) {
+      copy_rows(j, 0, rows);
+      return;
+    }
+    /* a contiguous block is cut into pieces of >= 256 KB, a strided one into runs of rows of about 512 KB */
+    size_t tail = 0, per_draw = 1;
+    if (width == dpitch && width == spitch) {
+      const size_t piece = std::max<size_t>((size_t)256 << 10, (bytes / (4 * (size_t)(n_threads + 1))) & ~(size_t)63);
+      j = Job{dst, src, piece, bytes / piece, piece, piece};
+      tail = bytes - j.rows * piece;
+    } else {
+      per_draw = std::max<size_t>(1, ((size_t)512 << 10) / width);
+    }
+    {
+      std::lock_guard<std::mutex> one(use);
+      std::unique_lock<std::mutex> lk(mu);
+      job = j;
+      next_row = 0;
+      chunk_rows = per_draw;
+      pending = n_threads;
+      generation++;
+      cv_go.notify_all();
+      while (next_row < job.rows) { /* the calling thread works too */
+        const size_t r0 = next_row, r1 = std::min(job.rows, r0 + chunk_rows);
+        next_row = r1;
+        lk.unlock();
+        copy_rows(job, r0, r1);
+        lk.lock();
+      }
+      cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    if (tail)
+      memcpy(dst + (bytes - tail), src + (bytes - tail), tail);
+  }
+  ~BouncePool()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv_go.notify_all();
+    }
+    for (std::thread &t : workers)
+      t.join();
+  }
+};
+BouncePool &bounce_pool()
+{
+  static BouncePool p;
+  return p;
+}
+/* dst / src: `rows` rows of `width` bytes, dpitch / spitch apart (rows == 1: one block) */
+void bounce_copy(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows)
+{
+  if (width && rows)
+    bounce_pool().run(static_cast<uint8_t *>(dst), dpitch, static_cast<const uint8_t *>(src), spitch, width, rows);
+}
+/* NRLDPC_HIP_PAGEABLE_DIRECT=1 -- CONTROL ARM of the soak in profiles/r05 only: pageable arrays are handed to hipMemcpy*Async
+ * again, as before 6dd81de (the arrangement that took a GPU memory fault in one test-suite run in ten) */
+bool pageable_direct()
+{
+  static const bool v = [] { const char *e = getenv("NRLDPC_HIP_PAGEABLE_DIRECT"); return e && atoi(e) != 0; }();
+  return v;
+}
+/* does the transport-block chain have to bounce this host array through page-locked memory? */
+bool needs_bounce(const void *p, size_t bytes);
+
 /* [p, p + bytes) is page-locked at one end only: the HIP runtime refuses copies out of such a range (it takes the array for
  * the registered piece), so the entry points that take host arrays say so instead of failing somewhere inside */
 bool host_range_is_partly_pinned(const void *p, size_t bytes)
@@ -461,6 +589,8 @@ bool host_range_is_partly_pinned(const void *p, size_t bytes)
     return false;
   return host_ptr_is_pinned(p) != host_ptr_is_pinned(static_cast<const uint8_t *>(p) + bytes - 1);
 }
+
+bool needs_bounce(const void *p, size_t bytes) { return !pageable_direct() && !host_ptr_is_pinned(p, bytes); }
 
 /* kernel choice: 0 = best available, 1 = generic, 2 = fast (error when the code / buffers do not allow it), with the
  * workgroup shape picked from the launch size; 3 / 4 = fast kernel, throughput / latency shape forced (tests, tuning) */

@@ -172,16 +172,40 @@ struct TbCtx {
    * Handing pageable memory to hipMemcpy*Async makes the runtime page-lock the caller's pages behind the scenes, and a
    * process that allocates and frees such arrays call after call eventually took a GPU memory fault inside a soft-buffer
    * copy -- once in ten runs of the test suite, all kernels of the call already finished (profiles/r04/README.md). */
-  struct FinCopy { uint8_t *dst; const uint8_t *src; size_t width, rows, dpitch, spitch; };
+  /* ev: the event behind the device -> mirror copy this hand-over waits for (nullptr: the caller has drained the stream).  The
+   * soft-buffer rows of a large call come down in runs of ~8 MB with an event behind each, so that the CPU hands run k over
+   * -- bounce_copy(): a few threads -- while the link brings run k + 1 (profiles/r05/slot_chain_host.json). */
+  struct FinCopy { uint8_t *dst; const uint8_t *src; size_t width, rows, dpitch, spitch; hipEvent_t ev; };
   std::vector<FinCopy> fin_copies;
+  std::vector<hipEvent_t> fin_ev; /* pool of events for the runs; fin_ev_used of them belong to the call in flight */
+  size_t fin_ev_used = 0;
   size_t harq_h_used = 0; /* bytes of harq_h the pieces of the call in flight have taken (a call may come in several pieces) */
-  void finish_copies()
+  hipEvent_t next_fin_event()
+  {
+    if (fin_ev_used == fin_ev.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+      fin_ev.push_back(e);
+    }
+    return fin_ev[fin_ev_used++];
+  }
+  void finish_copies(bool drained) /* drained: the caller has waited for the stream already */
   {
     harq_h_used = 0;
-    for (const FinCopy &f : fin_copies)
-      for (size_t r = 0; r < f.rows; r++)
-        memcpy(f.dst + r * f.dpitch, f.src + r * f.spitch, f.width);
+    hipEvent_t waited = nullptr;
+    for (const FinCopy &f : fin_copies) {
+      if (f.ev && f.ev != waited && !drained) {
+        (void)hipEventSynchronize(f.ev);
+        waited = f.ev;
+      } else if (!f.ev && !drained) {
+        (void)hipStreamSynchronize(own);
+        drained = true;
+      }
+      bounce_copy(f.dst, f.dpitch, f.src, f.spitch, f.width, f.rows);
+    }
     fin_copies.clear();
+    fin_ev_used = 0;
   }
   /* the host-buffer decode in flight: what tb_rx_finish has to hand over from payload_h (0 bytes: the kernels wrote the
    * caller's page-locked array themselves) */
@@ -208,6 +232,7 @@ struct TbCtx {
       (void)hipStreamSynchronize(own);
     pending = false;
     fin_copies.clear();
+    fin_ev_used = 0;
     harq_h_used = 0;
   }
 };
@@ -512,10 +537,10 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     if (c.io_payload.ensure(pay_n) != 0 || c.io_coded.ensure(cod_n) != 0)
       return -1;
     const uint8_t *pay_src = b->payload + pay_lo;
-    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && !host_ptr_is_pinned(pay_src, pay_n)) { /* pageable: bounced (TbCtx::fin_copies) */
+    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && needs_bounce(pay_src, pay_n)) { /* pageable: bounced (TbCtx::fin_copies) */
       if (c.payload_h.ensure(pay_n) != 0)
         return -1;
-      memcpy(c.payload_h.p, pay_src, pay_n);
+      bounce_copy(c.payload_h.p, pay_n, pay_src, pay_n, pay_n, 1);
       pay_src = c.payload_h.p;
     }
     HIP_TRY(hipMemcpyAsync(c.io_payload.p, pay_src, pay_n, hipMemcpyDefault, s));
@@ -552,15 +577,15 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     uint8_t *hc = static_cast<uint8_t *>(b->coded);
     const size_t cod_lo = pl.ext[2], cod_n = pl.ext[3] - pl.ext[2];
     uint8_t *out = hc; /* where the copies go: the caller's array, or (pageable array) this thread's page-locked mirror of it */
-    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && !host_ptr_is_pinned(hc + cod_lo, cod_n)) {
+    if (!(b->mem & NRLDPC_HIP_MEM_DEVICE) && needs_bounce(hc + cod_lo, cod_n)) {
       if (c.coded_h.ensure(cod_n) != 0)
         return -1;
       out = c.coded_h.p - cod_lo;
       if (pl.out_dense) {
-        c.fin_copies.push_back(TbCtx::FinCopy{hc + cod_lo, c.coded_h.p, cod_n, 1, 0, 0});
+        c.fin_copies.push_back(TbCtx::FinCopy{hc + cod_lo, c.coded_h.p, cod_n, 1, 0, 0, nullptr});
       } else {
         for (const TbPlan::OutRun &r : pl.out_runs)
-          c.fin_copies.push_back(TbCtx::FinCopy{hc + r.first, out + r.first, r.width, r.rows, r.pitch, r.pitch});
+          c.fin_copies.push_back(TbCtx::FinCopy{hc + r.first, out + r.first, r.width, r.rows, r.pitch, r.pitch, nullptr});
       }
     }
     if (pl.out_dense) {
@@ -579,7 +604,7 @@ int tb_tx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t ntb)
     return 0;
   TbCtx &c = tls_tb;
   HIP_TRY(hipStreamSynchronize(c.own));
-  c.finish_copies();
+  c.finish_copies(true);
   return 0;
 }
 
@@ -1050,10 +1075,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         if (c.io_coded.ensure(cod_n * 2) != 0)
           return -1;
         const void *cod_src = static_cast<const int16_t *>(b->coded) + cod_lo;
-        if (to_host && !host_ptr_is_pinned(cod_src, cod_n * 2)) { /* pageable: bounced (TbCtx::fin_copies) */
+        if (to_host && needs_bounce(cod_src, cod_n * 2)) { /* pageable: bounced (TbCtx::fin_copies) */
           if (c.coded_h.ensure(cod_n * 2) != 0)
             return -1;
-          memcpy(c.coded_h.p, cod_src, cod_n * 2);
+          bounce_copy(c.coded_h.p, cod_n * 2, cod_src, cod_n * 2, cod_n * 2, 1);
           cod_src = c.coded_h.p;
         }
         HIP_TRY(hipMemcpyAsync(c.io_coded.p, cod_src, cod_n * 2, hipMemcpyDefault, s));
@@ -1069,7 +1094,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       /* ... and only a HOST array is: device soft buffers of another GPU (a call cut over several GPUs, this part not the
        * owner's) take the strided copies directly -- peer copies --, the CPU must never touch them */
       const bool harq_is_host = !(b->mem & (NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_DEVICE));
-      harq_bounce = to_host && harq_is_host && !host_ptr_is_pinned(b->harq + harq_lo, harq_n * 2);
+      harq_bounce = to_host && harq_is_host && needs_bounce(b->harq + harq_lo, harq_n * 2);
       if (harq_bounce) { /* this piece's share of the mirror (growing it parks the old area: earlier pieces keep theirs) */
         const size_t at = align_up(c.harq_h_used, 64);
         if (c.harq_h.ensure(at + harq_n * 2) != 0)
@@ -1080,11 +1105,16 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       const int16_t *harq_src = harq_bounce ? reinterpret_cast<const int16_t *>(harq_mirror) - harq_lo : b->harq;
       for (const TbPlan::HarqRun &r : pl.harq_runs)
         if (r.upload) {
-          if (harq_bounce)
-            for (uint32_t q = 0; q < r.rows; q++)
-              memcpy(harq_mirror + (r.first - harq_lo) * 2 + q * stride2, b->harq + r.first + (size_t)q * b->harq_stride, (size_t)r.width * 2);
-          HIP_TRY(hipMemcpy2DAsync(c.io_harq.p + (r.first - harq_lo) * 2, stride2, harq_src + r.first, stride2, (size_t)r.width * 2, r.rows,
-                                   hipMemcpyDefault, s));
+          /* a bounced run goes up in pieces of ~8 MB: the CPU fills the mirror for piece k + 1 while the link takes piece k */
+          const uint32_t step = harq_bounce ? std::max<uint32_t>(1, (uint32_t)(((size_t)8 << 20) / ((size_t)r.width * 2))) : r.rows;
+          for (uint32_t q0 = 0; q0 < r.rows; q0 += step) {
+            const uint32_t nq = std::min(step, r.rows - q0);
+            const size_t first = r.first + (size_t)q0 * b->harq_stride;
+            if (harq_bounce)
+              bounce_copy(harq_mirror + (first - harq_lo) * 2, stride2, b->harq + first, stride2, (size_t)r.width * 2, nq);
+            HIP_TRY(hipMemcpy2DAsync(c.io_harq.p + (first - harq_lo) * 2, stride2, harq_src + first, stride2, (size_t)r.width * 2, nq,
+                                     hipMemcpyDefault, s));
+          }
         }
       harq = reinterpret_cast<int16_t *>(c.io_harq.p) - harq_lo;
     }
@@ -1103,7 +1133,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
        * memory makes the host wait for the piece before it can enqueue the next one; and letting the kernels store the
        * payload bytes over the link themselves was measured at 48 ms per slot: 4-byte writes, each one waited for.) */
       const size_t lo = st ? st->pay_lo : pay_lo, n = st ? st->pay_hi - st->pay_lo : pay_n;
-      if (host_ptr_is_pinned(b->payload + lo, n)) {
+      if (!needs_bounce(b->payload + lo, n)) {
         c.fin_pay_n = 0;
       } else {
         (void)hipGetLastError();
@@ -1258,11 +1288,21 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     }
     if (harq_staged)
       for (const TbPlan::HarqRun &r : pl.harq_runs) {
-        uint8_t *dst = harq_bounce ? harq_mirror + (r.first - pl.ext[4]) * 2 : reinterpret_cast<uint8_t *>(b->harq + r.first);
-        HIP_TRY(hipMemcpy2DAsync(dst, stride2, c.io_harq.p + (r.first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, r.rows,
-                                 hipMemcpyDefault, s));
-        if (harq_bounce)
-          c.fin_copies.push_back(TbCtx::FinCopy{reinterpret_cast<uint8_t *>(b->harq + r.first), dst, (size_t)r.width * 2, r.rows, stride2, stride2});
+        /* a bounced run comes down in pieces of ~8 MB with an event behind each: tb_rx_finish hands piece k over to the
+         * caller's array while piece k + 1 is on the link (TbCtx::finish_copies) */
+        const uint32_t step = harq_bounce ? std::max<uint32_t>(1, (uint32_t)(((size_t)8 << 20) / ((size_t)r.width * 2))) : r.rows;
+        for (uint32_t q0 = 0; q0 < r.rows; q0 += step) {
+          const uint32_t nq = std::min(step, r.rows - q0);
+          const size_t first = r.first + (size_t)q0 * b->harq_stride;
+          uint8_t *dst = harq_bounce ? harq_mirror + (first - pl.ext[4]) * 2 : reinterpret_cast<uint8_t *>(b->harq + first);
+          HIP_TRY(hipMemcpy2DAsync(dst, stride2, c.io_harq.p + (first - pl.ext[4]) * 2, stride2, (size_t)r.width * 2, nq, hipMemcpyDefault, s));
+          if (harq_bounce) {
+            hipEvent_t ev = c.next_fin_event();
+            if (ev)
+              HIP_TRY(hipEventRecord(ev, s));
+            c.fin_copies.push_back(TbCtx::FinCopy{reinterpret_cast<uint8_t *>(b->harq + first), dst, (size_t)r.width * 2, nq, stride2, stride2, ev});
+          }
+        }
       }
     if (!to_host) { /* a peer GPU's share of a device-resident batch: the verdicts go to the owner's arrays */
       HIP_TRY(hipMemcpyAsync(b->iter_max + tb0, c.io_small.p, (size_t)ntb * 4, hipMemcpyDefault, s));
@@ -1277,6 +1317,7 @@ int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
   if ((b->mem & NRLDPC_HIP_MEM_DEVICE) || ntb == 0)
     return 0;
   TbCtx &c = tls_tb;
+  c.finish_copies(false); /* first: it waits run by run and copies while the later runs are still on the link */
   HIP_TRY(hipStreamSynchronize(c.own));
   memcpy(b->iter_max + tb0, c.small_h.p, (size_t)ntb * 4); /* (written by the kernels: the area is device-mapped) */
   memcpy(b->ack + tb0, c.small_h.p + (size_t)ntb * 4, ntb);
@@ -1285,7 +1326,6 @@ int tb_rx_finish(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb)
       memcpy(b->payload + b->tb[i].payload_off, c.payload_h.p + (b->tb[i].payload_off - c.fin_pay_lo), b->tb[i].A / 8);
     c.fin_pay_n = 0;
   }
-  c.finish_copies();
   return 0;
 }
 
@@ -1376,8 +1416,8 @@ int tb_rx_enqueue_host(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t nt
     }
     if (e > a) {
       const void *from = src + a;
-      if (!pinned) {
-        memcpy(c.coded_h.p + (a - lo) * 2, from, (e - a) * 2);
+      if (!pinned && !pageable_direct()) {
+        bounce_copy(c.coded_h.p + (a - lo) * 2, (e - a) * 2, from, (e - a) * 2, (e - a) * 2, 1);
         from = c.coded_h.p + (a - lo) * 2;
       }
       HIP_TRY(hipMemcpyAsync(c.io_coded.p + (a - lo) * 2, from, (e - a) * 2, hipMemcpyHostToDevice, c.aux));

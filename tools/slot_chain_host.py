@@ -106,9 +106,13 @@ def run(n, out):
                 srcs.append(k)
             else:
                 srcs.append(llr_d.cpu().numpy().copy())
-        for where in ("host", "device", "library"):
+        for where in ("host", "host_registered", "device", "library"):
             if where == "host":
                 harq, mem, kw = np.zeros(int(ho[n]) + 16, np.int16), m.MEM_HOST, {}
+            elif where == "host_registered":   # the caller page-locks its persistent d[r] once (nrLDPC_hip_host_register / _alloc)
+                keep_harq = m.PinnedArray(int(ho[n]) + 16, np.int16)
+                keep_harq.a[:] = 0
+                harq, mem, kw = keep_harq.a, m.MEM_HOST, {}
             elif where == "device":
                 harq, mem, kw = torch.zeros(int(ho[n]) + 16, dtype=torch.int16, device="cuda"), m.MEM_HOST | m.MEM_HARQ_DEVICE, {}
             else:
@@ -119,8 +123,8 @@ def run(n, out):
             ok0 = bool(ack_h.all())
             r["round1_ms"] = timed(b1.decode, reps)
             r["all_ack"] = ok0 and bool(ack_h.all())
-            moved0 = llr_bytes + (harq_bytes if where == "host" else 0)        # round 0: soft buffers come back only
-            moved1 = llr_bytes + (2 * harq_bytes if where == "host" else 0)
+            moved0 = llr_bytes + (harq_bytes if where.startswith("host") else 0)        # round 0: soft buffers come back only
+            moved1 = llr_bytes + (2 * harq_bytes if where.startswith("host") else 0)
             r["link_MB_round0"], r["link_MB_round1"] = moved0 / 1e6, moved1 / 1e6
             r["llr_rate_GBps_round0"] = llr_bytes / r["round0_ms"] / 1e6
             r["frac_of_link_round0"] = (moved0 / r["round0_ms"] / 1e6) / out["link_GBps"]
