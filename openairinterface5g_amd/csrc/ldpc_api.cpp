@@ -713,7 +713,7 @@ extern "C" {
 
 int nrLDPC_hip_check_crc(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type) { return nr_hip_check_crc(decoded_bytes, n, crc_type); }
 const char *nrLDPC_hip_last_error(void) { return tls_error.c_str(); }
-const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.4 (gfx950)"; }
+const char *nrLDPC_hip_version(void) { return "libldpc_hip 0.5 (gfx950)"; }
 
 /* Optional hook of the reference's module loader (common/utils/load_module_shlib.c:174-185: "<modname>_checkbuildver",
  * modname = "ldpc" whatever the version suffix of the file name, nrLDPC_load.c:48,62): called right after
@@ -729,7 +729,7 @@ int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversio
 /* the same under a name that does not clash with the loader's hook: libldpc_hip_t2.so forwards its own ldpc_checkbuildver here */
 int32_t nrLDPC_hip_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion)
 {
-  static char version[] = "libldpc_hip 0.4 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
+  static char version[] = "libldpc_hip 0.5 (gfx950; plugin ABI of openairinterface5g v2.1.0: nrLDPC_defs.h:40-87, nrLDPC_types.h:75-127)";
   if (shlib_buildversion)
     *shlib_buildversion = version;
   const char *need = getenv("NRLDPC_HIP_REQUIRE_BUILD");

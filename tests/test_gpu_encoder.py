@@ -137,3 +137,25 @@ def test_reference_compiled_code_words(hip):
         outs = hip.LDPCencoder([v["info"] for v in vs], BG, Z, n_segments=len(vs), macro_num=0)
         for v, o in zip(vs, outs):
             assert np.array_equal(o, v["coded"]), (BG, Z)
+
+
+def test_unaligned_buffers_on_the_word_aligned_codes(hip):
+    """Zc % 32 == 0 has a path of its own (ldpc_enc_packed32.h) that wants 4-byte aligned input rows and 16-byte aligned
+    output rows; anything else must fall back to the general path and give the same code words (rows at odd addresses and
+    odd pitches, device buffers)."""
+    import torch
+    rng = np.random.default_rng(123)
+    for BG, Z in ((1, 384), (2, 64), (1, 32), (2, 256)):
+        K, N = kbits(BG, Z), (66 if BG == 1 else 50) * Z
+        n = 6
+        info = rng.integers(0, 256, (n, K // 8), dtype=np.uint8)
+        ref = np.stack([O.encode(BG, Z, info[i]) for i in range(n)])
+        for in_off, out_off in ((0, 0), (1, 0), (0, 4), (3, 5), (2, 16)):
+            buf_in = torch.zeros((n, K // 8 + 8 + in_off), dtype=torch.uint8, device="cuda")
+            buf_in[:, in_off:in_off + K // 8] = torch.from_numpy(info).cuda()
+            buf_out = torch.full((n, N + 32 + out_off), 7, dtype=torch.uint8, device="cuda")
+            hip.encode_batch_device(BG, Z, buf_in[:, in_off:], buf_out[:, out_off:])
+            torch.cuda.synchronize()
+            got = buf_out.cpu().numpy()
+            assert np.array_equal(got[:, out_off:out_off + N], ref), (BG, Z, in_off, out_off)
+            assert (got[:, :out_off] == 7).all() and (got[:, out_off + N:] == 7).all()       # nothing outside the rows
