@@ -148,8 +148,10 @@ def test_fused_segment_kernel_against_the_four_launch_path(hip):
 
 def test_first_transmissions_never_upload_host_soft_buffers(hip):
     """Host-resident soft buffers (the legacy layout): a call whose blocks are all first transmissions uploads nothing of
-    them -- they are cleared on the device -- and brings back exactly the Ncb values per segment it produced: what lies
-    behind them in the caller's rows (limited-buffer rate matching: Ncb < the row) is not touched, whatever it held."""
+    them -- they are cleared on the device -- and brings back max(Ncb, positions the decoder reads) values per segment: the
+    Ncb soft values it produced and, with limited-buffer rate matching (Ncb < N), ZEROS in [Ncb, np) -- the reference memsets
+    Ncb entries only (nr_rate_matching.c:554-555) and its decoder input reads what its calloc'ed buffer holds behind them,
+    which is zero as well.  What lies behind the circular buffer's N positions is never touched."""
     m = hip.ldpc
     rng = np.random.default_rng(5)
     tbs = [dict(t, rv=0) for t in make_tbs() if t["tbslbrm"]] + make_tbs()[:3]
@@ -172,6 +174,9 @@ def test_first_transmissions_never_upload_host_soft_buffers(hip):
         ncb = N if not t["tbslbrm"] else min(N, 3 * t["tbslbrm"] // (2 * s["C"]))
         for r in range(segs[i]):
             assert np.array_equal(harq[row + r, :ncb], href[r][:ncb]), (i, r)
+            tail = harq[row + r, ncb:N]                                                # [Ncb, N): zeros up to the decoder's reach, else untouched
+            nz = int(np.argmax(tail != 0)) if (tail != 0).any() else tail.size
+            assert not tail[:nz].any() and np.array_equal(tail[nz:], before[row + r, ncb + nz:N]), (i, r)
             assert np.array_equal(harq[row + r, N:], before[row + r, N:]), (i, r)       # behind the circular buffer: never touched
         row += segs[i]
 
