@@ -128,18 +128,23 @@ struct tb_rx_fused_io {
      * flags[4], flags[5] are zero since the block's prologue) */
     if (lane == 0 && xr)
       atomicXor(reinterpret_cast<unsigned int *>(&flags[2]), xr);
+    /* the count that decides who collects the block is asked for NOW: its round trip runs under the drain of the payload
+     * stores instead of behind it (nothing depends on the order: the collector waits for every slot's generation anyway, and
+     * a slot is only written below, behind the drain) */
+    int before = 0;
+    if (tid == 0)
+      before = __hip_atomic_fetch_add(&x.done[tbi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tb_wait_stores(); /* this thread's payload bytes have left for memory */
     __syncthreads();
     /* What the block's last segment needs of this one travels in ONE 8-byte store -- {CRC share, pass count, the block's
      * generation} -- and nothing orders it against the count below: the last segment reads the slots until every one carries
      * the current generation.  (A slot that shows the generation also says that the segment's payload bytes are in memory:
-     * they were waited for above.)  So a segment's epilogue costs one atomic's round trip, not two. */
+     * they were waited for above.)  So a segment's epilogue costs one memory round trip behind its stores, not three. */
     const uint32_t gen = gen_prev + 1u;
     if (tid == 0) {
       const unsigned long long slot = (unsigned long long)(ok ? (uint32_t)flags[2] : 0u) |
                                       ((unsigned long long)(((uint32_t)n_iter & 0xffffu) | (gen << 16)) << 32);
       __hip_atomic_store(&x.slots[job->seg_idx], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int before = __hip_atomic_fetch_add(&x.done[tbi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (before == (int)C - 1)
         flags[4] = 1;
     }
