@@ -469,7 +469,7 @@ struct BouncePool {
   int pending = 0;
   uint64_t generation = 0;
   bool quit = false;
-  int n_threads = -1;
+  std::atomic<int> n_threads{-1}; /* -1: pool not set up yet (set once, under `use`) */
   static void copy_rows(const Job &j, size_t r0, size_t r1)
   {
     if (j.width == j.dpitch && j.width == j.spitch) {
@@ -503,26 +503,27 @@ struct BouncePool {
   {
     Job j{dst, src, width, rows, dpitch, spitch};
     const size_t bytes = width * rows;
-    if (n_threads < 0) {
+    if (n_threads.load(std::memory_order_acquire) < 0) {
       std::lock_guard<std::mutex> lk(use);
-      if (n_threads < 0) {
+      if (n_threads.load(std::memory_order_relaxed) < 0) {
         const char *e = getenv("NRLDPC_HIP_BOUNCE_THREADS");
         const unsigned hw = std::thread::hardware_concurrency();
         int n = e ? atoi(e) : (int)std::min<unsigned>(8, hw / 2);
         n = n < 2 ? 0 : std::min(n, 32);
         for (int i = 0; i < n; i++)
           workers.emplace_back([this] { work(); });
-        n_threads = n;
+        n_threads.store(n, std::memory_order_release);
       }
     }
-    if (n_threads == 0 || bytes < ((size_t)2 << 20)) {
+    const int nthr = n_threads.load(std::memory_order_relaxed);
+    if (nthr == 0 || bytes < ((size_t)2 << 20)) {
       copy_rows(j, 0, rows);
       return;
     }
     /* a contiguous block is cut into pieces of >= 256 KB, a strided one into runs of rows of about 512 KB */
     size_t tail = 0, per_draw = 1;
     if (width == dpitch && width == spitch) {
-      const size_t piece = std::max<size_t>((size_t)256 << 10, (bytes / (4 * (size_t)(n_threads + 1))) & ~(size_t)63);
+      const size_t piece = std::max<size_t>((size_t)256 << 10, (bytes / (4 * (size_t)(nthr + 1))) & ~(size_t)63);
       j = Job{dst, src, piece, bytes / piece, piece, piece};
       tail = bytes - j.rows * piece;
     } else {
@@ -534,7 +535,7 @@ struct BouncePool {
       job = j;
       next_row = 0;
       chunk_rows = per_draw;
-      pending = n_threads;
+      pending = nthr;
       generation++;
       cv_go.notify_all();
       while (next_row < job.rows) { /* the calling thread works too */
