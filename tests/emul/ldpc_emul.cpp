@@ -153,6 +153,57 @@ extern "C" int ldpc_emul_encode_packed(int BG, int Zc, int Kb, const uint8_t *in
   return (code->ncols - 2) * Zc;
 }
 
+/* ---- the same kernel's path for Zc % 32 == 0 (ldpc_enc_packed32.h): the per-lane phases as the kernel calls them, one
+ * thread at a time; the DPP meeting of a lambda item's four slices and the wave-level order of the two core parity steps
+ * are loops here.  -2: the code does not take this path. */
+#include "../../openairinterface5g_amd/csrc/ldpc_enc_packed32.h"
+
+extern "C" int ldpc_emul_encode_packed32(int BG, int Zc, int Kb, const uint8_t *in, uint8_t *out, int nt)
+{
+  ldpc_code_desc_t code_s;
+  if (ldpc_build_code_desc(BG, Zc, BG == 1 ? 13 : 15, &code_s) != 0)
+    return -1;
+  const ldpc_code_desc_t *code = &code_s;
+  if (!ldpc_encp32_applies(code))
+    return -2;
+  std::vector<uint32_t> lds(ldpc_encp_lds_words(code->ncols, code->kb_full, Zc, code->nrows, code->nedges), 0x5a5a5a5au);
+  ldpc_encp_lds L;
+  ldpc_encp_carve(lds.data(), code, L);
+  if (nt <= 0)
+    nt = ldpc_encp_threads(code->nrows, Zc);
+  const ldpc_encp32 g = ldpc_encp32_make(code, Kb);
+  const uint32_t nd = (uint32_t)(g.kbf * g.W);
+  std::vector<uint32_t> in32(nd);
+  memcpy(in32.data(), in, (size_t)nd * 4);
+  /* loads -> LDS (ldpc_enc_packed_kernel's first stage) */
+  for (uint32_t i = 0; i < nd; i++)
+    ldpc_encp32_info(L, g, i, in32[i]);
+  for (int e = 0; e < code->nedges; e++)
+    L.ET[e] = code->enc_et[e];
+  for (int r = 0; r <= code->nrows; r++)
+    L.RP[r] = (uint32_t)code->row_ptr[r];
+  /* lambda: items of four lanes */
+  for (int i = 0; i < 16 * g.W; i += 4) {
+    uint32_t acc = 0;
+    for (int sl = 0; sl < 4; sl++)
+      acc ^= ldpc_encp32_lambda_partial(L, g, i + sl);
+    ldpc_encp32_lambda_store(L, g, i, acc);
+  }
+  /* core parity: one wave, two steps */
+  for (int lane = 0; lane < 64; lane++)
+    ldpc_encp32_core_step_p0(code, L, g, lane);
+  for (int lane = 0; lane < 64; lane++)
+    ldpc_encp32_core_step_rest(code, L, g, lane);
+  for (int tid = 0; tid < nt; tid++)
+    ldpc_encp32_extension(code, L, g, tid, nt);
+  std::vector<uint8_t> o2((size_t)(code->ncols - 2) * Zc + 32); /* (the stores are 16 bytes wide and want alignment) */
+  uint8_t *oa = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(o2.data()) + 15) & ~(uintptr_t)15);
+  for (int tid = 0; tid < nt; tid++)
+    ldpc_encp32_store_bytes(L, g, oa, 2, code->ncols, tid, nt);
+  memcpy(out, oa, (size_t)(code->ncols - 2) * Zc);
+  return (code->ncols - 2) * Zc;
+}
+
 extern "C" int ldpc_emul_desc(int BG, int Z, int R, ldpc_code_desc_t *d) { return ldpc_build_code_desc(BG, Z, R, d); }
 
 /* ---- fast kernel (ldpc_decoder_fast.hip) ---------------------------------------------------------------- */

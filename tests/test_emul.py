@@ -19,6 +19,7 @@ def emul(built):
         f.argtypes = [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
     L.ldpc_emul_encode.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
     L.ldpc_emul_encode_packed.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
+    L.ldpc_emul_encode_packed32.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int]
     return L
 
 
@@ -78,6 +79,39 @@ def test_encoder_every_code(emul):
                     out[:] = 7
                     n = fn(BG, Z, Kb, info.ctypes.data, out.ctypes.data)
                     assert n == ref.size and np.array_equal(out[:n], ref), (BG, Z, Kb, fn.__name__)
+
+
+def test_encoder_word_aligned_path_on_the_cpu(emul):
+    """ldpc_enc_packed32.h -- what ldpc_enc_packed_kernel and the fused TX kernel run for Zc % 32 == 0 -- one thread at a time on
+    the CPU: every such code, Kb < 10, several workgroup sizes (the extension phase's two-words-per-lane split and the loops'
+    strides depend on it), against the oracle AND against the code words of the reference-compiled encoder
+    (tests/golden/ref_encoder.npz)."""
+    from common import load_ref_code_words
+    rng = np.random.default_rng(32)
+    sizes = [Z for Z in O.LIFT_SIZES if Z % 32 == 0]
+    assert len(sizes) == 12
+    out = np.full(68 * 384 + 64, 7, np.uint8)
+    for BG in (1, 2):
+        for Z in sizes:
+            for Kb in ([22] if BG == 1 else [10, 9, 8, 6]):
+                bits = rng.integers(0, 2, kbits(BG, Z), dtype=np.uint8)
+                bits[Kb * Z:] = 0
+                info = np.packbits(bits)
+                ref = O.encode(BG, Z, info, Kb)
+                for nt in (0, 64, 128, 512):
+                    out[:] = 7
+                    n = emul.ldpc_emul_encode_packed32(BG, Z, Kb, info.ctypes.data, out.ctypes.data, nt)
+                    assert n == ref.size and np.array_equal(out[:n], ref), (BG, Z, Kb, nt)
+                    assert (out[n:] == 7).all()
+    assert emul.ldpc_emul_encode_packed32(1, 36, 22, info.ctypes.data, out.ctypes.data, 0) == -2   # not a word-aligned code
+    n_ref = 0
+    for v in load_ref_code_words():
+        if v["Z"] % 32:
+            continue
+        n = emul.ldpc_emul_encode_packed32(v["BG"], v["Z"], v["Kb"], np.ascontiguousarray(v["info"]).ctypes.data, out.ctypes.data, 0)
+        assert n == v["coded"].size and np.array_equal(out[:n], v["coded"]), (v["BG"], v["Z"], v["Kb"])
+        n_ref += 1
+    assert n_ref >= 48
 
 
 def test_rx_dematch_phases_against_the_oracle(emul):
