@@ -109,10 +109,14 @@ def _tb_worker(rank, world, port, ret):
         dist.broadcast_object_list(box, src=0)
         tbs = box[0]
         sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6)
-        assert sh.cut[0] == 0 and sh.cut[-1] == len(tbs) and 0 < sh.cut[1] < len(tbs)
-        # the peer's range travels and is decoded in three pieces, the root's own range in one
-        assert len(sh.chunk_cut[0]) == 2 and len(sh.chunk_cut[1]) == 4 and sh.chunk_cut[1][0] == sh.cut[1] and sh.chunk_cut[1][-1] == len(tbs)
-        assert sh.chunk_cut[1] == sorted(set(sh.chunk_cut[1]))
+        assert sh.cut[0] == 0 and sh.cut[-1] == len(tbs) and len(sh.cut) == world + 1 and sh.cut == sorted(sh.cut) and 0 < sh.cut[1] < len(tbs)
+        # a peer's range travels and is decoded in up to three pieces (of whole transport blocks), the root's own range in one
+        assert len(sh.chunk_cut[0]) == 2
+        for r in range(1, world):
+            c = sh.chunk_cut[r]
+            assert c[0] == sh.cut[r] and c[-1] == sh.cut[r + 1] and c == sorted(c) and 2 <= len(c) <= 4
+        if world == 2:
+            assert len(sh.chunk_cut[1]) == 4 and sh.chunk_cut[1] == sorted(set(sh.chunk_cut[1]))
         po, co, ho, segs = ldpc.tb_layout(tbs)
         rng = np.random.default_rng(5)
         ref_tbs = [dict(t) for t in tbs]
@@ -170,6 +174,24 @@ def test_transport_blocks_sharded_world2(built):
         p.start()
     for p in procs:
         p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+def test_transport_blocks_sharded_world4(built):
+    """The same with FOUR ranks: three peers, whose chunks the root posts chunk-major (every link busy at once) and whose
+    results come back in the order they are produced -- the posting order of a real node, which two ranks cannot show."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_tb_worker, args=(r, 4, port, ret)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
 
