@@ -175,3 +175,155 @@ def test_generic_bnprocpc_differs_only_in_parity_columns():
             n1, o1 = RL.decode(BG, Z, R, llr, 8, 1, deg1_generic=True)
             assert n0 == n1 and np.array_equal(o0[:ncore * Z], o1[:ncore * Z])
             assert not o0[ncore * Z:].any()
+
+
+# ---- the SHIPPED node functions' text, written by the reference's own generators (oracle/ref_pin/ref_gen_main.c) --------------
+GEN = RL.LIB_PATH.parent / "gen"
+RATES = {1: (13, 23, 89), 2: (15, 13, 23)}
+
+
+def _lut(BG, R):
+    """group LUTs of (BG, R) as nrLDPC_init hands them out (reference-compiled), plain Python lists"""
+    L = RL.lib()
+    h = L.ref_dec_new(BG, 384, R)
+    G = L.ref_dec_numCnGroups(h)
+    d = dict(G=G, numCn=[L.ref_dec_numCnInCnGroups(h)[g] for g in range(G)], startCn=[L.ref_dec_startAddrCnGroups(h)[g] for g in range(G)],
+             bnInCn=[L.ref_dec_bnInCnGroup(h, g) for g in range(G)], cnFull=[L.ref_dec_cnInCnGroupFull(h, g) for g in range(G)],
+             numBn=[L.ref_dec_numBnInBnGroups(h)[k] for k in range(30)])
+    nz = sum(1 for x in d["numBn"] if x)
+    d["startBn"] = [L.ref_dec_startAddrBnGroups(h)[k] for k in range(nz)]
+    d["startLlr"] = [L.ref_dec_startAddrBnGroupsLlr(h)[k] for k in range(nz)]
+    L.ref_dec_free(h)
+    return d
+
+
+@pytest.mark.skipif(not (GEN / ".done").exists(), reason="generated headers not built")
+def test_generated_check_node_function_is_the_generic_formula_with_all_others_wiring():
+    """[D2] on the shipped code: nrLDPC_cnProc_BG1_R{13,23,89}_AVX2.h as written by the reference's generator
+    (generator_cnProc/cnProc_gen_BG1_avx2.c, compiled from the reference tree) -- every loop of it must be
+        sgn = sign_epi8(ones, x_a); min = abs_epi8(x_a);  then for every further input  min = min_epu8(min, abs_epi8(x)); sgn = sign_epi8(sgn, x);
+        min = min_epu8(min, maxLLR = 127);  out = sign_epi8(min, sgn)
+    with ones = 1, and its inputs must be exactly the OTHER bit nodes' words of the same check-node group -- addresses from
+    the reference's own LUTs -- for every output of every group, M = (numCn Z + 31) >> 5 words each.  That is the formula the
+    oracle restates from the generic nrLDPC_cnProc.h:81-118; the intrinsics' semantics are Intel's."""
+    import re
+    for R in RATES[1]:
+        txt = (GEN / "cnProc" / f"nrLDPC_cnProc_BG1_R{R}_AVX2.h").read_text()
+        assert "ones   = simde_mm256_set1_epi8((int8_t)1);" in txt and "maxLLR = simde_mm256_set1_epi8((int8_t)127);" in txt
+        lut = _lut(1, R)
+        # every loop, statement by statement, as sets of the input words that have gone into `min` and into `sgn`
+        blocks, cur_m = [], None
+        it = iter(txt.splitlines())
+        for line in it:
+            s = line.strip()
+            m = re.fullmatch(r"M = \((\d+)\*Z \+ 31\)>>5;", s)
+            if m:
+                cur_m = int(m.group(1))
+            if s != "for (int i=0;i<M;i++) {":
+                continue
+            reads, in_min, in_sgn, cur, capped, out = [], None, None, None, False, None
+            for line in it:
+                s = line.strip()
+                if s == "}":
+                    break
+                m = re.fullmatch(r"ymm0 = \(\(simde__m256i\*\)cnProcBuf\)\[(\d+)\+i\];", s)
+                w = re.fullmatch(r"\(\(simde__m256i\*\)cnProcBufRes\)\[(\d+)\+i\] = simde_mm256_sign_epi8\(min, sgn\);", s)
+                assert out is None, "a statement behind the store"
+                if m:
+                    assert not capped
+                    cur = int(m.group(1))
+                    assert cur not in reads
+                    reads.append(cur)
+                elif s == "sgn  = simde_mm256_sign_epi8(ones, ymm0);":
+                    assert in_sgn is None and cur is not None
+                    in_sgn = {cur}
+                elif s == "min  = simde_mm256_abs_epi8(ymm0);":
+                    assert in_min is None and cur is not None
+                    in_min = {cur}
+                elif s == "min  = simde_mm256_min_epu8(min, simde_mm256_abs_epi8(ymm0));":
+                    assert in_min is not None and cur not in in_min and not capped
+                    in_min.add(cur)
+                elif s == "sgn  = simde_mm256_sign_epi8(sgn, ymm0);":
+                    assert in_sgn is not None and cur not in in_sgn
+                    in_sgn.add(cur)
+                elif s == "min = simde_mm256_min_epu8(min, maxLLR);":
+                    assert not capped and in_min == set(reads)
+                    capped = True
+                elif w:
+                    assert capped and in_min == in_sgn == set(reads)
+                    out = int(w.group(1))
+                else:
+                    raise AssertionError("statement outside the formula: " + s)
+            assert out is not None
+            blocks.append((cur_m, sorted(reads), out))
+        assert blocks
+        want = []
+        for g in range(lut["G"]):
+            if not lut["numCn"][g]:
+                continue
+            d, base, off = lut["bnInCn"][g], lut["startCn"][g] // 32, lut["cnFull"][g] * 384 // 32
+            for j in range(d):
+                want.append((lut["numCn"][g], sorted(base + k * off for k in range(d) if k != j), base + j * off))
+        assert blocks == want, (R, len(blocks), len(want))
+        assert sum(len(r) + 1 for _, r, _ in want) == sum(lut["numCn"][g] and lut["bnInCn"][g] ** 2 for g in range(lut["G"]))
+
+
+@pytest.mark.skipif(not (GEN / ".done").exists(), reason="generated headers not built")
+def test_generated_bit_node_sum_skips_the_one_check_columns_and_sums_every_message_once():
+    """[D3] / [F5] on the shipped code: nrLDPC_bnProcPc_BG1_R*_AVX2.h as written by generator_bnProc/bnProcPc_gen_BG1_avx2.c.
+    A group of bit nodes with N >= 2 check nodes: widen (cvtepi8_epi16) and add (adds_epi16) the N messages at
+    start + k cnOffset, add the channel LLR, pack with saturation (packs_epi16 + the lane fix-up), store to llrRes -- addresses
+    from the reference's LUTs; and there is NO code for the 1-check group: llrRes of the degree-1 parity columns (its
+    [0, startAddrBnGroupsLlr[1]) entries) is never written, which is why the oracle reports them as 0."""
+    import re
+    for R in RATES[1]:
+        txt = (GEN / "bnProcPc" / f"nrLDPC_bnProcPc_BG1_R{R}_AVX2.h").read_text()
+        lut = _lut(1, R)
+        secs = re.split(r"// Process group with (\d+) CNs", txt)
+        groups = {int(secs[i]): secs[i + 1] for i in range(1, len(secs), 2)}
+        assert 1 in groups and all(N in groups for N in range(2, 31) if lut["numBn"][N - 1])
+        idx = 0
+        for N in sorted(groups):
+            body = groups[N]
+            if N == 1 or lut["numBn"][N - 1] == 0:
+                assert "simde" not in body and "=" not in body.replace("==", ""), (R, N)      # nothing but the comment
+                continue
+            idx += 1
+            nb = lut["numBn"][N - 1]
+            assert re.search(rf"M = \({nb}\*Z \+ 31\)>>5;", body), (R, N)
+            assert f"&bnProcBuf    [{lut['startBn'][idx]}];" in body and f"&llrProcBuf   [{lut['startLlr'][idx]}];" in body
+            assert f"&llrRes       [{lut['startLlr'][idx]}];" in body
+            offs = sorted(int(x) for x in re.findall(r"ymm0 = simde_mm256_cvtepi8_epi16\(p_bnProcBuf\[(\d+) \+ j\]\);", body))
+            assert offs == [k * nb * 384 // 16 for k in range(1, N)], (R, N, offs)
+            assert body.count("ymmRes0 = simde_mm256_cvtepi8_epi16(p_bnProcBuf [j]);") == 1
+            assert body.count("simde_mm256_adds_epi16(ymmRes0,") == N and body.count("simde_mm256_adds_epi16(ymmRes1,") == N   # N-1 messages + the LLR
+            assert body.count("simde_mm256_cvtepi8_epi16(p_llrProcBuf[j]);") == 1
+            assert "ymm0 = simde_mm256_packs_epi16(ymmRes0, ymmRes1);" in body and "p_llrRes[i] = simde_mm256_permute4x64_epi64(ymm0, 0xD8);" in body
+        assert idx == sum(1 for x in lut["numBn"][1:] if x) and lut["startLlr"][1] == lut["numBn"][0] * 384
+
+
+@pytest.mark.skipif(not (GEN / ".done").exists(), reason="generated headers not built")
+def test_generated_bit_to_check_messages_subtract_from_the_clamped_sum():
+    """[D5] on the shipped code: nrLDPC_bnProc_BG2_R*_AVX2.h as written by generator_bnProc/bnProc_gen_BG2_avx2.c: for every
+    group with N >= 2 checks and every k < N:  bnProcBufRes[start + k off + i] = subs_epi8(llrRes[startLlr + i], bnProcBuf[start + k off + i])
+    -- the saturating byte subtraction from llrRes, i.e. from the ALREADY CLAMPED sum -- and nothing for the 1-check group."""
+    import re
+    for R in RATES[2]:
+        txt = (GEN / "bnProc" / f"nrLDPC_bnProc_BG2_R{R}_AVX2.h").read_text()
+        lut = _lut(2, R)
+        # (the generator does not print a heading for every group: the file is read as one sequence of stores)
+        st = re.findall(r"\(\(simde__m256i\*\)bnProcBufRes\)\[(\d+) \+ i \] = simde_mm256_subs_epi8\(\(\(simde__m256i\*\)llrRes\)\[(\d+) \+ i \], "
+                        r"\(\(simde__m256i\*\) bnProcBuf\)\[(\d+) \+ i\]\);", txt)
+        ms = [int(x) for x in re.findall(r"M = \((\d+)\*Z \+ 31\)>>5;", txt)]
+        want, want_m, idx = [], [], 0
+        for N in range(2, 31):
+            nb = lut["numBn"][N - 1]
+            if not nb:
+                continue
+            idx += 1
+            S, Lr, off = lut["startBn"][idx] // 32, lut["startLlr"][idx] // 32, nb * 384 // 32
+            want += [(S + k * off, Lr, S + k * off) for k in range(N)]
+            want_m.append(nb)
+        assert [tuple(int(v) for v in t) for t in st] == want, R
+        assert ms == want_m and txt.count("simde_mm256") == len(want)                       # nothing else: no 1-check group
+        assert min(w[1] for w in want) == lut["startLlr"][1] // 32 == lut["numBn"][0] * 384 // 32
