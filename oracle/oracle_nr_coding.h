@@ -16,8 +16,8 @@
  *       those compiled functions + a second, independent restatement of the node arithmetic on the reference's own
  *       buffer layouts (oracle/ref_pin/ref_hybrid_decoder.c) gives this oracle's pass counts and output bytes for every
  *       (BG, Zc, R), every output mode, parity and CRC stop (tests/test_ref_pin.py).
- *     - the node functions' FORMULA AND WIRING on the shipped (generated) code: the reference's own generators for cnProc BG1,
- *       bnProcPc BG1 and bnProc BG2 compile without SIMDE; the headers they write are read statement by statement
+ *     - the node functions' FORMULA AND WIRING on the shipped (generated) code: the reference's own generators for cnProc (AVX-512:
+ *       both base graphs; AVX2: BG1), bnProcPc BG1 and bnProc BG2 compile without SIMDE; the headers they write are read statement by statement
  *       (tests/test_ref_pin.py test_generated_*): every check-node output = sign(min_epu8(min over the OTHER inputs of abs_epi8, 127),
  *       sign product) [D2]; every bit-node sum = the N widened messages + the channel LLR, packed with saturation, and NO code
  *       for the 1-check group [D3][F5]; every bit-to-check message = subs_epi8(llrRes, message) [D5]; addresses from the LUTs.

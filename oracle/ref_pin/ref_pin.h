@@ -14,8 +14,8 @@
  *     openair1/PHY/CODING/nrLDPC_decoder/nrLDPC_mPass.h                llr2llrProcBuf :98, llr2CnProcBuf_BG1/2 :128,193,
  *                                                                      cn2bnProcBuf_BG2/1 :226,260, bn2cnProcBuf_BG2/1
  *                                                                      :306,344, llrRes2llrOut :394
- *   reference-GENERATED text (ref_gen_main.c links the three code generators that compile without SIMDE -- cnProc BG1,
- *   bnProcPc BG1, bnProc BG2 -- and runs them; oracle/_ref/gen/*): the node functions the SHIPPED decoder calls.  They cannot be
+ *   reference-GENERATED text (ref_gen_main.c links the code generators that compile without SIMDE -- AVX2: cnProc BG1,
+ *   bnProcPc BG1, bnProc BG2; AVX-512: cnProc BG1 and BG2 -- and runs them; oracle/_ref/gen/*): the node functions the SHIPPED decoder calls.  They cannot be
  *   compiled here; tests/test_ref_pin.py reads them statement by statement: formula and wiring of [D2], [D3]/[F5], [D5].
  *   RESTATED here because their bodies are SIMDE intrinsics (ref_hybrid_decoder.c, each citing file:line):
  *     nrLDPC_cnProc_BG1/2, nrLDPC_cnProcPc_BG1/2 (nrLDPC_cnProc.h), nrLDPC_bnProcPc, nrLDPC_bnProc,

@@ -197,63 +197,93 @@ def _lut(BG, R):
     return d
 
 
+CN_VARIANTS = {
+    # AVX2: sign handling by sign_epi8 (zero inputs zero the product); word = 32 bytes
+    "avx2": dict(dir="cnProc", suffix="AVX2", word=32, vec="simde__m256i", reg="ymm0", p="simde_mm256_", bgs=(1,),
+                 consts=("ones   = simde_mm256_set1_epi8((int8_t)1);", "maxLLR = simde_mm256_set1_epi8((int8_t)127);"),
+                 sgn_first="sgn  = simde_mm256_sign_epi8(ones, ymm0);", sgn_next="sgn  = simde_mm256_sign_epi8(sgn, ymm0);",
+                 store=r"simde_mm256_sign_epi8\(min, sgn\);"),
+    # AVX-512 (the canonical build, SURVEY 8c): sign bit by xor, applied by conditional_negate = mask_sub_epi8(a, movepi8_mask(b), z, a)
+    # (nrLDPC_cnProc_avx512.h:35): -min where the xor of the others' sign bits is set; word = 64 bytes; both base graphs
+    "avx512": dict(dir="cnProc_avx512", suffix="AVX512", word=64, vec="simde__m512i", reg="zmm0", p="simde_mm512_", bgs=(1, 2),
+                   consts=("ones = simde_mm512_set1_epi8((char)1);", "maxLLR = simde_mm512_set1_epi8((char)127);", "zeros  = simde_mm512_setzero_si512();"),
+                   sgn_first="sgn  = simde_mm512_xor_si512(ones, zmm0);", sgn_next="sgn  = simde_mm512_xor_si512(sgn, zmm0);",
+                   store=r"conditional_negate\(min, sgn,zeros\);"),
+}
+
+
 @pytest.mark.skipif(not (GEN / ".done").exists(), reason="generated headers not built")
-def test_generated_check_node_function_is_the_generic_formula_with_all_others_wiring():
-    """[D2] on the shipped code: nrLDPC_cnProc_BG1_R{13,23,89}_AVX2.h as written by the reference's generator
-    (generator_cnProc/cnProc_gen_BG1_avx2.c, compiled from the reference tree) -- every loop of it must be
-        sgn = sign_epi8(ones, x_a); min = abs_epi8(x_a);  then for every further input  min = min_epu8(min, abs_epi8(x)); sgn = sign_epi8(sgn, x);
-        min = min_epu8(min, maxLLR = 127);  out = sign_epi8(min, sgn)
-    with ones = 1, and its inputs must be exactly the OTHER bit nodes' words of the same check-node group -- addresses from
-    the reference's own LUTs -- for every output of every group, M = (numCn Z + 31) >> 5 words each.  That is the formula the
-    oracle restates from the generic nrLDPC_cnProc.h:81-118; the intrinsics' semantics are Intel's."""
+@pytest.mark.parametrize("variant", ["avx2", "avx512"])
+def test_generated_check_node_function_is_the_generic_formula_with_all_others_wiring(variant):
+    """[D2] on the shipped code: nrLDPC_cnProc_BG*_R*_{AVX2,AVX512}.h as written by the reference's generators
+    (generator_cnProc/cnProc_gen_BG1_avx2.c; generator_cnProc_avx512/cnProc_gen_BG{1,2}_avx512.c -- compiled from the
+    reference tree) -- every loop of them must be
+        sgn = SIGN(ones, x_a); min = abs_epi8(x_a);  then for every further input  min = min_epu8(min, abs_epi8(x)); sgn = SIGN(sgn, x);
+        min = min_epu8(min, maxLLR = 127);  out = APPLY(min, sgn)
+    (SIGN / APPLY = sign_epi8 / sign_epi8 in the AVX2 text, xor / conditional_negate in the AVX-512 text: the same value
+    wherever the magnitude is not 0, and 0 either way where it is), and its inputs must be exactly the OTHER bit nodes' words
+    of the same check-node group -- addresses from the reference's own LUTs -- for every output of every group,
+    M = ceil(numCn Z / word) words each.  That is the formula the oracle restates from the generic nrLDPC_cnProc.h:81-118; the
+    intrinsics' semantics are Intel's."""
     import re
-    for R in RATES[1]:
-        txt = (GEN / "cnProc" / f"nrLDPC_cnProc_BG1_R{R}_AVX2.h").read_text()
-        assert "ones   = simde_mm256_set1_epi8((int8_t)1);" in txt and "maxLLR = simde_mm256_set1_epi8((int8_t)127);" in txt
-        lut = _lut(1, R)
-        # every loop, statement by statement, as sets of the input words that have gone into `min` and into `sgn`
+    V = CN_VARIANTS[variant]
+    W, reg, P, vec = V["word"], V["reg"], re.escape(V["p"]), re.escape(V["vec"])
+    n_files = 0
+    for BG in V["bgs"]:
+      for R in RATES[BG]:
+        txt = (GEN / V["dir"] / f"nrLDPC_cnProc_BG{BG}_R{R}_{V['suffix']}.h").read_text()
+        for c in V["consts"]:
+            assert re.sub(r"\s+", "", c) in re.sub(r"\s+", "", txt), c
+        lut = _lut(BG, R)
+        n_files += 1
+        # every loop, statement by statement (white space ignored: the generators' spelling of it varies), as sets of the
+        # input words that have gone into `min` and into `sgn`
+        nows = lambda x: re.sub(r"\s+", "", x)
+        S_FIRST, S_NEXT = nows(V["sgn_first"]), nows(V["sgn_next"])
+        M_FIRST, M_NEXT = nows(f"min = {V['p']}abs_epi8({reg});"), nows(f"min = {V['p']}min_epu8(min, {V['p']}abs_epi8({reg}));")
+        CAP = nows(f"min = {V['p']}min_epu8(min, maxLLR);")
         blocks, cur_m = [], None
         it = iter(txt.splitlines())
         for line in it:
-            s = line.strip()
-            m = re.fullmatch(r"M = \((\d+)\*Z \+ 31\)>>5;", s)
+            s = nows(line)
+            m = re.fullmatch(rf"M=\((\d+)\*Z\+{W - 1}\)>>{W.bit_length() - 1};", s)
             if m:
                 cur_m = int(m.group(1))
-            if s != "for (int i=0;i<M;i++) {":
+            if s not in ("for(inti=0;i<M;i++){", "for(i=0;i<M;i++){"):
                 continue
             reads, in_min, in_sgn, cur, capped, out = [], None, None, None, False, None
             for line in it:
-                s = line.strip()
+                s = nows(line)
                 if s == "}":
                     break
-                m = re.fullmatch(r"ymm0 = \(\(simde__m256i\*\)cnProcBuf\)\[(\d+)\+i\];", s)
-                w = re.fullmatch(r"\(\(simde__m256i\*\)cnProcBufRes\)\[(\d+)\+i\] = simde_mm256_sign_epi8\(min, sgn\);", s)
+                m = re.fullmatch(rf"{reg}=\(\({vec}\*\)cnProcBuf\)\[(\d+)\+i\];", s)
+                w = re.fullmatch(rf"\(\({vec}\*\)cnProcBufRes\)\[(\d+)\+i\]=" + nows(V["store"]), s)
                 assert out is None, "a statement behind the store"
                 if m:
                     assert not capped
                     cur = int(m.group(1))
                     assert cur not in reads
                     reads.append(cur)
-                elif s == "sgn  = simde_mm256_sign_epi8(ones, ymm0);":
+                elif s == S_FIRST:
                     assert in_sgn is None and cur is not None
                     in_sgn = {cur}
-                elif s == "min  = simde_mm256_abs_epi8(ymm0);":
+                elif s == M_FIRST:
                     assert in_min is None and cur is not None
                     in_min = {cur}
-                elif s == "min  = simde_mm256_min_epu8(min, simde_mm256_abs_epi8(ymm0));":
+                elif s == M_NEXT:
                     assert in_min is not None and cur not in in_min and not capped
                     in_min.add(cur)
-                elif s == "sgn  = simde_mm256_sign_epi8(sgn, ymm0);":
+                elif s == S_NEXT:
                     assert in_sgn is not None and cur not in in_sgn
                     in_sgn.add(cur)
-                elif s == "min = simde_mm256_min_epu8(min, maxLLR);":
+                elif s == CAP:
                     assert not capped and in_min == set(reads)
                     capped = True
                 elif w:
                     assert capped and in_min == in_sgn == set(reads)
                     out = int(w.group(1))
                 else:
-                    raise AssertionError("statement outside the formula: " + s)
+                    raise AssertionError("statement outside the formula: " + line)
             assert out is not None
             blocks.append((cur_m, sorted(reads), out))
         assert blocks
@@ -261,11 +291,11 @@ def test_generated_check_node_function_is_the_generic_formula_with_all_others_wi
         for g in range(lut["G"]):
             if not lut["numCn"][g]:
                 continue
-            d, base, off = lut["bnInCn"][g], lut["startCn"][g] // 32, lut["cnFull"][g] * 384 // 32
+            d, base, off = lut["bnInCn"][g], lut["startCn"][g] // W, lut["cnFull"][g] * 384 // W
             for j in range(d):
                 want.append((lut["numCn"][g], sorted(base + k * off for k in range(d) if k != j), base + j * off))
-        assert blocks == want, (R, len(blocks), len(want))
-        assert sum(len(r) + 1 for _, r, _ in want) == sum(lut["numCn"][g] and lut["bnInCn"][g] ** 2 for g in range(lut["G"]))
+        assert blocks == want, (variant, BG, R, len(blocks), len(want))
+    assert n_files == 3 * len(V["bgs"])
 
 
 @pytest.mark.skipif(not (GEN / ".done").exists(), reason="generated headers not built")
