@@ -357,3 +357,28 @@ def test_generated_bit_to_check_messages_subtract_from_the_clamped_sum():
         assert [tuple(int(v) for v in t) for t in st] == want, R
         assert ms == want_m and txt.count("simde_mm256") == len(want)                       # nothing else: no 1-check group
         assert min(w[1] for w in want) == lut["startLlr"][1] // 32 == lut["numBn"][0] * 384 // 32
+
+
+def test_the_recipe_holds_no_stand_ins():
+    """What makes oracle/_ref a pin and not a restatement: the recipe compiles reference files WHERE THEY LIE with include paths
+    into the reference tree only, the wrapper TU contains no arithmetic of its own, and nothing under oracle/ref_pin/ defines
+    or fakes a SIMDE name (the survey-stage build did, which is why its vectors pin nothing)."""
+    import re
+    pin = RL.PIN_DIR
+    mk = (pin / "Makefile").read_text()
+    incs = re.findall(r"-I(\S+)", mk)
+    assert incs and all(i.startswith("$(REF)") or i.startswith("$(CODING)") for i in incs), incs
+    assert "REF ?= /root/reference" in mk and "CODING = $(REF)/openair1/PHY/CODING" in mk
+    wrap = (pin / "ref_wrap.c").read_text()
+    quoted = re.findall(r'#include "([^"]+)"', wrap)
+    assert quoted == ["ldpc_generate_coefficient.c", "nrLDPC_types.h", "nrLDPC_init.h", "nrLDPC_mPass.h", "ref_pin.h"], quoted
+    for name in ("ldpc_generate_coefficient.c", "nrLDPC_types.h", "nrLDPC_init.h", "nrLDPC_mPass.h"):
+        assert not (pin / name).exists() and not list(RL.ROOT.glob(f"oracle/**/{name}"))       # included from the reference tree, not copied
+    body = wrap[wrap.index('#include "ref_pin.h"'):]
+    code = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert not re.search(r"\b(for|while)\s*\(", code) and not re.search(r"\^|<<|>>|%|\+\+", code)   # plumbing only: no loops, no arithmetic of the path
+    for f in pin.iterdir():
+        if f.suffix in (".c", ".h"):
+            code = re.sub(r"/\*.*?\*/", "", f.read_text(), flags=re.S)
+            assert not re.search(r"#\s*define\s+simde|typedef[^;]*simde_|simde_mm\w*\s*\(", code), f.name
+    assert RL.REFERENCE.exists() or not (pin / "nothing").exists()
