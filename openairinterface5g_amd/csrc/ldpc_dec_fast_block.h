@@ -37,6 +37,9 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             (decoder.c:556-559) for a caller whose `ab` is raised by another thread while the call is in
  *                             flight; 0 / false elsewhere
  *   uint32_t *stamps()        optional (LDS): wall_clock64 after the prologue and after the last pass (diagnostics)
+ *   static bool pass_stamps   diagnostic instantiation: stamps() is a row of 54 words in memory (zeroed by the launcher) and
+ *                             also takes [2p], [2p + 1] the clocks behind pass p's check-node / bit-node barrier, [20] the
+ *                             passes that ran the eager parity sweep (bit p), [22 + p] the unsatisfied lanes counted by pass p
  *   int tid()                 threadIdx.x
  *   uint32_t ld_llr(p)        one dword of src32_prologue()'s row: a plain load, or one that bypasses the caches when the
  *                             row was written by the host while this kernel was running (resident server)
@@ -52,6 +55,13 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *   bool tb_fused()           ... and does so for this block: instead of an output row, io.tb_finish(n_iter, bits_word,
  *                             flags) delivers the segment's payload bytes, its share of the TB CRC and -- from the last
  *                             segment of a transport block to finish -- the block's verdict
+ *   static bool persistent    the caller is a persistent workgroup that draws its blocks from a counter
+ *                             (ldpc_dec_fast_persist_kernel): towards the likely end of a block the body draws the next block's
+ *                             index (io.draw_issue / io.draw_publish) and requests its LLRs (io.prefetch: loads into
+ *                             registers that the next call's prologue takes with io.take_prefetch), so that the trip to HBM
+ *                             runs under this block's parity sweep / CRC check and hard decision
+ *   int fair_turns()          0, or: the workgroup shares its CU with others of its kind and has this many waves per SIMD -- it
+ *                             takes turns with them at the issue priority, pass by pass (see below)
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
  *                             check-node phase when the block has converged); same results, same pass counts */
@@ -114,7 +124,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
    * otherwise sit behind a trip over the link. */
   const int n_app = ncore * zq, n_ext = ext_global ? 0 : (code->ncols - ncore) * zq;
   uint32_t va[4], ve[4];
-  if (!stage) {
+  bool prefetched = false;
+  if constexpr (IO::persistent)
+    prefetched = io.take_prefetch(va, ve);
+  if (!stage && !prefetched) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int ia = tid + k * nt;
@@ -212,8 +225,27 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
 #define LDPC_TLOG_END(phase, deg) do { } while (0)
 #define LDPC_TSTAMP(id) do { } while (0)
 #endif
+  /* Workgroups that share a CU: the SIMDs' issue arbiter serves the OLDEST wave first, so of two co-resident workgroups the
+   * one that arrived first runs at the speed it would have alone (8.7 us per pass for BG1 Zc = 384 R = 2/3) and the other one at
+   * what is left (14 us) -- until the first one leaves and its successor is the younger one (profiles/r06/README.md).  The CU's
+   * throughput is the same either way, but the last workgroup of a CU always ends up finishing alone on a half-used CU.  Taking
+   * turns: a wave's slot on its SIMD tells which of the CU's workgroups it belongs to, and a workgroup raises its priority in
+   * the passes whose number matches its slot -- two workgroups that run side by side then alternate, and one that has fallen a
+   * pass behind holds the high priority until it has caught up. */
+  const int fair = io.fair_turns();
+  int prio_slot = 0;
+  if (fair)
+    prio_slot = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u) / fair; /* HW_REG_HW_ID.wave_id / waves per SIMD and workgroup */
   for (int p = 1; p <= max_pass; ++p) {
     uint32_t syn = 0;
+    if (fair) {
+      if ((p + prio_slot) & 1)
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (IO::persistent)
+      io.drop_prefetch(); /* (requested behind the previous pass, which did not turn out to be the last: asked for again later) */
     const uint32_t ab_word = (io.has_abort() && tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
     /* likewise the transport block's flag (a load that leaves the caches: its latency would otherwise sit between the
      * check-node phase and the barrier, once per pass) */
@@ -299,6 +331,12 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         flags[3] = 1;
     }
     __syncthreads();
+    if constexpr (IO::pass_stamps) {
+      if (tid == 0 && p <= 9) {
+        io.stamps()[2 * p] = (uint32_t)wall_clock64();
+        io.stamps()[22 + p] = (uint32_t)flags[p & 1];
+      }
+    }
     if (io.has_abort() && flags[3]) { /* (set by one of the two abort sources) */
       n_iter = max_pass + 1;
       break;
@@ -311,6 +349,16 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       n_iter = p - 1;
       break;
     }
+    /* persistent workgroups: is this pass likely to be the block's last?  (the last one allowed; a CRC check follows; the
+     * parity sweep follows.)  Then the next block's index is drawn now -- the atomic's trip runs under the bit-node phase -- and
+     * its LLRs are requested behind the phase's barrier */
+    bool ending = false;
+    if constexpr (IO::persistent) {
+      ending = p == max_pass || (io.use_crc() ? p >= 3 : (p >= 2 && bad_prev <= LDPC_EAGER_MAX_BAD_LANES));
+      if (ending)
+        io.draw_issue(tid);
+    }
+    (void)ending;
 #ifndef LDPC_ABLATE_BN
     if constexpr (IO::bn_tickets) {
     /* the next ticket is asked for behind an item's gather and looked at behind its store: the draw's round trip runs
@@ -373,7 +421,19 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     cn_ticket = ldpc_draw(&flags[8 + ((p + 1) & 1)], lane);
     if (tid == 0)
       flags[(p + 1) & 1] = 0;
+    if constexpr (IO::persistent) {
+      if (ending)
+        io.draw_publish(tid, flags);
+    }
     __syncthreads();
+    if constexpr (IO::persistent) {
+      if (ending)
+        io.prefetch(flags, tid, nt, n_app, n_ext);
+    }
+    if constexpr (IO::pass_stamps) {
+      if (tid == 0 && p <= 9)
+        io.stamps()[2 * p + 1] = (uint32_t)wall_clock64();
+    }
     if (io.eager_check() && !io.use_crc() && p >= 2 && p < max_pass && bad_prev <= LDPC_EAGER_MAX_BAD_LANES) {
       /* the check the next pass would make first thing (decoder.c:842-848: cnProcPc on this pass' results; p + 1 >= 3 and
        * p + 1 <= max_pass as there), as a sweep of its own over the same task list -- when the previous pass was already
@@ -382,6 +442,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       /* items are walked by index, not by task: row record (degree, first edge) per lane from the LDS table, no queue and
        * no task records from the descriptor -- the sweep is a few loads per edge, and the fetch chain in front of every
        * task was most of its time (6 us -> 2 us for BG1 Zc = 384) */
+      if constexpr (IO::pass_stamps) {
+        if (tid == 0)
+          io.stamps()[20] |= 1u << p;
+      }
       uint32_t esyn = 0;
       const int n_items = code->nrows * zq;
       for (int item = tid; item < n_items; item += nt) {
@@ -413,6 +477,9 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       /* four hard decisions (one APP dword: Zc % 4 == 0 keeps them in one column) and their four table entries per
        * step, the loads unconditional and masked afterwards: independent loads in flight instead of a chain of
        * bit test -> load -> wait (E is a multiple of 8) */
+      /* (not unrolled: a handful of iterations per thread, and unrolled it was the kernel's register peak -- 126 instead of
+       * 92 VGPRs, scratch memory in the instantiations that carry both stop modes) */
+#pragma unroll 1
       for (int i = 4 * tid; i < crcE; i += 4 * nt) {
         const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
         const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + u); /* bit 8k+7 set <=> APP of lane k < 0 */

@@ -114,7 +114,9 @@ __device__ __forceinline__ void ldpc_mb_write_out(const ldpc_fast_lds &L, ldpc_c
 }
 
 /* blocks first .. first + n_valid - 1 of the launch (n_valid <= f_mb * SUB); results to a.out / a.n_iter */
-template <int SUB, bool JOBS>
+/* CRC = the launch's stop mode, known to the launcher: the other mode's check is not compiled in (with both, the kernels
+ * for SUB = 1 needed scratch memory, which costs every launch 15-20 us on this stack: profiles/r06/README.md) */
+template <int SUB, bool JOBS, bool CRC>
 __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr_t code, const ldpc_mb_io<JOBS> &io, int n_valid)
 {
   const ldpc_dec_args &a = io.a;
@@ -222,7 +224,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
 
   /* ---- passes ------------------------------------------------------------------------------------------ */
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tasks = code->f_n_bn_tasks, bn_group = code->f_bn_group;
-  const int use_crc = a.use_crc;
+  constexpr int use_crc = CRC ? 1 : 0;
   /* is group / block g still worked on?  SUB = 1: the block's own flag; SUB = 4: any of its four */
   auto group_active = [&](int g) -> bool {
     if (SUB == 1)
@@ -332,6 +334,7 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
           continue;
         uint32_t x = 0;
         if (SUB == 1) {
+#pragma unroll 1
           for (int i = 4 * tid; i < crcE; i += 4 * nt) {
             const int c = (int)ldpc_umulhi((uint32_t)i, z_magic), u = i - c * Z;
             const uint32_t nb = ~*reinterpret_cast<const uint32_t *>(L.app + c * astride + blk * pa + u);

@@ -18,7 +18,7 @@
 /* CRC = the launch is known to stop on the CRC (the transport-block chain's job launches): the parity of the hard decisions,
  * which only the parity-check stop looks at, is then not computed at all -- an XOR per edge and a dozen ops per item of the
  * check-node bodies fall away as dead code */
-template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
+template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io {
   const ldpc_dec_args &a;
   ldpc_job_ptr_t job; /* nullptr without JOBS: known at compile time, so the selects below fold away */
   __device__ __forceinline__ const uint32_t *src32() const
@@ -27,7 +27,10 @@ template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
   }
   __device__ __forceinline__ int8_t *out() const { return a.out + (job ? (size_t)job->out_off : (size_t)blockIdx.x * a.out_stride); }
   __device__ __forceinline__ int max_pass() const { return (job ? job->num_max_iter : a.num_max_iter) + 1; }
-  __device__ __forceinline__ int use_crc() const { return CRC ? 1 : a.use_crc; }
+  /* (the launchers pick the instantiation from a.use_crc: CRC = false never meets a CRC-stop call, and the CRC check is not
+   * compiled into it -- its registers were what pushed the parity-check instantiation into scratch memory, and a kernel that
+   * uses ANY scratch pays 15-20 us per launch on this stack: profiles/r06/ab_scratch_probe.txt) */
+  __device__ __forceinline__ int use_crc() const { return CRC ? 1 : 0; }
   static constexpr bool syndrome = !CRC;
   __device__ __forceinline__ int crcE() const { return job ? job->E : a.E; }
   __device__ __forceinline__ const uint32_t *crc_pow() const { return job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow; }
@@ -36,7 +39,14 @@ template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
   {
     return (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
   }
-  __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
+  /* (TRACE: the diagnostic instantiation, NRLDPC_HIP_DEC_TRACE -- the stamps go straight into the workgroup's trace row) */
+  __device__ __forceinline__ uint32_t *stamps() const
+  {
+    return TRACE ? reinterpret_cast<uint32_t *>(a.trace + (size_t)blockIdx.x * 32 + 5) : nullptr;
+  }
+  static constexpr bool pass_stamps = TRACE;
+  static constexpr bool persistent = false;
+  __device__ __forceinline__ int fair_turns() const { return a.fair; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   /* homogeneous launches: the parity check of a pass right after it when the block is close to converging (a block that
    * stops saves the next pass' check-node phase; one that does not converge never gets close and pays nothing) */
@@ -59,7 +69,7 @@ template <bool JOBS, bool CRC = false> struct ldpc_batch_io {
  * waves per CU: the throughput shapes put k workgroups of w <= 16 / k waves on a CU and count on all 16 wave slots
  * (a variant compiled for <= 768 threads may take 129+ VGPRs and silently drop the CU to 12 waves: measured 180 -> 262 us
  * on the 1664-segment slot). */
-template <bool JOBS, bool CRC = false>
+template <bool JOBS, bool CRC = false, bool TRACE = false>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -67,11 +77,183 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
    * so everything derived from them stays in SGPRs */
   const ldpc_job_ptr_t job = JOBS ? (ldpc_job_ptr_t)a.jobs + blockIdx.x : (ldpc_job_ptr_t) nullptr;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)(job ? job->code : a.code);
-  const ldpc_batch_io<JOBS, CRC> io{a, job};
+  const ldpc_batch_io<JOBS, CRC, TRACE> io{a, job};
+  unsigned long long *tr = TRACE ? a.trace + (size_t)blockIdx.x * 32 : nullptr;
+  if (TRACE && threadIdx.x == 0) {
+    tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID: wave, simd, cu, sh, se ... */
+    tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* HW_REG_XCC_ID */
+    tr[2] = wall_clock64();
+  }
   const int n_iter = ldpc_dec_fast_block(fsm, code, io);
   if (threadIdx.x == 0)
     a.n_iter[job ? (uint32_t)job->iter_idx : blockIdx.x] = n_iter;
+  if (TRACE) {
+    __syncthreads(); /* (the output row's stores are on their way) */
+    if (threadIdx.x == 0) {
+      tr[3] = wall_clock64();
+      tr[4] = (unsigned long long)n_iter;
+    }
+  }
 }
+
+/* Persistent form of the homogeneous launch: one workgroup per slot of the GPU; a workgroup takes block blockIdx.x first and
+ * then whatever the launch's counter hands out (a.draw: list scheduling by whoever is free, as the hardware's dispatcher does
+ * it for one-block workgroups), keeps the code's tables in LDS, and asks for the next block's index and LLRs while the
+ * current block is finishing (ldpc_dec_fast_block.h, IO::persistent) -- the 2-3 us between "last pass done" and "first
+ * check-node task of the next block" that a fresh workgroup spends waiting for HBM. */
+template <bool TRACE = false> struct ldpc_persist_io {
+  const ldpc_dec_args &a;
+  mutable uint32_t blk, next;        /* current block; the one after it (valid when published) */
+  mutable uint32_t seq;              /* blocks this workgroup has started: parity selects the LDS word the index travels through */
+  mutable bool drawn, published;     /* the next index: requested from the counter / known to every wave */
+  mutable bool resident;             /* tables in LDS (every block but the workgroup's first) */
+  mutable bool pref, have_pref;      /* LLRs requested for `next` / this block's LLRs are in pv */
+  mutable uint32_t nxt_v;            /* thread 0: the counter's answer */
+  mutable uint32_t pva[4], pve[4];
+  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(a.llr + (size_t)blk * a.llr_stride); }
+  __device__ __forceinline__ int8_t *out() const { return a.out + (size_t)blk * a.out_stride; }
+  __device__ __forceinline__ int max_pass() const { return a.num_max_iter + 1; }
+  __device__ __forceinline__ int use_crc() const { return 0; } /* (parity-check stop only: ldpc_launch_dec_fast_persist) */
+  static constexpr bool syndrome = true;
+  __device__ __forceinline__ int crcE() const { return a.E; }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return a.crc_pow; }
+  __device__ __forceinline__ int out_mode() const { return a.out_mode; }
+  __device__ __forceinline__ int *tb_abort() const { return nullptr; }
+  __device__ __forceinline__ uint32_t *stamps() const
+  {
+    return TRACE ? reinterpret_cast<uint32_t *>(a.trace + (size_t)blk * 32 + 5) : nullptr;
+  }
+  static constexpr bool pass_stamps = TRACE;
+  static constexpr bool persistent = true;
+  __device__ __forceinline__ int fair_turns() const { return 0; } /* (one workgroup per CU) */
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ bool eager_check() const { return true; }
+  static constexpr bool bn_tickets = true;
+  static constexpr bool tb_epilogue = false;
+  __device__ __forceinline__ bool tables_resident() const { return resident; }
+  __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
+  __device__ __forceinline__ uint32_t abort_load() const { return 0u; }
+  __device__ __forceinline__ bool abort_is(uint32_t) const { return false; }
+  __device__ __forceinline__ bool has_abort() const { return false; }
+  __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { *p = make_uint4(x, y, z, t); }
+  __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return *p; }
+  __device__ __forceinline__ const uint32_t *src32_prologue() const { return src32(); }
+  __device__ __forceinline__ uint32_t *stage_core() const { return nullptr; }
+  /* ---- the next block ---- */
+  __device__ __forceinline__ void draw_issue(int tid) const
+  {
+    if (!drawn) {
+      drawn = true;
+      if (tid == 0)
+        nxt_v = __hip_atomic_fetch_add(a.draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gridDim.x;
+    }
+  }
+  /* (in front of a barrier) */
+  __device__ __forceinline__ void draw_publish(int tid, int *flags) const
+  {
+    if (drawn && !published && tid == 0)
+      flags[32 + (seq & 1)] = (int)nxt_v;
+  }
+  /* (behind that barrier) */
+  __device__ __forceinline__ void learn_next(const int *flags) const
+  {
+    if (drawn && !published) {
+      next = LDPC_UNIFORM((uint32_t)flags[32 + (seq & 1)]);
+      published = true;
+    }
+  }
+  __device__ __forceinline__ void prefetch(const int *flags, int tid, int nt, int n_app, int n_ext) const
+  {
+    learn_next(flags);
+    if (published && next < a.n_blocks) {
+      const uint32_t *s = reinterpret_cast<const uint32_t *>(a.llr + (size_t)next * a.llr_stride);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ia = tid + k * nt;
+        pva[k] = ia < n_app ? s[ia] : 0u;
+        pve[k] = ia < n_ext ? s[n_app + ia] : 0u;
+      }
+      pref = true;
+    }
+  }
+  /* (the values are overwritten, not just disowned: otherwise they stay alive -- eight registers -- through the next pass) */
+  __device__ __forceinline__ void drop_prefetch() const
+  {
+    pref = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      pva[k] = pve[k] = 0u;
+  }
+  __device__ __forceinline__ bool take_prefetch(uint32_t (&va)[4], uint32_t (&ve)[4]) const
+  {
+    if (!have_pref)
+      return false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      va[k] = pva[k];
+      ve[k] = pve[k];
+    }
+    return true;
+  }
+};
+
+template <bool TRACE = false>
+__global__ void __launch_bounds__(1024) ldpc_dec_fast_persist_kernel(const ldpc_dec_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
+  int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
+  ldpc_persist_io<TRACE> io{a};
+  io.blk = blockIdx.x;
+  io.next = 0;
+  io.seq = 0;
+  io.resident = false;
+  io.have_pref = false;
+  io.nxt_v = 0;
+  io.drop_prefetch();
+  for (;;) {
+    io.drawn = io.published = io.pref = false;
+    /* (the descriptor pointer is made opaque once per block: otherwise everything the body derives from it is hoisted out of
+     * this loop and kept alive across it -- a hundred registers spilled) */
+    ldpc_code_ptr_t code_i = code;
+    asm volatile("" : "+s"(code_i));
+    unsigned long long *tr = TRACE ? a.trace + (size_t)io.blk * 32 : nullptr;
+    if (TRACE && threadIdx.x == 0) {
+      tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+      tr[2] = wall_clock64();
+    }
+    const int n_iter = ldpc_dec_fast_block(fsm, code_i, io);
+    if (threadIdx.x == 0)
+      a.n_iter[io.blk] = n_iter;
+    const bool late = !io.published; /* the block ended where nobody expected it to (or never looked: a one-pass cap) */
+    if (late) {
+      io.draw_issue((int)threadIdx.x);
+      io.draw_publish((int)threadIdx.x, flags);
+    }
+    __syncthreads(); /* every wave has taken its hard decisions from the APP rows: the next block's prologue may overwrite them */
+    if (TRACE && threadIdx.x == 0) {
+      tr[3] = wall_clock64();
+      tr[4] = (unsigned long long)n_iter;
+    }
+    if (late)
+      io.learn_next(flags);
+    if (io.next >= a.n_blocks)
+      break;
+    io.blk = io.next;
+    io.have_pref = io.pref;
+    io.resident = true;
+    io.seq++;
+  }
+  /* the last workgroup to leave puts the counter back (every workgroup's draws precede its own count) */
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(a.draw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      __hip_atomic_store(a.draw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.draw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 
 /* Host-buffer batches: the block's LLRs sit in page-locked host memory.  The workgroup pulls its row over the link into
  * its row of the device staging buffer (16-byte loads, all of a 1024-thread workgroup's 26 KB in flight at once) and then
@@ -79,6 +261,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
  * workgroups at different points of their life (pulling / decoding) the link and the CUs are busy at the same time, with
  * no copy-engine -> kernel dependency anywhere (measured: a chunked hipMemcpyAsync pipeline loses ~40 us per such edge;
  * profiles/r02/README.md). */
+template <bool CRC>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -131,15 +314,15 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_pull_kernel(const ldpc_dec
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const ldpc_batch_io<false> io{a, (ldpc_job_ptr_t) nullptr};
+  const ldpc_batch_io<false, CRC> io{a, (ldpc_job_ptr_t) nullptr};
   const int n_iter = ldpc_dec_fast_block(fsm, code, io);
   if (threadIdx.x == 0)
     a.n_iter[blockIdx.x] = n_iter;
 }
 
 /* small lifting sizes: f_mb blocks (SUB = 4: f_mb groups of four byte-interleaved blocks) per workgroup
- * (ldpc_dec_fast_mblock.h) */
-template <int SUB>
+ * (ldpc_dec_fast_mblock.h); CRC = the launch's stop mode */
+template <int SUB, bool CRC>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -148,10 +331,10 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_kernel(const ldpc_de
   const uint32_t first = blockIdx.x * per_wg;
   const uint32_t left = a.n_blocks - first;
   const ldpc_mb_io<false> io{a, first, (ldpc_job_ptr_t) nullptr, a.num_max_iter, a.E, a.crc_pow};
-  ldpc_dec_fast_mblock<SUB, false>(fsm, code, io, left < per_wg ? (int)left : (int)per_wg);
+  ldpc_dec_fast_mblock<SUB, false, CRC>(fsm, code, io, left < per_wg ? (int)left : (int)per_wg);
 }
 /* the same for a group of jobs of the transport-block chain (small segments of one code, cap and CRC) */
-template <int SUB>
+template <int SUB, bool CRC>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -159,18 +342,22 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
   const grp_ptr_t gr = (grp_ptr_t)a.mgroups + blockIdx.x;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)gr->code;
   const ldpc_mb_io<true> io{a, gr->first_job, (ldpc_job_ptr_t)a.jobs + gr->first_job, gr->num_max_iter, gr->E, a.crc_pow_tbl[gr->crc_type & 3]};
-  ldpc_dec_fast_mblock<SUB, true>(fsm, code, io, (int)gr->n_valid);
+  ldpc_dec_fast_mblock<SUB, true, CRC>(fsm, code, io, (int)gr->n_valid);
 }
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[9] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1>),
-                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4>)};
-  for (int i = 0; i < 9; i++) {
+  const void *k[] = {reinterpret_cast<const void *>(ldpc_dec_fast_persist_kernel<true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_persist_kernel<false>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<1, true>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_jobs_kernel<4, true>)};
+  for (size_t i = 0; i < sizeof(k) / sizeof(k[0]); i++) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
       return e;
@@ -186,8 +373,26 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
   if (a.use_crc) /* CRC stop: the instantiation without the parity of the hard decisions */
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  else if (a.trace)
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t ldpc_launch_dec_fast_persist(const ldpc_dec_args &a0, const ldpc_code_desc_t &hc, uint32_t n_blocks, uint32_t grid,
+                                        hipStream_t stream)
+{
+  if (n_blocks == 0)
+    return hipSuccess;
+  if (a0.jobs || a0.use_crc || !a0.draw || grid == 0 || grid > n_blocks)
+    return hipErrorInvalidValue;
+  ldpc_dec_args a = a0;
+  a.n_blocks = n_blocks;
+  if (a.trace)
+    hipLaunchKernelGGL(ldpc_dec_fast_persist_kernel<true>, dim3(grid), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_persist_kernel<false>, dim3(grid), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 
@@ -201,10 +406,17 @@ hipError_t ldpc_launch_dec_fast_multi(const ldpc_dec_args &a0, const ldpc_code_d
   a.n_blocks = n_blocks;
   const uint32_t per_wg = (uint32_t)hc.f_mb * (uint32_t)hc.f_sub;
   const dim3 grid((n_blocks + per_wg - 1) / per_wg), block(hc.f_n_threads);
-  if (hc.f_sub == 4)
-    hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<4>, grid, block, hc.f_lds_total, stream, a);
-  else
-    hipLaunchKernelGGL(ldpc_dec_fast_multi_kernel<1>, grid, block, hc.f_lds_total, stream, a);
+  if (hc.f_sub == 4) {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_kernel<4, true>), grid, block, hc.f_lds_total, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_kernel<4, false>), grid, block, hc.f_lds_total, stream, a);
+  } else {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_kernel<1, true>), grid, block, hc.f_lds_total, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_kernel<1, false>), grid, block, hc.f_lds_total, stream, a);
+  }
   return hipGetLastError();
 }
 
@@ -215,10 +427,17 @@ hipError_t ldpc_launch_dec_fast_multi_jobs(const ldpc_dec_args &a, int sub, int 
     return hipSuccess;
   if (!a.jobs || !a.mgroups)
     return hipErrorInvalidValue;
-  if (sub == 4)
-    hipLaunchKernelGGL(ldpc_dec_fast_multi_jobs_kernel<4>, dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL(ldpc_dec_fast_multi_jobs_kernel<1>, dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+  if (sub == 4) {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_jobs_kernel<4, true>), dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_jobs_kernel<4, false>), dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+  } else {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_jobs_kernel<1, true>), dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_multi_jobs_kernel<1, false>), dim3(n_groups), dim3(n_threads), lds_bytes, stream, a);
+  }
   return hipGetLastError();
 }
 
@@ -228,7 +447,10 @@ hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_des
     return hipSuccess;
   if (a.jobs || !a.pull)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ldpc_dec_fast_pull_kernel, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  if (a.use_crc)
+    hipLaunchKernelGGL(ldpc_dec_fast_pull_kernel<true>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+  else
+    hipLaunchKernelGGL(ldpc_dec_fast_pull_kernel<false>, dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 

@@ -98,6 +98,9 @@ template <bool CRC> struct srv_fast_io { /* the request header sits in LDS: read
   __device__ __forceinline__ bool abort_is(uint32_t w) const { return w == tag_; }
   __device__ __forceinline__ bool has_abort() const { return true; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
+  static constexpr bool pass_stamps = false;
+  static constexpr bool persistent = false;
+  __device__ __forceinline__ int fair_turns() const { return 0; }
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }
   /* one block per CU with as many waves as tasks: grouping short bit-node tasks buys nothing here, and the plain loop is

@@ -353,6 +353,49 @@ def test_full_size_batch_properties_device(hip):
     assert int(out0[torch.from_numpy(ok0).cuda()][:, :K // 8].max()) == 0
 
 
+@pytest.mark.parametrize("cfg", [(1, 384, 13, 257), (1, 384, 13, 701), (2, 384, 15, 513), (1, 352, 13, 300)])
+def test_persistent_launches_ragged_sizes_and_mixed_pass_counts(hip, cfg):
+    """Launches of more than one workgroup round of a one-workgroup-per-CU code run as persistent workgroups that draw
+    their blocks from a counter (ldpc_dec_fast_persist_kernel): block counts that do not fill the last round, noise levels
+    from "converges in 3 passes" to "never" mixed in one launch (every workgroup finishes its blocks at another time), the
+    launch repeated (the counter puts itself back) -- every block against the generic kernel, a sample against the oracle."""
+    import torch
+    BG, Z, R, n = cfg
+    K = (22 if BG == 1 else 10) * Z
+    ncol = hip.ldpc.NCOLS[(BG, R)]
+    g = torch.Generator(device="cuda").manual_seed(99 + n)
+    info = torch.randint(0, 256, (n, K // 8), dtype=torch.uint8, device="cuda", generator=g)
+    coded = torch.empty((n, (66 if BG == 1 else 50) * Z), dtype=torch.uint8, device="cuda")
+    hip.encode_batch_device(BG, Z, info, coded)
+    snr = torch.tensor([(-12.0, -1.0, 0.0, 0.5, 1.0, 2.0, 4.0)[i % 7] for i in range(n)], device="cuda")
+    sigma = (1.0 / torch.sqrt(2.0 * 10 ** (snr / 10.0)))[:, None]
+    y = 1.0 - 2.0 * coded.float() + sigma * torch.randn(coded.shape, device="cuda", generator=g)
+    llr = torch.zeros((n, ncol * Z), dtype=torch.int8, device="cuda")
+    llr[:, 2 * Z:] = torch.clamp(torch.floor(y / (sigma / 16.0)), -128, 127).to(torch.int8)
+    out = torch.zeros((n, hip.ldpc.out_bytes(BG, Z, R)), dtype=torch.uint8, device="cuda")
+    it = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out_g, it_g = torch.zeros_like(out), torch.zeros_like(it)
+    hip.decode_batch_device(BG, Z, R, llr, out_g, it_g, numMaxIter=8, kernel=1)
+    for rep in range(3):
+        out.zero_()
+        it.zero_()
+        hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=8)
+        torch.cuda.synchronize()
+        assert torch.equal(it, it_g), rep
+        assert torch.equal(out, out_g), rep
+    it_h = it.cpu().numpy()
+    assert len(set(it_h.tolist())) >= 3, np.bincount(it_h)       # the launch really mixes pass counts
+    llr_h, out_h = llr.cpu().numpy(), out.cpu().numpy()
+    for i in range(0, n, 41):
+        n_ref, out_ref = O.decode(BG, Z, R, llr_h[i], 8, vec=True)
+        assert n_ref == it_h[i] and np.array_equal(out_ref, out_h[i]), i
+    # a one-pass cap: no workgroup ever sees "this pass may be the last" before it is over
+    hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=0)
+    hip.decode_batch_device(BG, Z, R, llr, out_g, it_g, numMaxIter=0, kernel=1)
+    torch.cuda.synchronize()
+    assert torch.equal(it, it_g) and torch.equal(out, out_g)
+
+
 @pytest.mark.parametrize("cfg", [(1, 384, 13), (1, 96, 23), (2, 208, 15), (2, 64, 13), (1, 32, 89), (2, 16, 23)])
 def test_host_buffer_paths(hip, cfg):
     """LDPCdecoder_batch with mem = HOST: the decoder's workgroups pull their LLR rows over the link themselves -- from the

@@ -25,7 +25,7 @@ def child():
     pkg.LDPCinit()
     res = {}
     n = 1024
-    for BG, Z, R in CODES:
+    for BG, Z, R in (CODES[:1] if os.environ.get("AB_ONLY_R13") else CODES):
         g = torch.Generator(device="cuda").manual_seed(7)
         ncol = m.NCOLS[(BG, R)]
         K = (22 if BG == 1 else 10) * Z
