@@ -167,6 +167,20 @@ static void llr2bitPacked(int8_t *out, const int8_t *llrOut, uint32_t numLLR)
       ((uint8_t *)out)[i >> 3] |= (uint8_t)(0x80 >> (i & 7));
 }
 
+/* the three restated functions that have no generated text to be compared with, exported so that tests/test_ref_pin.py can
+ * run them beside a statement-by-statement reading of nrLDPC_cnProc.h:887-1946 and nrLDPC_bnProc.h:1321-1380 */
+uint32_t ref_hybrid_cnProcPc(const ref_dec_t *h, int Z, const int8_t *cnProcBuf, const int8_t *cnProcBufRes)
+{
+  return cnProcPc(h, Z, cnProcBuf, cnProcBufRes);
+}
+void ref_hybrid_llr2bit(int8_t *out, const int8_t *llrOut, uint32_t numLLR, int packed)
+{
+  if (packed)
+    llr2bitPacked(out, llrOut, numLLR);
+  else
+    llr2bit(out, llrOut, numLLR);
+}
+
 int ref_hybrid_decode(int BG, int Z, int R, int numMaxIter, int outMode,
                       int (*check_crc)(uint8_t *, uint32_t, uint8_t), int E, int crc_type, int deg1_generic,
                       const int8_t *p_llr_in, int8_t *p_out)

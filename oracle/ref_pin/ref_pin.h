@@ -75,6 +75,9 @@ uint32_t ref_max_num_llr(void);
 int ref_hybrid_decode(int BG, int Z, int R, int numMaxIter, int outMode,
                       int (*check_crc)(uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type), int E, int crc_type,
                       int deg1_generic, const int8_t *p_llr, int8_t *p_out);
+/* the hybrid's restated parity check and hard decision alone (tests: beside the reference's text read statement by statement) */
+uint32_t ref_hybrid_cnProcPc(const ref_dec_t *h, int Z, const int8_t *cnProcBuf, const int8_t *cnProcBufRes);
+void ref_hybrid_llr2bit(int8_t *out, const int8_t *llrOut, uint32_t numLLR, int packed);
 /* LDPCencoder of ldpc_encoder.c:44-252 with gen_code == 0: unpack, reference-compiled parity part, assemble.
  * in: block_length/8 bytes (MSB first); out: one bit per byte; returns the output length (:251), -1 = no generator. */
 int ref_ldpc_encoder_orig(const uint8_t *in, uint8_t *out, int BG, int Zc, int Kb, int block_length);

@@ -62,6 +62,10 @@ def lib():
             getattr(L, "ref_" + n).restype = None
         for n in ("size_cn_proc_buf", "size_bn_proc_buf", "max_num_llr"):
             getattr(L, "ref_" + n).restype = C.c_uint32
+        L.ref_hybrid_cnProcPc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_hybrid_cnProcPc.restype = C.c_uint32
+        L.ref_hybrid_llr2bit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.ref_hybrid_llr2bit.restype = None
         L.ref_hybrid_decode.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_ldpc_encoder_orig.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
         _lib = L

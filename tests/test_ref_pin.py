@@ -381,4 +381,234 @@ def test_the_recipe_holds_no_stand_ins():
         if f.suffix in (".c", ".h"):
             code = re.sub(r"/\*.*?\*/", "", f.read_text(), flags=re.S)
             assert not re.search(r"#\s*define\s+simde|typedef[^;]*simde_|simde_mm\w*\s*\(", code), f.name
-    assert RL.REFERENCE.exists() or not (pin / "nothing").exists()
+
+
+# ---- the GENERIC functions no generator writes: parity check [D7][F6], hard decision [D9], the pass loop [D8], read as text ------
+DEC_DIR = RL.REFERENCE / "openair1" / "PHY" / "CODING" / "nrLDPC_decoder"
+needs_reference_text = pytest.mark.skipif(not (DEC_DIR / "nrLDPC_cnProc.h").exists(), reason="reference tree not present")
+
+
+def _code(text):
+    """C text without comments and without white space"""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^[ \t]*#[^\n]*$", "", text, flags=re.M)       # preprocessor lines
+    return re.sub(r"\s+", "", text)
+
+
+def _function_body(text, signature_start):
+    """the text from `signature_start` to the closing brace of that function"""
+    a = text.index(signature_start)
+    while text.index(";", a) < text.index("{", a):          # a prototype: the definition follows
+        a = text.index(signature_start, a + 1)
+    depth, i = 0, text.index("{", a)
+    while True:
+        depth += text[i] == "{"
+        depth -= text[i] == "}"
+        i += 1
+        if depth == 0:
+            return text[a:i]
+
+
+@needs_reference_text
+@pytest.mark.parametrize("BG", [1, 2])
+def test_generic_parity_check_text_group_by_group_and_the_mrem_rule(BG):
+    """[D7][F6] nrLDPC_cnProcPc_BG1 / _BG2 (nrLDPC_cnProc.h:887-1526, 1528-1946), the function the shipped decoder calls for the
+    parity-check stop (decoder.c:842-846) and for which no generator exists.  Read statement by statement: EVERY check-node group
+    is `if (lut_numCnInCnGroups[g] > 0)`: M = numCn*Z lanes, Mrem = M & 31, M32 = ceil(M / 32); chunks 0 .. M32-2 in full,
+    pcRes ^= movemask_epi8(adds_epi8(cnProcBuf, cnProcBufRes)) over exactly the group's D bit nodes at word offsets j*OFF + i; the
+    LAST chunk with the same wiring, masked 0xFFFFFFFF >> (32 - Mrem) and counted ONLY `if (Mrem)` [F6]; early return of the group's
+    word.  D and OFF must be the group's degree and stride in the reference-compiled LUTs.  The text model is then EXECUTED (numpy) on
+    random buffers beside the hybrid's restatement -- which is what tests/golden/ref_decoder.npz was produced with."""
+    import re
+    text = (DEC_DIR / "nrLDPC_cnProc.h").read_text()
+    body = _code(_function_body(text, f"static inline uint32_t nrLDPC_cnProcPc_BG{BG}("))
+    head = (f"staticinlineuint32_tnrLDPC_cnProcPc_BG{BG}(t_nrLDPC_lut*p_lut,int8_t*cnProcBuf,int8_t*cnProcBufRes,uint16_tZ){{"
+            "constuint8_t*lut_numCnInCnGroups=p_lut->numCnInCnGroups;constuint32_t*lut_startAddrCnGroups=p_lut->startAddrCnGroups;"
+            "simde__m256i*p_cnProcBuf;simde__m256i*p_cnProcBufRes;uint32_tM;uint32_ti;uint32_tj;uint32_tpcRes=0;uint32_tpcResSum=0;"
+            "uint32_tMrem;uint32_tM32;simde__m256iymm0,ymm1;")
+    assert body.startswith(head), body[:400]
+    rest = body[len(head):]
+    inner = (r"for\(j=0;j<(?P<D{k}>\d+);j\+\+\)\{{ymm0=p_cnProcBuf\[j\*(?P<O{k}>\d+)\+i\];ymm1=p_cnProcBufRes\[j\*(?P<P{k}>\d+)\+i\];"
+             r"pcRes\^=simde_mm256_movemask_epi8\(simde_mm256_adds_epi8\(ymm0,ymm1\)\);\}}")
+    group = re.compile(
+        r"if\(lut_numCnInCnGroups\[(?P<g>\d+)\]>0\)\{pcResSum=0;M=lut_numCnInCnGroups\[(?P<g2>\d+)\]\*Z;Mrem=M&31;M32=\(M\+31\)>>5;"
+        r"p_cnProcBuf=\(simde__m256i\*\)&cnProcBuf\[lut_startAddrCnGroups\[(?P<g3>\d+)\]\];"
+        r"p_cnProcBufRes=\(simde__m256i\*\)&cnProcBufRes\[lut_startAddrCnGroups\[(?P<g4>\d+)\]\];"
+        r"for\(i=0;i<\(M32-1\);i\+\+\)\{pcRes=0;" + inner.format(k=1) + r"pcResSum\|=pcRes;\}"
+        r"pcRes=0;" + inner.format(k=2) +
+        r"if\(Mrem\)pcResSum\|=\(pcRes&\(0xFFFFFFFF>>\(32-Mrem\)\)\);if\(pcResSum>0\)\{returnpcResSum;\}\}")
+    groups, pos = [], 0
+    while True:
+        m = group.match(rest, pos)
+        if not m:
+            break
+        d = m.groupdict()
+        assert d["g"] == d["g2"] == d["g3"] == d["g4"] and d["D1"] == d["D2"] and len({d["O1"], d["P1"], d["O2"], d["P2"]}) == 1, d
+        groups.append((int(d["g"]), int(d["D1"]), int(d["O1"])))
+        pos = m.end()
+    assert rest[pos:] == "returnpcResSum;}", rest[pos:pos + 200]       # nothing else in the function
+    lut = _lut(BG, 13 if BG == 1 else 15)
+    assert [g for g, _, _ in groups] == list(range(lut["G"]))           # every group, in LUT order
+    for g, D, off in groups:
+        assert D == lut["bnInCn"][g] and off == lut["cnFull"][g] * 384 // 32, (g, D, off)
+    # ---- run the text's model beside the restatement --------------------------------------------------------------------------
+    L = RL.lib()
+    rng = np.random.default_rng(20 + BG)
+    ncn = L.ref_size_cn_proc_buf()
+
+    def text_model(numCn, start, Z, a, b):
+        sgn = (np.clip(a.astype(np.int16) + b.astype(np.int16), -128, 127) < 0)          # movemask(adds_epi8)
+        for g, D, off in groups:
+            if numCn[g] == 0:
+                continue
+            M = numCn[g] * Z
+            Mrem, M32 = M & 31, (M + 31) >> 5
+            word = 0
+            for i in range(M32):
+                pc = 0
+                for j in range(D):
+                    lanes = sgn[start[g] + 32 * (j * off + i):start[g] + 32 * (j * off + i) + 32]
+                    pc ^= int(np.packbits(lanes, bitorder="little").view(np.uint32)[0])
+                if i < M32 - 1:
+                    word |= pc
+                elif Mrem:
+                    word |= pc & (0xFFFFFFFF >> (32 - Mrem))
+            if word:
+                return word
+        return 0
+
+    seen_nonzero = seen_zero = seen_f6 = 0
+    for Z in (384, 352, 208, 36, 22, 13, 8, 2):
+        for R in RATES[BG]:
+            h = L.ref_dec_new(BG, Z, R)
+            if not h:
+                continue
+            G = L.ref_dec_numCnGroups(h)
+            numCn = [L.ref_dec_numCnInCnGroups(h)[g] for g in range(G)]
+            start = [L.ref_dec_startAddrCnGroups(h)[g] for g in range(G)]
+            for case in range(6):
+                a = np.zeros(ncn + 64, np.int8)
+                b = np.zeros(ncn + 64, np.int8)
+                if case < 2:     # dense random: some group fails
+                    a[:ncn] = rng.integers(-128, 128, ncn)
+                    b[:ncn] = rng.integers(-128, 128, ncn)
+                else:            # all satisfied, then ONE lane of ONE group flipped: in a counted chunk, or in the last chunk
+                    a[:ncn] = rng.integers(0, 128, ncn)
+                    b[:ncn] = rng.integers(0, 100, ncn)
+                    if case >= 3:
+                        live = [g for g in range(G) if numCn[g]]
+                        g = live[int(rng.integers(len(live)))]
+                        M = numCn[g] * Z
+                        lane = M - 1 - int(rng.integers(min(M, 32))) if case >= 4 else int(rng.integers(M))
+                        a[start[g] + lane] = -100
+                        seen_f6 += (M & 31) == 0 and lane >= M - 32
+                want = L.ref_hybrid_cnProcPc(h, Z, a.ctypes.data, b.ctypes.data)
+                got = text_model(numCn, start, Z, a, b)
+                assert got == want, (BG, Z, R, case, hex(got), hex(want))
+                seen_nonzero += want != 0
+                seen_zero += want == 0
+            L.ref_dec_free(h)
+    assert seen_nonzero > 20 and seen_zero > 20 and seen_f6 > 3, (seen_nonzero, seen_zero, seen_f6)
+
+
+@needs_reference_text
+def test_generic_hard_decision_text_and_bit_order():
+    """[D9] nrLDPC_llr2bit / nrLDPC_llr2bitPacked (nrLDPC_bnProc.h:1321-1345, 1353-1380) as text: bit = (0 > llr) per byte resp.
+    movemask of the byte-reversed-within-8 load -- bit 8b of the input in the MSB of output byte b -- for the numLLR >> 5 full
+    words, and a scalar tail `(p[i] < 0) << ((7 - i) + 16 * (i / 8))` written only `if (Mr)`.  The text's model runs beside the
+    hybrid's restatement for lengths with and without a tail."""
+    text = (DEC_DIR / "nrLDPC_bnProc.h").read_text()
+    b1 = _code(_function_body(text, "static inline void nrLDPC_llr2bit("))
+    assert b1 == ("staticinlinevoidnrLDPC_llr2bit(int8_t*out,int8_t*llrOut,uint16_tnumLLR){simde__m256i*p_llrOut=(simde__m256i*)llrOut;"
+                  "simde__m256i*p_out=(simde__m256i*)out;constuint32_tM=numLLR>>5;constuint32_tMr=numLLR&31;"
+                  "constsimde__m256i*p_zeros=(simde__m256i*)zeros256_epi8;constsimde__m256i*p_ones=(simde__m256i*)ones256_epi8;"
+                  "for(uint32_ti=0;i<M;i++){*p_out++=simde_mm256_and_si256(*p_ones,simde_mm256_cmpgt_epi8(*p_zeros,*p_llrOut));p_llrOut++;}"
+                  "int8_t*p_llrOut8=(int8_t*)p_llrOut;int8_t*p_out8=(int8_t*)p_out;for(uint32_ti=0;i<Mr;i++)p_out8[i]=p_llrOut8[i]<0;}"), b1
+    b2 = _code(_function_body(text, "static inline void nrLDPC_llr2bitPacked("))
+    assert b2 == ("staticinlinevoidnrLDPC_llr2bitPacked(int8_t*out,int8_t*llrOut,uint16_tnumLLR){"
+                  "constuint8_tconstShuffle_256_epi8[32]__attribute__((aligned(32)))={7,6,5,4,3,2,1,0,15,14,13,12,11,10,9,8,7,6,5,4,3,2,1,0,15,14,13,12,11,10,9,8};"
+                  "constsimde__m256i*p_shuffle=(simde__m256i*)constShuffle_256_epi8;simde__m256i*p_llrOut=(simde__m256i*)llrOut;"
+                  "uint32_t*p_bits=(uint32_t*)out;constuint32_tM=numLLR>>5;constuint32_tMr=numLLR&31;"
+                  "for(uint32_ti=0;i<M;i++){constsimde__m256iinPerm=simde_mm256_shuffle_epi8(*p_llrOut,*p_shuffle);"
+                  "*p_bits++=simde_mm256_movemask_epi8(inPerm);p_llrOut++;}"
+                  "if(Mr){constint8_t*p_llrOut8=(int8_t*)p_llrOut;uint32_tbitsTmp=0;"
+                  "for(uint32_ti=0;i<Mr;i++)bitsTmp|=(p_llrOut8[i]<0)<<((7-i)+(16*(i/8)));*p_bits=bitsTmp;}}"), b2
+    shuffle = [7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8] * 2      # (per 128-bit lane, as shuffle_epi8 works)
+
+    def packed_model(llr):
+        n = len(llr)
+        M, Mr = n >> 5, n & 31
+        words = []
+        for i in range(M):
+            w = llr[32 * i:32 * i + 32]
+            perm = np.concatenate([w[:16][shuffle[:16]], w[16:][shuffle[16:]]])
+            words.append(int(np.packbits(perm < 0, bitorder="little").view(np.uint32)[0]))
+        if Mr:
+            t = 0
+            for i in range(Mr):
+                t |= int(llr[32 * M + i] < 0) << ((7 - i) + 16 * (i // 8))
+            words.append(t)
+        return np.array(words, dtype=np.uint32).view(np.uint8)
+
+    L = RL.lib()
+    rng = np.random.default_rng(9)
+    for n in (64, 26112, 52 * 2, 68 * 3, 27 * 5, 35 * 7, 17 * 13, 32 * 9, 27 * 384):
+        llr = np.zeros(n + 64, np.int8)
+        llr[:n] = rng.integers(-128, 128, n)
+        out = np.full(n + 64, 0x5A, np.uint8)
+        L.ref_hybrid_llr2bit(out.ctypes.data, llr.ctypes.data, n, 1)
+        want = packed_model(llr[:n])
+        assert np.array_equal(out[:len(want)], want) and (out[len(want):] == 0x5A).all(), n
+        assert np.array_equal(np.unpackbits(want)[:n], (llr[:n] < 0).astype(np.uint8))       # = MSB first, as the oracle packs
+        L.ref_hybrid_llr2bit(out.ctypes.data, llr.ctypes.data, n, 0)
+        assert np.array_equal(out[:n], (llr[:n] < 0).astype(np.uint8)), n                   # and(ones, cmpgt(zeros, llr)) / llr < 0
+
+
+@needs_reference_text
+def test_pass_loop_text_of_the_decoder_core():
+    """[D8] + iteration control (a10, a12) as text, nrLDPC_decoder.c: the entry point aborts the transport block when the core
+    returns more than numMaxIter (:189-193); the core counts the unconditional first pass as 1 and loops
+    `while ((numIter <= numMaxIter) && (pcRes != 0))`, incrementing first, returning numMaxIter + 2 on an abort (:552-559); the
+    stop test at the end of a pass is cnProcPc when there is no predicate, else -- only `if (numIter > 2)` -- reorder, hard decision
+    in the caller's output mode INTO p_out, predicate on (p_out, E, crc_type), break (:841-861); the output is produced after the
+    loop only when there is no predicate (:864-879); the pass count is returned (:880).  The hybrid decoder and both oracle
+    restatements follow exactly this skeleton."""
+    text = (DEC_DIR / "nrLDPC_decoder.c").read_text()
+    entry = _code(_function_body(text, "int32_t LDPCdecoder(t_nrLDPC_dec_params* p_decParams,"))
+    assert ("numLLR=nrLDPC_init(p_decParams,p_lut);intnumIter=nrLDPC_decoder_core(p_llr,p_out,numLLR,p_lut,p_decParams,p_profiler,ab);"
+            "if(numIter>p_decParams->numMaxIter){") in entry and entry.endswith("set_abort(ab,true);}returnnumIter;}"), entry[-300:]
+    core = _code(_function_body(text, "static inline uint32_t nrLDPC_decoder_core(int8_t* p_llr,"))
+    order = [
+        "uint32_tnumIter=1;int32_tpcRes=1;while((numIter<=numMaxIter)&&(pcRes!=0)){numIter++;if(check_abort(ab)){numIter=numMaxIter+2;break;}",
+        "if(!p_decParams->check_crc){",
+        "if(BG==1)pcRes=nrLDPC_cnProcPc_BG1(p_lut,cnProcBuf,cnProcBufRes,Z);elsepcRes=nrLDPC_cnProcPc_BG2(p_lut,cnProcBuf,cnProcBufRes,Z);",
+        "}else{if(numIter>2){int8_tllrOut[NR_LDPC_MAX_NUM_LLR]__attribute__((aligned(64)))={0};"
+        "int8_t*p_llrOut=outMode==nrLDPC_outMode_LLRINT8?p_out:llrOut;nrLDPC_llrRes2llrOut(p_lut,p_llrOut,llrRes,Z,BG);"
+        "if(outMode==nrLDPC_outMode_BIT)nrLDPC_llr2bitPacked(p_out,p_llrOut,numLLR);elsenrLDPC_llr2bit(p_out,p_llrOut,numLLR);"
+        "if(p_decParams->check_crc((uint8_t*)p_out,p_decParams->E,p_decParams->crc_type)){",
+        "break;}}}}if(!p_decParams->check_crc){int8_tllrOut[NR_LDPC_MAX_NUM_LLR]__attribute__((aligned(64)))={0};"
+        "int8_t*p_llrOut=outMode==nrLDPC_outMode_LLRINT8?p_out:llrOut;",
+        "nrLDPC_llrRes2llrOut(p_lut,p_llrOut,llrRes,Z,BG);",
+        "if(outMode==nrLDPC_outMode_BIT)nrLDPC_llr2bitPacked(p_out,p_llrOut,numLLR);elsenrLDPC_llr2bit(p_out,p_llrOut,numLLR);",
+        "}returnnumIter;}",
+    ]
+    pos = 0
+    for frag in order:
+        at = core.find(frag, pos)
+        assert at >= 0, frag
+        pos = at + len(frag)
+    assert pos == len(core)                                            # the function ends with the last fragment
+    # nothing between the pieces of the stop test but profiler / debug macros
+    tail = core[core.index(order[1]):]
+    import re
+    between = tail
+    for frag in order[1:]:
+        between = between.replace(frag, "", 1)
+    between = re.sub(r"NR_LDPC_PROFILER_DETAIL\((start|stop)_meas\(&p_profiler->\w+\)\);", "", between)
+    between = re.sub(r"LOG_D\(PHY,\"[^\"]*\"\);", "", between)
+    assert between == "", between[:300]
+    # the first pass runs no parity check and the loop body holds exactly one call of each node function per base graph / rate
+    first = core[:core.index(order[0])]
+    assert "nrLDPC_cnProcPc" not in first and "check_crc" not in first
