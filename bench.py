@@ -187,6 +187,12 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
     if rank != 0:
         return None
     pay, ack, itm = out
+    # what the model of measured pieces says this N should cost (parallel.SLOT_MODEL) -- for the loopback run: the model of
+    # the V real ranks it stands in for, NOT of the loopback itself (one GPU decodes every share there)
+    shares_seg = [int(sum(segs[a:b])) for a, b in sh.tb_ranges]
+    shares_llr = [int(co[b] - co[a]) * 2 for a, b in sh.tb_ranges]
+    shares_res = [int(po[b] - po[a]) + 5 * int(b - a) for a, b in sh.tb_ranges]
+    pred = parallel.predict_slot_ms(shares_seg, shares_llr, shares_res, chunks=3)
     ok = bool(ack.all().item()) and all(torch.equal(pay[po[i]:po[i] + A // 8], payload[po[i]:po[i] + A // 8]) for i in range(n_tb))
     return {"loopback_virtual_ranks": loop, "rccl_p2p_bytes": int(sh.p2p_bytes), "rccl_p2p_bytes_per_slot": int(sh.p2p_bytes // (steps + 2)),
             "workload": "64 PUSCH transport blocks of one slot (273 PRB x 13 symbols, 64QAM, TBS 213 176 bit: 1664 code "
@@ -200,7 +206,18 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
                       "ms_per_slot_events_rank0: a HIP event pair on the chain's stream around the same K slots; "
                       "ms_per_slot_synchronised_each: one slot, synchronize, next slot",
             "ms_per_slot_events_rank0": ev_ms / steps, "ms_per_slot_synchronised_each": dt_each / steps * 1e3,
+            # (round 4's lines carried the synchronised figure under "ms_per_slot", round 5's the back-to-back one: both are
+            # spelled out now, "ms_per_slot" stays what round 5 made it and says so -- ADVICE r05)
+            "ms_per_slot_is": "back_to_back", "ms_per_slot_back_to_back": dt / steps * 1e3,
             "steps": steps, "ms_per_slot": dt / steps * 1e3, "info_gbps": n_tb * A * steps / dt / 1e9,
+            "info_gbps_synchronised_each": n_tb * A * steps / dt_each / 1e9,
+            "predicted_ms": pred["predicted_ms"], "predicted_ms_range": pred.get("predicted_ms_range"),
+            "prediction": {"for_ranks": len(shares_seg), "bound": pred["bound"], "assumptions": pred.get("assumptions"),
+                           "model": "openairinterface5g_amd/parallel.py predict_slot_ms: measured chain time by segments per call "
+                                    "(profiles/r05/tb_latency.txt) + RCCL group overhead from the loopback slot + ASSUMED 50 GB/s "
+                                    "per xGMI link and direction; N = 1: the chain call alone.  Weak scaling (the headline "
+                                    "`value`): N x the N = 1 figure, no exchange on the data path",
+                           "slowest_peer": pred.get("slowest_peer")},
             "coded_gbps": n_tb * G * steps / dt / 1e9, "llr_bytes_scattered": int(co[-1]) * 2,
             "all_ack_and_payload_equal": ok, "max_passes": int(itm.max().item())}
 

@@ -128,6 +128,12 @@ int32_t LDPCshutdown(void);
  * executable's build string contains <text>. */
 int32_t ldpc_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion);
 int32_t nrLDPC_hip_checkbuildver(char *mainexec_buildversion, char **shlib_buildversion); /* (what the offload-slot library forwards to) */
+/* Optional loader hook (common/utils/load_module_shlib.c:186-191, initfunc_t): called by load_module_version_shlib() after the
+ * version hook with the `initfunc_arg` of its caller -- NULL from load_LDPClib (nrLDPC_load.c:61).  NULL: nothing to do,
+ * returns 0 (the GPU is taken by LDPCinit, which the loader's caller runs next: nrLDPC_load.c:66-67).  A maintainer who passes
+ * an argument passes a C string with the GPU list in NRLDPC_HIP_DEVICES' format ("0", "2,3"): it is put into the environment
+ * for LDPCinit unless the variable is already set.  The loader ignores the return value. */
+int32_t ldpc_autoinit(void *arg);
 /* One code block, synchronous, host buffers.  p_llr: int8[ncols(BG,R)*Z] in base-graph column order, the two
  * punctured columns 0 and fillers +127 (callers: nr_ulsch_decoding.c:195-219, ldpctest.c:294-332).
  * Returns the number of passes executed; > numMaxIter means "not decoded" and sets *ab (decoder.c:190-193);
@@ -140,8 +146,10 @@ int32_t nrLDPC_hip_checkbuildver(char *mainexec_buildversion, char **shlib_build
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
 /* Up to 8 segments per call (ldpc_encoder_optim8segmulti.c:46-213): input[j] K/8 bytes MSB first,
- * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Returns 0, -1 on bad parameters (the
- * reference's callers ignore the value: nr_dlsch_coding.c:171).  Served by a resident kernel of its own, like the decoder
+ * output[j] one bit per byte, (BG1 ? 66 : 50)*Zc bytes = c[2Zc..K) || parity.  Return value: that of the DEFAULT reference
+ * library, ldpc_encoder_optim8segmulti.c:213 -- 0, and -1 on bad parameters (:88-100 there) -- not the output length that
+ * ldpc_encoder.c:251 (`libldpc_orig.so`) returns; the reference's callers ignore the value (nr_dlsch_coding.c:171,
+ * nr_ulsch_coding.c:167, ldpctest.c:265-282), tests/test_gpu_encoder.py asserts the 0.  Served by a resident kernel of its own, like the decoder
  * (NRLDPC_HIP_ENC_SERVER=0: one launch per call). */
 int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *impp);
 
@@ -155,7 +163,7 @@ int32_t LDPCencoder(uint8_t **input, uint8_t **output, encoder_implemparams_t *i
  * harq_process->d[r]) while the LLRs of a slot arrive in host memory (nr_ulsch_decoding(..., short *ulsch_llr, ...), :320):
  * with NRLDPC_HIP_MEM_HOST | NRLDPC_HIP_MEM_HARQ_DEVICE or ..._HARQ_LIBRARY a call moves the slot's LLRs over the link once
  * and nothing else -- the soft buffers never leave the GPU. */
-#define NRLDPC_HIP_MEM_HARQ_DEVICE 2  /* b->harq is device memory (hipMalloc) on the library's GPU whatever bit 0 says */
+#define NRLDPC_HIP_MEM_HARQ_DEVICE 2  /* b->harq is device memory (hipMalloc, or hipMallocManaged) on the library's GPU whatever bit 0 says */
 #define NRLDPC_HIP_MEM_HARQ_LIBRARY 4 /* b->harq is ignored: the library keeps the soft buffers in GPU memory of its own, one
                                        * set of C x harq_stride int16 per transport block, found by tb[i].harq_off used as an
                                        * opaque 64-bit id chosen by the caller (e.g. ulsch_id << 8 | harq_pid -- the way the T2

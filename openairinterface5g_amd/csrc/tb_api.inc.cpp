@@ -582,7 +582,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         return -1;
       out = c.coded_h.p - cod_lo;
       if (pl.out_dense) {
-        c.fin_copies.push_back(TbCtx::FinCopy{hc + cod_lo, c.coded_h.p, cod_n, 1, 0, 0, nullptr});
+        c.fin_copies.push_back(TbCtx::FinCopy{hc + cod_lo, c.coded_h.p, cod_n, 1, cod_n, cod_n, nullptr}); /* (one contiguous block: cut over the helpers) */
       } else {
         for (const TbPlan::OutRun &r : pl.out_runs)
           c.fin_copies.push_back(TbCtx::FinCopy{hc + r.first, out + r.first, r.width, r.rows, r.pitch, r.pitch, nullptr});
@@ -695,7 +695,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   if (!harq_lib && (!staged || (b->mem & (NRLDPC_HIP_MEM_HARQ_DEVICE | NRLDPC_HIP_MEM_DEVICE)))) {
     hipPointerAttribute_t at;
     bool harq_is_dev = false;
-    if (hipPointerGetAttributes(&at, b->harq) == hipSuccess && at.type == hipMemoryTypeDevice) {
+    /* (hipMalloc memory, or hipMallocManaged memory -- the kernels and the peer copies reach both: ADVICE r05) */
+    if (hipPointerGetAttributes(&at, b->harq) == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) {
       harq_is_dev = true;
       harq_here = at.device == G().id;
     } else {

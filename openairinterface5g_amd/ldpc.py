@@ -88,7 +88,7 @@ def device_crc_pointer():
     evaluates (as the host executable's own `check_crc` does); any other pointer is called on the host (nrLDPC_hip.h)."""
     return C.cast(load_library().nrLDPC_hip_check_crc, C.c_void_p).value
 
-EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "LDPCdecoder_batch", "LDPCencoder_batch",
+EXPORTS = ["LDPCinit", "LDPCshutdown", "LDPCdecoder", "LDPCencoder", "ldpc_checkbuildver", "ldpc_autoinit", "LDPCdecoder_batch", "LDPCencoder_batch",
            "LDPCdecoder_jobs", "nrLDPC_hip_checkbuildver", "nrLDPC_hip_check_crc",
            "nrLDPC_hip_num_llr", "nrLDPC_hip_out_bytes", "nrLDPC_hip_lds_bytes", "nrLDPC_hip_code_info", "nrLDPC_hip_last_error",
            "nrLDPC_hip_version", "nrLDPC_hip_server_stats"]
@@ -182,7 +182,8 @@ def make_dec_params(BG, Z, R, numMaxIter=8, outMode=nrLDPC_outMode_BIT, check_cr
     p = t_nrLDPC_dec_params(BG=BG, Z=Z, R=R, numMaxIter=numMaxIter, outMode=outMode, E=E, crc_type=crc_type)
     if callable(check_crc):      # a caller's own predicate (decoded_bytes_ptr, n, crc_type) -> int: called on the host
         cb = CHECK_CRC_T(check_crc)
-        _user_predicates.append(cb)
+        p._check_crc_keepalive = cb      # lives as long as the parameter block that points at it ...
+        _user_predicates.append(cb)      # ... and a little longer for by-value copies of the block (job arrays)
         del _user_predicates[:-64]
         p.check_crc = C.cast(cb, C.c_void_p)
     elif check_crc:
@@ -239,6 +240,8 @@ def LDPCencoder(inputs, BG, Zc, Kb=None, n_segments=None, macro_num=0, meters=No
         impp.tinput, impp.tprep, impp.tparity, impp.toutput = (C.addressof(m) for m in meters)
     rc = L.LDPCencoder(ip, op, C.byref(impp))
     _check(rc, "LDPCencoder")
+    if rc != 0:     # the default reference library's value (ldpc_encoder_optim8segmulti.c:213), not ldpc_encoder.c:251's length
+        raise RuntimeError(f"LDPCencoder returned {rc}, expected 0")
     N = (66 if BG == 1 else 50) * Zc if block_length is None else (3 if BG == 1 else 5) * block_length
     return [o[:N] for o in outs]
 

@@ -146,6 +146,84 @@ def decode_sharded(BG: int, Z: int, R: int, llr_root, n_blocks: int, numMaxIter:
     return out_all.reshape(n_blocks, ob), it_all
 
 
+# ---- what a slot cut over N GPUs should cost: written down BEFORE hardware measures it -----------------------------------
+# Every number is either measured on one MI355X (file named) or an assumption (marked); bench.py puts the prediction for its N
+# into the line (strong_scaling_slot.predicted_ms), so that the first real N > 1 record can be read against it.
+SLOT_MODEL = {
+    # UL-SCH chain, device resident, one call: microseconds by code segments in the call (BG1 Zc = 384, 64QAM, 3 passes to the
+    # CRC): profiles/r05/tb_latency.txt (1 .. 64 transport blocks of 26 segments) -- the slot of 64 blocks back to back: 166 us
+    "chain_us_by_segments": [(26, 45.1), (52, 45.6), (104, 46.7), (208, 48.7), (416, 63.6), (832, 108.8), (1664, 166.0)],
+    # one batch_isend_irecv group through RCCL (Python, group launch, stream ordering): from the loopback slot of
+    # profiles/r05/bench_dist1.json -- 1409 us per slot with 4 virtual ranks = 12 groups + 10 chain calls of 423 us in total +
+    # 47.5 MB of device-local copies (~45 us): (1409 - 423 - 45) / 12
+    # -- an UPPER bound for a real rank: in the loopback run one process posts BOTH ends of every pair
+    "group_us": 78.0,
+    "group_us_low": 39.0,        # ASSUMPTION for the lower end of the prediction: half of it (a rank posts one end only)
+    # ASSUMPTION: one xGMI link, one direction, through RCCL send / receive: 50 GB/s (peak 76.8 GB/s per direction per link;
+    # the root reaches every peer over a link of its own, /opt/skills/guides/MI355X_MICROARCH.md).  Not measurable on a 1-GPU box.
+    "link_GBps": 50.0,
+}
+
+
+def _chain_us(segments: float) -> float:
+    pts = SLOT_MODEL["chain_us_by_segments"]
+    if segments <= 0:
+        return 0.0
+    if segments <= pts[0][0]:
+        return pts[0][1]
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if segments <= x1:
+            return y0 + (y1 - y0) * (segments - x0) / (x1 - x0)
+    (x0, y0), (x1, y1) = pts[-2], pts[-1]
+    return y1 + (y1 - y0) / (x1 - x0) * (segments - x1)          # beyond a slot: the last slope (full workgroup rounds)
+
+
+def predict_slot_ms(segments_per_rank: Sequence[int], llr_bytes_per_rank: Sequence[int], result_bytes_per_rank: Sequence[int],
+                    chunks: int = 3, root: int = 0) -> dict:
+    """ShardedUlsch.decode() of one slot on len(segments_per_rank) GPUs as a timeline of measured pieces (SLOT_MODEL):
+    the root posts `chunks` send groups one after the other (group_us each on its host thread), every peer's chunk k is on
+    its link from the moment its group is posted and the chunk before it has left (bytes / link_GBps), a peer decodes chunk
+    k when it has arrived and the chunk before it is decoded (chain_us of the chunk's segments), returns it with one more
+    group; the root decodes its own range meanwhile.  The slot is done when the root has its own range and every peer's
+    last results.  N = 1: the chain call alone."""
+    world = len(segments_per_rank)
+    if SLOT_MODEL.get("_inner") is None and world > 1:        # the range [group_us_low, group_us]: predicted_ms is its upper end
+        SLOT_MODEL["_inner"] = True
+        try:
+            hi = predict_slot_ms(segments_per_rank, llr_bytes_per_rank, result_bytes_per_rank, chunks, root)
+            keep = SLOT_MODEL["group_us"]
+            SLOT_MODEL["group_us"] = SLOT_MODEL["group_us_low"]
+            lo = predict_slot_ms(segments_per_rank, llr_bytes_per_rank, result_bytes_per_rank, chunks, root)
+            SLOT_MODEL["group_us"] = keep
+        finally:
+            SLOT_MODEL["_inner"] = None
+        hi["predicted_ms_range"] = [lo["predicted_ms"], hi["predicted_ms"]]
+        return hi
+    g, rate = SLOT_MODEL["group_us"], SLOT_MODEL["link_GBps"] * 1e3          # bytes per microsecond
+    own = _chain_us(segments_per_rank[root])
+    if world == 1:
+        return {"predicted_ms": own / 1e3, "root_chain_us": own, "bound": "compute"}
+    posted = [g * (k + 1) for k in range(chunks)]
+    root_done = posted[-1] + own                        # (its own call is enqueued behind the last send group)
+    worst, detail = 0.0, []
+    for r in range(world):
+        if r == root or segments_per_rank[r] == 0:
+            continue
+        arrive = dec_end = 0.0
+        seg_k, byt_k = segments_per_rank[r] / chunks, llr_bytes_per_rank[r] / chunks
+        for k in range(chunks):
+            arrive = max(posted[k], arrive) + byt_k / rate
+            dec_end = max(arrive, dec_end) + _chain_us(seg_k)
+        back = dec_end + g + result_bytes_per_rank[r] / chunks / rate
+        detail.append({"rank": r, "last_chunk_arrives_us": arrive, "decoded_us": dec_end, "results_on_root_us": back})
+        worst = max(worst, back)
+    total = max(root_done, worst)
+    link_only = max(llr_bytes_per_rank[r] for r in range(world) if r != root) / rate
+    return {"predicted_ms": total / 1e3, "root_chain_us": own, "root_done_us": root_done, "slowest_peer": max(detail, key=lambda d: d["results_on_root_us"]),
+            "link_time_us": link_only, "bound": "link + group overhead" if worst > root_done else "root compute",
+            "assumptions": {"group_us": g, "link_GBps": SLOT_MODEL["link_GBps"]}}
+
+
 # ---- a slot's transport blocks (BASELINE configs[4]) -------------------------------------------------------------------
 class _DistTransport:
     """point-to-point through torch.distributed (nccl = RCCL on ROCm, gloo on CPU)"""

@@ -74,6 +74,23 @@ def test_loader_version_hook(built):
         assert r.stdout.split()[0] == str(rc) and "libldpc_hip" in r.stdout and "gfx950" in r.stdout, (need, r.stdout, r.stderr)
 
 
+def test_loader_autoinit_hook(built):
+    """ldpc_autoinit, the loader's second optional hook (load_module_shlib.c:186-191): NULL -- what load_LDPClib passes
+    (nrLDPC_load.c:61) -- is a no-op; a GPU list goes into NRLDPC_HIP_DEVICES unless the variable is set; anything else is refused."""
+    import os
+    import sys
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, %r); import openairinterface5g_amd as p; L = p.load_library();"
+            "L.ldpc_autoinit.argtypes = [C.c_void_p]; libc = C.CDLL(None); libc.getenv.restype = C.c_char_p;"
+            "a = L.ldpc_autoinit(None); e0 = libc.getenv(b'NRLDPC_HIP_DEVICES');"
+            "s = C.create_string_buffer(b'2,3'); b = L.ldpc_autoinit(C.cast(s, C.c_void_p)); e1 = libc.getenv(b'NRLDPC_HIP_DEVICES');"
+            "t = C.create_string_buffer(b'5'); c = L.ldpc_autoinit(C.cast(t, C.c_void_p)); e2 = libc.getenv(b'NRLDPC_HIP_DEVICES');"
+            "u = C.create_string_buffer(b'gpu0'); d = L.ldpc_autoinit(C.cast(u, C.c_void_p));"
+            "print(a, e0, b, e1, c, e2, d)" % str(ROOT))
+    env = {k: v for k, v in os.environ.items() if k != "NRLDPC_HIP_DEVICES"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.stdout.split() == ["0", "None", "0", "b'2,3'", "0", "b'2,3'", "-1"], (r.stdout, r.stderr)
+
+
 def test_introspection_without_gpu(built):
     import openairinterface5g_amd as pkg
     L = pkg.load_library()

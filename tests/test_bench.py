@@ -51,6 +51,9 @@ def test_rccl_path_runs_on_one_gpu(hip):
     assert line["roofline"]["traffic_source"].startswith("profiles/hbm_traffic.json") and 0 < line["roofline"]["binding_resource"]["overhead_frac"] < 1
     assert len(line["ms_per_step_per_rank"]) == 1 and len(s["ms_per_slot_per_rank"]) == 1
     assert s["ms_per_slot_events_rank0"] <= s["ms_per_slot"] * 1.05 and s["ms_per_slot_synchronised_each"] > 0
+    assert s["ms_per_slot_is"] == "back_to_back" and s["ms_per_slot_back_to_back"] == s["ms_per_slot"]
+    # the prediction written down for the N = 4 ranks this loopback stands in for (parallel.predict_slot_ms)
+    assert s["prediction"]["for_ranks"] == 4 and 0.2 < s["predicted_ms_range"][0] <= s["predicted_ms"] < 1.0
 
 
 @pytest.mark.gpu
@@ -72,8 +75,12 @@ def test_rccl_path_with_eight_virtual_ranks(hip):
 @pytest.mark.gpu
 def test_plain_single_process_line(hip):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_FORCE_DIST")}
-    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-strong"], capture_output=True, text=True, env=env, timeout=900)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-chain"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["rccl_ranks"] == 0 and line["n_gpus"] == 1 and line["metric"] == "ldpc_decoder_coded_throughput"
+    # N = 1: the slot's prediction is the measured chain call itself (parallel.SLOT_MODEL) -- the line must agree with it
+    s = line["strong_scaling_slot"]
+    assert s["prediction"]["for_ranks"] == 1 and s["predicted_ms_range"] is None
+    assert abs(s["predicted_ms"] / s["ms_per_slot_events_rank0"] - 1.0) < 0.10, (s["predicted_ms"], s["ms_per_slot_events_rank0"])

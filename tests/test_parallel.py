@@ -252,3 +252,28 @@ def test_transport_blocks_loopback_one_process(built):
     p.join(300)
     assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def test_slot_prediction_model():
+    """parallel.predict_slot_ms: the N = 1 figure is the measured chain call; cutting the slot over N GPUs from ONE root is
+    bounded by the root's links and the point-to-point groups, not by the decoders -- more ranks never cost more, the lower end
+    of the range never exceeds the upper, and with free communication the prediction falls back to the per-rank chain time."""
+    from openairinterface5g_amd import parallel as P
+    res = {}
+    for N in (1, 2, 4, 8):
+        seg, llr, back = [1664 // N] * N, [31451136 // N] * N, [64 * 26650 // N] * N
+        res[N] = P.predict_slot_ms(seg, llr, back)
+    assert abs(res[1]["predicted_ms"] - 0.166) < 1e-9 and res[1]["bound"] == "compute"
+    assert res[2]["predicted_ms"] > res[4]["predicted_ms"] > res[8]["predicted_ms"] > res[1]["predicted_ms"]
+    for N in (2, 4, 8):
+        lo, hi = res[N]["predicted_ms_range"]
+        assert lo <= hi == res[N]["predicted_ms"] and res[N]["bound"].startswith("link")
+        assert res[N]["link_time_us"] == pytest.approx(31451136 / N / 50e3)
+    keep = dict(P.SLOT_MODEL)
+    try:
+        P.SLOT_MODEL.update(group_us=0.0, group_us_low=0.0, link_GBps=1e9)
+        free = P.predict_slot_ms([208] * 8, [31451136 // 8] * 8, [213200] * 8)
+        assert free["predicted_ms"] == pytest.approx(max(P._chain_us(208), 3 * P._chain_us(208 / 3)) / 1e3)
+    finally:
+        P.SLOT_MODEL.clear()
+        P.SLOT_MODEL.update(keep)
