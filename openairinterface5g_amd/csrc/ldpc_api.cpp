@@ -70,7 +70,6 @@ struct CodeEntry {
 };
 
 #define NRLDPC_HIP_MAX_DEVICES 16
-#define NRLDPC_HIP_DRAW_SLOTS 256
 
 /* One per logical device: everything that lives in a GPU's memory.  NRLDPC_HIP_DEVICES=0,1,... lists the GPUs the
  * host-buffer entry points shard their batches over (whole code blocks / whole transport blocks per GPU, no data-path
@@ -83,24 +82,6 @@ struct Device {
   std::atomic<CodeEntry *> code_tbl[2][385][3]; /* published entries, [BG-1][Z][rate index]: read without a lock */
   uint32_t *crc_pow[4] = {nullptr, nullptr, nullptr, nullptr}; /* CRC24_A, CRC24_B, CRC16, CRC8: x^j mod g, j < 8448 */
   uint32_t *crc_pow_24a_long = nullptr;                        /* CRC24_A up to a whole transport block */
-  /* block counters of the persistent decoder launches, one pair per stream that has launched one: launches of one stream
-   * follow each other, so a pair is never shared by two kernels in flight; a pair zeroes itself (ldpc_dec_fast_persist_kernel) */
-  uint32_t *draw_ctr = nullptr;
-  std::mutex draw_mu;
-  std::vector<hipStream_t> draw_owner;
-  uint32_t *draw_for(hipStream_t s)
-  {
-    std::lock_guard<std::mutex> lk(draw_mu);
-    if (!draw_ctr)
-      return nullptr;
-    for (size_t i = 0; i < draw_owner.size(); i++)
-      if (draw_owner[i] == s)
-        return draw_ctr + 2 * i;
-    if (draw_owner.size() >= NRLDPC_HIP_DRAW_SLOTS)
-      return nullptr;
-    draw_owner.push_back(s);
-    return draw_ctr + 2 * (draw_owner.size() - 1);
-  }
 };
 
 struct Library {
@@ -173,8 +154,6 @@ int device_init_locked(Device &d, int ordinal)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.crc_pow_24a_long), t.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(d.crc_pow_24a_long, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.draw_ctr), 2 * NRLDPC_HIP_DRAW_SLOTS * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(d.draw_ctr, 0, 2 * NRLDPC_HIP_DRAW_SLOTS * sizeof(uint32_t)));
   d.ready = true;
   if (prev >= 0)
     (void)hipSetDevice(prev);
@@ -677,21 +656,11 @@ int launch_decoder(int kernel, ldpc_dec_args a, const CodeEntry *ce, uint32_t n_
       HIP_TRY(hipMemsetAsync(trace_d, 0, (size_t)n_blocks * 256, s));
       a.trace = static_cast<unsigned long long *>(trace_d);
     }
-    /* launches of more than one workgroup round: persistent workgroups that draw their blocks (NRLDPC_HIP_PERSIST=0: off) */
-    static const int persist_env = [] { const char *e = getenv("NRLDPC_HIP_PERSIST"); return e ? atoi(e) : 1; }();
     const ldpc_code_desc_t &hsel = lat ? ce->host_lat : ce->host;
-    const uint32_t slots = (uint32_t)(G().n_cus * hsel.f_wg_per_cu);
     /* workgroups that share a CU take turns at the issue priority (ldpc_dec_fast_block.h; NRLDPC_HIP_FAIR=0: off) */
     static const int fair_env = [] { const char *e = getenv("NRLDPC_HIP_FAIR"); return e ? atoi(e) : 1; }();
     if (fair_env && hsel.f_wg_per_cu >= 2 && n_blocks > (uint32_t)G().n_cus && hsel.f_n_threads >= 256)
       a.fair = hsel.f_n_threads / 256; /* waves per SIMD of one workgroup */
-    uint32_t *draw = nullptr;
-    /* (one workgroup per CU only: where several share a CU the hardware's dispatcher does as well -- profiles/r06/README.md;
-     * parity-check stop only: the CRC check's registers would put the persistent loop into scratch memory) */
-    if (persist_env && !lat && !a.jobs && !a.use_crc && hsel.f_wg_per_cu == 1 && n_blocks > slots && (draw = G().draw_for(s)) != nullptr) {
-      a.draw = draw;
-      HIP_TRY(ldpc_launch_dec_fast_persist(a, hsel, n_blocks, slots, s));
-    } else
     HIP_TRY(ldpc_launch_dec_fast(a, hsel, n_blocks, s));
     if (trace_d) {
       std::vector<unsigned long long> h((size_t)n_blocks * 32);
@@ -747,7 +716,6 @@ int fill_dec_args(const t_nrLDPC_dec_params &p, const CodeEntry *ce, ldpc_dec_ar
   a.n_blocks = 0;
   a.pull_stagger_ticks = a.pull_first_round = 0;
   a.trace = nullptr;
-  a.draw = nullptr;
   a.fair = 0;
   for (int i = 0; i < 4; i++)
     a.crc_pow_tbl[i] = G().crc_pow[i];

@@ -55,11 +55,6 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *   bool tb_fused()           ... and does so for this block: instead of an output row, io.tb_finish(n_iter, bits_word,
  *                             flags) delivers the segment's payload bytes, its share of the TB CRC and -- from the last
  *                             segment of a transport block to finish -- the block's verdict
- *   static bool persistent    the caller is a persistent workgroup that draws its blocks from a counter
- *                             (ldpc_dec_fast_persist_kernel): towards the likely end of a block the body draws the next block's
- *                             index (io.draw_issue / io.draw_publish) and requests its LLRs (io.prefetch: loads into
- *                             registers that the next call's prologue takes with io.take_prefetch), so that the trip to HBM
- *                             runs under this block's parity sweep / CRC check and hard decision
  *   int fair_turns()          0, or: the workgroup shares its CU with others of its kind and has this many waves per SIMD -- it
  *                             takes turns with them at the issue priority, pass by pass (see below)
  *   bool eager_check()        latency path: evaluate the parity check of a pass in a sweep of its own right after the
@@ -124,10 +119,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
    * otherwise sit behind a trip over the link. */
   const int n_app = ncore * zq, n_ext = ext_global ? 0 : (code->ncols - ncore) * zq;
   uint32_t va[4], ve[4];
-  bool prefetched = false;
-  if constexpr (IO::persistent)
-    prefetched = io.take_prefetch(va, ve);
-  if (!stage && !prefetched) {
+  if (!stage) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int ia = tid + k * nt;
@@ -244,8 +236,6 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       else
         __builtin_amdgcn_s_setprio(0);
     }
-    if constexpr (IO::persistent)
-      io.drop_prefetch(); /* (requested behind the previous pass, which did not turn out to be the last: asked for again later) */
     const uint32_t ab_word = (io.has_abort() && tid == 0 && p >= 2) ? io.abort_load() : 0u; /* in flight during the check-node phase */
     /* likewise the transport block's flag (a load that leaves the caches: its latency would otherwise sit between the
      * check-node phase and the barrier, once per pass) */
@@ -271,10 +261,34 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     int task = cn_ticket;
     for (; task < n_cn_tasks; task = ldpc_draw(pq, lane)) {
       LDPC_TLOG_BEGIN();
-      const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+      const int deg_f = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
       const int item = code->f_cn_task[task][2] + lane;
       const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
-      if (item < gend) {
+      const int deg = deg_f & 0xff;
+      if (deg_f & 0x100) {
+        /* a double task (ldpc_graph.h f_cn_task): items lane and lane + 64 of 128 consecutive ones, walked together; a
+         * thread without a second item takes its first one twice (the same bytes are stored twice) */
+        if (item < gend) {
+          const int item_b = item + 64 < gend ? item + 64 : item;
+          const int gia = item - gstart, gib = item_b - gstart;
+          const int riga = (int)ldpc_umulhi((uint32_t)gia, zq_magic), ja = gia - riga * zq;
+          const int rigb = (int)ldpc_umulhi((uint32_t)gib, zq_magic), jb = gib - rigb * zq;
+          const uint32_t reca = rowtbl[srow0 + riga], recb = rowtbl[srow0 + rigb];
+          const int e0a = (int)(reca & 0x1ffu), e0b = (int)(recb & 0x1ffu);
+          const int valida = (int)(reca >> 16) - 4 * ja, validb = (int)(recb >> 16) - 4 * jb;
+          uint32_t ma = 0, mb = 0;
+          if (p == 1)
+            (void)ldpc_fast_cn2_dispatch<true>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
+          else
+            ma = ldpc_fast_cn2_dispatch<false>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
+          const uint32_t maska = valida >= 4 ? 0xfu : (valida <= 0 ? 0u : ((1u << valida) - 1u));
+          const uint32_t maskb = validb >= 4 ? 0xfu : (validb <= 0 ? 0u : ((1u << validb) - 1u));
+          if constexpr (IO::syndrome)
+            syn |= (ma & maska) | (mb & maskb);
+          else
+            (void)ma, (void)mb, (void)maska, (void)maskb;
+        }
+      } else if (item < gend) {
         /* degree-19 rows: an item is shared by two neighbouring lanes (ldpc_graph.h f_pair19) */
         const bool pair = deg == 19 && code->f_pair19;
         const int gi = pair ? (item - gstart) >> 1 : item - gstart, half = (item - gstart) & 1;
@@ -349,16 +363,6 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       n_iter = p - 1;
       break;
     }
-    /* persistent workgroups: is this pass likely to be the block's last?  (the last one allowed; a CRC check follows; the
-     * parity sweep follows.)  Then the next block's index is drawn now -- the atomic's trip runs under the bit-node phase -- and
-     * its LLRs are requested behind the phase's barrier */
-    bool ending = false;
-    if constexpr (IO::persistent) {
-      ending = p == max_pass || (io.use_crc() ? p >= 3 : (p >= 2 && bad_prev <= LDPC_EAGER_MAX_BAD_LANES));
-      if (ending)
-        io.draw_issue(tid);
-    }
-    (void)ending;
 #ifndef LDPC_ABLATE_BN
     if constexpr (IO::bn_tickets) {
     /* the next ticket is asked for behind an item's gather and looked at behind its store: the draw's round trip runs
@@ -421,15 +425,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     cn_ticket = ldpc_draw(&flags[8 + ((p + 1) & 1)], lane);
     if (tid == 0)
       flags[(p + 1) & 1] = 0;
-    if constexpr (IO::persistent) {
-      if (ending)
-        io.draw_publish(tid, flags);
-    }
     __syncthreads();
-    if constexpr (IO::persistent) {
-      if (ending)
-        io.prefetch(flags, tid, nt, n_app, n_ext);
-    }
     if constexpr (IO::pass_stamps) {
       if (tid == 0 && p <= 9)
         io.stamps()[2 * p + 1] = (uint32_t)wall_clock64();

@@ -335,6 +335,120 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
   return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
 }
 
+/* TWO items of one degree group per thread (a double task, ldpc_graph.h f_cn_task), walked edge by edge TOGETHER: the same
+ * arithmetic as ldpc_fast_cn_ps with an item index on everything, so that the two chains of table entry -> window ->
+ * arithmetic -> store overlap inside one wave.  e0x / jx = first edge and 4-lane group of item x; returns item A's mask, item
+ * B's in mask_b.  (An inactive second item is given item A's coordinates by the caller: it then stores the same bytes
+ * twice.) */
+template <int D, bool EXT, bool P1 = false>
+LDPC_HD uint32_t ldpc_fast_cn_ps2(const ldpc_fast_lds &L, int e0a, int ja, int e0b, int jb, int Z, int rstride, uint32_t &mask_b)
+{
+  constexpr int N = 2, NP = D / 2;
+  const int e0[N] = {e0a, e0b}, t[N] = {4 * ja, 4 * jb};
+  uint32_t m_lo[N][D], m_hi[N][D], p_lo[N][NP > 0 ? NP : 1], p_hi[N][NP > 0 ? NP : 1], s4[N][D];
+  const ldpc_v2u cap = ldpc_splatu(0x8000 + 127);
+  uint32_t sx4[N] = {0, 0}, parw[N] = {0, 0}, extl[N] = {0, 0}, exth[N] = {0, 0};
+  uint8_t *rrow[N], *rpad[N];
+#pragma unroll
+  for (int n = 0; n < N; n++) {
+    rrow[n] = L.r + e0[n] * rstride + t[n];
+    rpad[n] = rrow[n] + (t[n] == 0 ? Z : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    uint32_t info[N], rw[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      info[n] = L.etbl[e0[n] + k];
+      rw[n] = P1 ? 0u : *reinterpret_cast<const uint32_t *>(rrow[n] + k * rstride);
+    }
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      uint32_t dl, dh;
+      if (EXT && k == D - 1)
+        ldpc_fast_cn_edge<true, P1>(L, info[n], t[n], rw[n], true, dl, dh, parw[n], extl[n], exth[n]);
+      else
+        ldpc_fast_cn_edge<false, P1>(L, info[n], t[n], rw[n], true, dl, dh, parw[n], extl[n], exth[n]);
+      const ldpc_v2u ml = ldpc_pmaxu(ldpc_as_v2u(dl), ldpc_as_v2u(0x00010000u - dl));
+      const ldpc_v2u mh = ldpc_pmaxu(ldpc_as_v2u(dh), ldpc_as_v2u(0x00010000u - dh));
+      m_lo[n][k] = ldpc_u2u32(ml);
+      m_hi[n][k] = ldpc_u2u32(mh);
+      s4[n][k] = ldpc_perm(dh, dl, 0x07050301u);
+      sx4[n] ^= s4[n][k];
+      if ((k & 1) && k < D - 1) {
+        const int i = k / 2;
+        p_lo[n][i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_lo[n][i - 1]) : cap, ldpc_as_v2u(m_lo[n][k - 1]), ml));
+        p_hi[n][i] = ldpc_u2u32(ldpc_pmin3_keys(i ? ldpc_as_v2u(p_hi[n][i - 1]) : cap, ldpc_as_v2u(m_hi[n][k - 1]), mh));
+      }
+    }
+  }
+  if (!((D - 1) & 1)) {
+    sx4[0] ^= 0x80808080u;
+    sx4[1] ^= 0x80808080u;
+  }
+  auto put = [&](int n, int k, ldpc_v2u ol, ldpc_v2u oh) {
+    const uint32_t o4 = ldpc_perm(ldpc_u2u32(oh), ldpc_u2u32(ol), 0x06040200u);
+    const uint32_t x4 = sx4[n] ^ s4[n][k];
+    const uint32_t w = (o4 ^ x4) + (x4 & 0x01010101u);
+    *reinterpret_cast<uint32_t *>(rrow[n] + k * rstride) = w;
+    *reinterpret_cast<uint32_t *>(rpad[n] + k * rstride) = w;
+  };
+  ldpc_v2u sl[N] = {cap, cap}, sh[N] = {cap, cap};
+  if (D & 1) {
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      put(n, D - 1, NP ? ldpc_as_v2u(p_lo[n][NP - 1]) : cap, NP ? ldpc_as_v2u(p_hi[n][NP - 1]) : cap);
+      sl[n] = ldpc_as_v2u(m_lo[n][D - 1]);
+      sh[n] = ldpc_as_v2u(m_hi[n][D - 1]);
+    }
+  }
+#pragma unroll
+  for (int i = NP - 1; i >= 0; i--) {
+    const int k0 = 2 * i, k1 = 2 * i + 1;
+    const bool last = !(D & 1) && i == NP - 1;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      const ldpc_v2u pvl = i ? ldpc_as_v2u(p_lo[n][i - 1]) : cap, pvh = i ? ldpc_as_v2u(p_hi[n][i - 1]) : cap;
+      const ldpc_v2u a0l = ldpc_as_v2u(m_lo[n][k0]), a0h = ldpc_as_v2u(m_hi[n][k0]), a1l = ldpc_as_v2u(m_lo[n][k1]), a1h = ldpc_as_v2u(m_hi[n][k1]);
+      put(n, k0, last ? ldpc_pminu(pvl, a1l) : ldpc_pmin3_keys(pvl, a1l, sl[n]), last ? ldpc_pminu(pvh, a1h) : ldpc_pmin3_keys(pvh, a1h, sh[n]));
+      put(n, k1, last ? ldpc_pminu(pvl, a0l) : ldpc_pmin3_keys(pvl, a0l, sl[n]), last ? ldpc_pminu(pvh, a0h) : ldpc_pmin3_keys(pvh, a0h, sh[n]));
+      if (i > 0) {
+        sl[n] = last ? ldpc_pminu(a0l, a1l) : ldpc_pmin3_keys(sl[n], a0l, a1l);
+        sh[n] = last ? ldpc_pminu(a0h, a1h) : ldpc_pmin3_keys(sh[n], a0h, a1h);
+      }
+    }
+  }
+  uint32_t out[N];
+#pragma unroll
+  for (int n = 0; n < N; n++) {
+    uint32_t np = (parw[n] >> 7) & 0x01010101u;
+    if (EXT) {
+      np ^= ((extl[n] >> 8) & 1u) | (((extl[n] >> 24) & 1u) << 8);
+      np ^= (((exth[n] >> 8) & 1u) << 16) | (((exth[n] >> 24) & 1u) << 24);
+    }
+    if (D & 1)
+      np ^= 0x01010101u;
+    out[n] = (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+  }
+  mask_b = out[1];
+  return out[0];
+}
+/* dispatch of a double task (extension rows of degree 3 .. LDPC_F_CN_DOUBLE) */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LDPC_CN2_NOINLINE)
+#define LDPC_CN2_ATTR __device__ __attribute__((noinline))
+#else
+#define LDPC_CN2_ATTR LDPC_HD
+#endif
+template <bool P1 = false>
+LDPC_CN2_ATTR uint32_t ldpc_fast_cn2_dispatch(int deg, const ldpc_fast_lds &L, int e0a, int ja, int e0b, int jb, int Z, int rstride, uint32_t &mask_b)
+{
+  switch (deg) {
+    case 3: return ldpc_fast_cn_ps2<3, true, P1>(L, e0a, ja, e0b, jb, Z, rstride, mask_b);
+    case 4: return ldpc_fast_cn_ps2<4, true, P1>(L, e0a, ja, e0b, jb, Z, rstride, mask_b);
+    default: return ldpc_fast_cn_ps2<5, true, P1>(L, e0a, ja, e0b, jb, Z, rstride, mask_b);
+  }
+}
+
 /* A degree-19 row item shared by TWO neighbouring lanes (lane parity = half): half 0 takes the row's edges 0..9, half 1
  * edges 10..18 -- ten edges in registers each (the one-lane version has to re-read LDS in its second sweep, MODE 2, or
  * spill), the partial minima / sign xor / parity word are swapped through a DPP move and merged, then every lane writes

@@ -45,7 +45,6 @@ template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io 
     return TRACE ? reinterpret_cast<uint32_t *>(a.trace + (size_t)blockIdx.x * 32 + 5) : nullptr;
   }
   static constexpr bool pass_stamps = TRACE;
-  static constexpr bool persistent = false;
   __device__ __forceinline__ int fair_turns() const { return a.fair; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   /* homogeneous launches: the parity check of a pass right after it when the block is close to converging (a block that
@@ -95,165 +94,6 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
     }
   }
 }
-
-/* Persistent form of the homogeneous launch: one workgroup per slot of the GPU; a workgroup takes block blockIdx.x first and
- * then whatever the launch's counter hands out (a.draw: list scheduling by whoever is free, as the hardware's dispatcher does
- * it for one-block workgroups), keeps the code's tables in LDS, and asks for the next block's index and LLRs while the
- * current block is finishing (ldpc_dec_fast_block.h, IO::persistent) -- the 2-3 us between "last pass done" and "first
- * check-node task of the next block" that a fresh workgroup spends waiting for HBM. */
-template <bool TRACE = false> struct ldpc_persist_io {
-  const ldpc_dec_args &a;
-  mutable uint32_t blk, next;        /* current block; the one after it (valid when published) */
-  mutable uint32_t seq;              /* blocks this workgroup has started: parity selects the LDS word the index travels through */
-  mutable bool drawn, published;     /* the next index: requested from the counter / known to every wave */
-  mutable bool resident;             /* tables in LDS (every block but the workgroup's first) */
-  mutable bool pref, have_pref;      /* LLRs requested for `next` / this block's LLRs are in pv */
-  mutable uint32_t nxt_v;            /* thread 0: the counter's answer */
-  mutable uint32_t pva[4], pve[4];
-  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(a.llr + (size_t)blk * a.llr_stride); }
-  __device__ __forceinline__ int8_t *out() const { return a.out + (size_t)blk * a.out_stride; }
-  __device__ __forceinline__ int max_pass() const { return a.num_max_iter + 1; }
-  __device__ __forceinline__ int use_crc() const { return 0; } /* (parity-check stop only: ldpc_launch_dec_fast_persist) */
-  static constexpr bool syndrome = true;
-  __device__ __forceinline__ int crcE() const { return a.E; }
-  __device__ __forceinline__ const uint32_t *crc_pow() const { return a.crc_pow; }
-  __device__ __forceinline__ int out_mode() const { return a.out_mode; }
-  __device__ __forceinline__ int *tb_abort() const { return nullptr; }
-  __device__ __forceinline__ uint32_t *stamps() const
-  {
-    return TRACE ? reinterpret_cast<uint32_t *>(a.trace + (size_t)blk * 32 + 5) : nullptr;
-  }
-  static constexpr bool pass_stamps = TRACE;
-  static constexpr bool persistent = true;
-  __device__ __forceinline__ int fair_turns() const { return 0; } /* (one workgroup per CU) */
-  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-  __device__ __forceinline__ bool eager_check() const { return true; }
-  static constexpr bool bn_tickets = true;
-  static constexpr bool tb_epilogue = false;
-  __device__ __forceinline__ bool tables_resident() const { return resident; }
-  __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
-  __device__ __forceinline__ uint32_t abort_load() const { return 0u; }
-  __device__ __forceinline__ bool abort_is(uint32_t) const { return false; }
-  __device__ __forceinline__ bool has_abort() const { return false; }
-  __device__ __forceinline__ void put16(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t t) const { *p = make_uint4(x, y, z, t); }
-  __device__ __forceinline__ uint32_t ld_llr(const uint32_t *p) const { return *p; }
-  __device__ __forceinline__ const uint32_t *src32_prologue() const { return src32(); }
-  __device__ __forceinline__ uint32_t *stage_core() const { return nullptr; }
-  /* ---- the next block ---- */
-  __device__ __forceinline__ void draw_issue(int tid) const
-  {
-    if (!drawn) {
-      drawn = true;
-      if (tid == 0)
-        nxt_v = __hip_atomic_fetch_add(a.draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gridDim.x;
-    }
-  }
-  /* (in front of a barrier) */
-  __device__ __forceinline__ void draw_publish(int tid, int *flags) const
-  {
-    if (drawn && !published && tid == 0)
-      flags[32 + (seq & 1)] = (int)nxt_v;
-  }
-  /* (behind that barrier) */
-  __device__ __forceinline__ void learn_next(const int *flags) const
-  {
-    if (drawn && !published) {
-      next = LDPC_UNIFORM((uint32_t)flags[32 + (seq & 1)]);
-      published = true;
-    }
-  }
-  __device__ __forceinline__ void prefetch(const int *flags, int tid, int nt, int n_app, int n_ext) const
-  {
-    learn_next(flags);
-    if (published && next < a.n_blocks) {
-      const uint32_t *s = reinterpret_cast<const uint32_t *>(a.llr + (size_t)next * a.llr_stride);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int ia = tid + k * nt;
-        pva[k] = ia < n_app ? s[ia] : 0u;
-        pve[k] = ia < n_ext ? s[n_app + ia] : 0u;
-      }
-      pref = true;
-    }
-  }
-  /* (the values are overwritten, not just disowned: otherwise they stay alive -- eight registers -- through the next pass) */
-  __device__ __forceinline__ void drop_prefetch() const
-  {
-    pref = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      pva[k] = pve[k] = 0u;
-  }
-  __device__ __forceinline__ bool take_prefetch(uint32_t (&va)[4], uint32_t (&ve)[4]) const
-  {
-    if (!have_pref)
-      return false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      va[k] = pva[k];
-      ve[k] = pve[k];
-    }
-    return true;
-  }
-};
-
-template <bool TRACE = false>
-__global__ void __launch_bounds__(1024) ldpc_dec_fast_persist_kernel(const ldpc_dec_args a)
-{
-  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-  ldpc_code_ptr_t code = (ldpc_code_ptr_t)a.code;
-  int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
-  ldpc_persist_io<TRACE> io{a};
-  io.blk = blockIdx.x;
-  io.next = 0;
-  io.seq = 0;
-  io.resident = false;
-  io.have_pref = false;
-  io.nxt_v = 0;
-  io.drop_prefetch();
-  for (;;) {
-    io.drawn = io.published = io.pref = false;
-    /* (the descriptor pointer is made opaque once per block: otherwise everything the body derives from it is hoisted out of
-     * this loop and kept alive across it -- a hundred registers spilled) */
-    ldpc_code_ptr_t code_i = code;
-    asm volatile("" : "+s"(code_i));
-    unsigned long long *tr = TRACE ? a.trace + (size_t)io.blk * 32 : nullptr;
-    if (TRACE && threadIdx.x == 0) {
-      tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      tr[2] = wall_clock64();
-    }
-    const int n_iter = ldpc_dec_fast_block(fsm, code_i, io);
-    if (threadIdx.x == 0)
-      a.n_iter[io.blk] = n_iter;
-    const bool late = !io.published; /* the block ended where nobody expected it to (or never looked: a one-pass cap) */
-    if (late) {
-      io.draw_issue((int)threadIdx.x);
-      io.draw_publish((int)threadIdx.x, flags);
-    }
-    __syncthreads(); /* every wave has taken its hard decisions from the APP rows: the next block's prologue may overwrite them */
-    if (TRACE && threadIdx.x == 0) {
-      tr[3] = wall_clock64();
-      tr[4] = (unsigned long long)n_iter;
-    }
-    if (late)
-      io.learn_next(flags);
-    if (io.next >= a.n_blocks)
-      break;
-    io.blk = io.next;
-    io.have_pref = io.pref;
-    io.resident = true;
-    io.seq++;
-  }
-  /* the last workgroup to leave puts the counter back (every workgroup's draws precede its own count) */
-  if (threadIdx.x == 0) {
-    if (__hip_atomic_fetch_add(a.draw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-      __hip_atomic_store(a.draw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.draw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 
 /* Host-buffer batches: the block's LLRs sit in page-locked host memory.  The workgroup pulls its row over the link into
  * its row of the device staging buffer (16-byte loads, all of a 1024-thread workgroup's 26 KB in flight at once) and then
@@ -347,9 +187,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
 
 hipError_t ldpc_fast_kernel_init(void)
 {
-  const void *k[] = {reinterpret_cast<const void *>(ldpc_dec_fast_persist_kernel<true>),
-                     reinterpret_cast<const void *>(ldpc_dec_fast_persist_kernel<false>),
-                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, true>),
+  const void *k[] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<true>),
@@ -377,22 +215,6 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
-  return hipGetLastError();
-}
-
-hipError_t ldpc_launch_dec_fast_persist(const ldpc_dec_args &a0, const ldpc_code_desc_t &hc, uint32_t n_blocks, uint32_t grid,
-                                        hipStream_t stream)
-{
-  if (n_blocks == 0)
-    return hipSuccess;
-  if (a0.jobs || a0.use_crc || !a0.draw || grid == 0 || grid > n_blocks)
-    return hipErrorInvalidValue;
-  ldpc_dec_args a = a0;
-  a.n_blocks = n_blocks;
-  if (a.trace)
-    hipLaunchKernelGGL(ldpc_dec_fast_persist_kernel<true>, dim3(grid), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
-  else
-    hipLaunchKernelGGL(ldpc_dec_fast_persist_kernel<false>, dim3(grid), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   return hipGetLastError();
 }
 

@@ -82,10 +82,22 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
     if (paired)
       d->f_pair19 = 1;
     const int gstart = item, gend = item + (j - i) * zq * (paired ? 2 : 1);
-    for (int b = gstart; b < gend; b += 64) {
+    int dbl_max = LDPC_F_CN_DOUBLE;
+    {
+      const char *e = getenv("NRLDPC_HIP_CN_DOUBLE"); /* tuning knob: largest row degree that gets double tasks (0: none) */
+      if (e)
+        dbl_max = atoi(e);
+      if (dbl_max > LDPC_F_CN_DOUBLE)
+        dbl_max = LDPC_F_CN_DOUBLE; /* (the kernel has two-item bodies for degrees 3 .. LDPC_F_CN_DOUBLE) */
+    }
+    /* (groups of at least three rows: a lone row's 96 items make one three-quarters-full double task where two single ones
+     * were enough -- BG1 R = 8/9 lost 3 % that way, profiles/r06/ab_double_tasks.txt) */
+    const int dbl = mb == 1 && d->f_sub != 4 && !paired && rows[i].key >= 3 && rows[i].key <= dbl_max && row_has_ext(d, rows[i].id) && zq >= 64 &&
+                    j - i >= 3;
+    for (int b = gstart; b < gend; b += dbl ? 128 : 64) {
       if (nt >= LDPC_F_MAX_CN_TASKS)
         return;
-      d->f_cn_task[nt][0] = rows[i].key;
+      d->f_cn_task[nt][0] = rows[i].key | (dbl ? 0x100 : 0);
       d->f_cn_task[nt][1] = row_has_ext(d, rows[i].id); /* rows of one degree group are all core or all extension rows? checked below */
       d->f_cn_task[nt][2] = b;
       d->f_cn_task[nt][3] = gstart;
@@ -94,6 +106,8 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
       /* instruction-count model of a task: ~36 VALU per edge (47 for the degree-19 rows, which re-read LDS in their
        * second sweep) + ~40 of prologue/epilogue */
       cost[nt] = paired ? 10 * 36 + 60 : rows[i].key * (rows[i].key >= 16 ? 47 : 36) + 40;
+      if (dbl)
+        cost[nt] = 2 * rows[i].key * 36 + 60;
       nt++;
     }
     /* a degree group must not mix core rows (no extension column) with extension rows */
@@ -104,6 +118,20 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
     i = j;
   }
   d->f_n_cn_tasks = nt;
+  /* the queue hands tasks out in id order: most expensive first (insertion sort, stable; double tasks move up) */
+  for (int a = 1; a < nt; a++) {
+    int32_t rec[6];
+    const int c = cost[a];
+    memcpy(rec, d->f_cn_task[a], sizeof(rec));
+    int k = a - 1;
+    while (k >= 0 && cost[k] < c) {
+      memcpy(d->f_cn_task[k + 1], d->f_cn_task[k], sizeof(rec));
+      cost[k + 1] = cost[k];
+      k--;
+    }
+    memcpy(d->f_cn_task[k + 1], rec, sizeof(rec));
+    cost[k + 1] = c;
+  }
   /* columns sorted by degree (descending), their adjacency, BN tasks */
   sort_item_t cols[LDPC_MAX_CORE];
   for (int c = 0; c < d->ncore; c++) {

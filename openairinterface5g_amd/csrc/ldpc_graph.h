@@ -24,6 +24,7 @@
 #define LDPC_F_MAX_CN_TASKS 96
 #define LDPC_F_MAX_BN_TASKS 48
 #define LDPC_F_BN_SHORT 6 /* columns up to this degree count as short */
+#define LDPC_F_CN_DOUBLE 5 /* extension rows up to this degree come as tasks of 128 items, two per thread (f_cn_task) */
 #define LDPC_F_BN_GROUP 5 /* short tasks per ticket at most */
 #define LDPC_F_MAX_CTBL 800 /* <= 26 columns x degree 30 when every list is padded to the maximum */
 
@@ -90,7 +91,10 @@ typedef struct ldpc_code_desc {
   /* The kernel's waves draw the tasks of a phase in id order (= most expensive first) from a queue, an LDS counter:
    * static per-wave shares leave the SIMDs' oldest waves idle early, because the issue arbiter favours them and equal
    * shares do not finish together. */
-  /* CN task: {degree, has_ext, first item, group first item, group end item, sorted-row index of the group's first row} */
+  /* CN task: {degree (| 0x100: a DOUBLE task), has_ext, first item, group first item, group end item, sorted-row index of
+   * the group's first row}.  A double task is 128 consecutive items of a low-degree group and a thread takes items lane and
+   * lane + 64 TOGETHER (ldpc_fast_cn_ps2): the chain of round trips in front of a task -- ticket, record, row record, edge
+   * table, windows -- is longer than the arithmetic of a degree-3..5 row, and two items share one chain. */
   int32_t f_cn_task[LDPC_F_MAX_CN_TASKS][6];
   /* BN task: {first item, end item (all columns), loop bound = degree of the first item's column} */
   int32_t f_bn_task[LDPC_F_MAX_BN_TASKS][3];

@@ -63,9 +63,6 @@ struct ldpc_dec_args {
   /* diagnostics (NRLDPC_HIP_DEC_TRACE=<file>, homogeneous fast launches): 32 x uint64 per workgroup -- placement, start / end
    * and the clocks of every phase of every pass (ldpc_dec_fast_kernel<.., .., true>; tools/dec_trace.py) */
   unsigned long long *trace;
-  /* persistent launches (ldpc_launch_dec_fast_persist): {next block to hand out - gridDim, workgroups that have left}, both
-   * zero when the kernel starts and zeroed again by the last workgroup to leave */
-  uint32_t *draw;
   /* > 0: workgroups of this launch share a CU, each with this many waves per SIMD -- they take turns at the issue priority
    * (ldpc_dec_fast_block.h, io.fair_turns()) */
   int32_t fair;
@@ -98,9 +95,6 @@ hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_b
 hipError_t ldpc_fast_kernel_init(void);
 hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                 hipStream_t stream);
-/* the same as `grid` persistent workgroups that draw the launch's blocks from a.draw (launches of several workgroup rounds) */
-hipError_t ldpc_launch_dec_fast_persist(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks, uint32_t grid,
-                                        hipStream_t stream);
 /* the same with a.pull set: every workgroup pulls its LLR row over the link itself (no copy engine, no staging copy) */
 hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_desc_t &host_code, uint32_t n_blocks,
                                      hipStream_t stream);

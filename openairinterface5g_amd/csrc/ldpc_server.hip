@@ -99,7 +99,6 @@ template <bool CRC> struct srv_fast_io { /* the request header sits in LDS: read
   __device__ __forceinline__ bool has_abort() const { return true; }
   __device__ __forceinline__ uint32_t *stamps() const { return st; }
   static constexpr bool pass_stamps = false;
-  static constexpr bool persistent = false;
   __device__ __forceinline__ int fair_turns() const { return 0; }
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ bool eager_check() const { return true; }

@@ -1225,6 +1225,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       static const int stagger_us = [] { const char *e = getenv("NRLDPC_HIP_TB_STAGGER_US"); return e ? atoi(e) : 0; }();
       const int per_cu = std::min(16 / std::max(dl.threads / 64, 1), (160 * 1024) / std::max(dl.lds, 1024));
       fx.stagger_ticks = 0;
+      /* workgroups that share a CU take turns at the issue priority, pass by pass (ldpc_dec_fast_block.h fair_turns;
+       * NRLDPC_HIP_TB_FAIR=0: off) */
+      static const int fair_env = [] { const char *e = getenv("NRLDPC_HIP_TB_FAIR"); return e ? atoi(e) : 1; }();
+      da.fair = (fair_env && per_cu >= 2 && dl.n > (uint32_t)G().n_cus && dl.threads >= 256) ? dl.threads / 256 : 0;
       if (stagger_us > 0 && per_cu >= 2 && dl.n > (uint32_t)G().n_cus) {
         fx.stagger_ticks = (uint32_t)(stagger_us * 100 * 2 / per_cu);
         fx.stagger_cus = (uint32_t)G().n_cus;

@@ -54,8 +54,7 @@ struct tb_rx_fused_io {
   __device__ __forceinline__ int *tb_abort() const { return (a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr; }
   __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
   static constexpr bool pass_stamps = false;
-  static constexpr bool persistent = false;
-  __device__ __forceinline__ int fair_turns() const { return 0; }
+  __device__ __forceinline__ int fair_turns() const { return a.fair; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ bool eager_check() const { return false; }
   static constexpr bool bn_tickets = true;

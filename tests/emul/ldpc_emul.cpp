@@ -272,9 +272,10 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
     (void)nt;
     /* the kernel's waves draw the tasks of a phase from a queue; the tasks are independent, so any order will do */
     for (int task = 0; task < code->f_n_cn_tasks; task++) {
-      for (int lane = 0; lane < 64; lane++) {
+      /* (a double task -- degree | 0x100 -- is 128 items: the kernel's threads take items lane and lane + 64 together) */
+      for (int lane = 0; lane < ((code->f_cn_task[task][0] & 0x100) ? 128 : 64); lane++) {
         uint32_t syn = 0;
-        const int deg = code->f_cn_task[task][0], ext = code->f_cn_task[task][1];
+        const int deg = code->f_cn_task[task][0] & 0xff, ext = code->f_cn_task[task][1];
         const int item = code->f_cn_task[task][2] + lane;
         const int gstart = code->f_cn_task[task][3], gend = code->f_cn_task[task][4], srow0 = code->f_cn_task[task][5];
         if (item < gend) {

@@ -354,11 +354,11 @@ def test_full_size_batch_properties_device(hip):
 
 
 @pytest.mark.parametrize("cfg", [(1, 384, 13, 257), (1, 384, 13, 701), (2, 384, 15, 513), (1, 352, 13, 300)])
-def test_persistent_launches_ragged_sizes_and_mixed_pass_counts(hip, cfg):
-    """Launches of more than one workgroup round of a one-workgroup-per-CU code run as persistent workgroups that draw
-    their blocks from a counter (ldpc_dec_fast_persist_kernel): block counts that do not fill the last round, noise levels
-    from "converges in 3 passes" to "never" mixed in one launch (every workgroup finishes its blocks at another time), the
-    launch repeated (the counter puts itself back) -- every block against the generic kernel, a sample against the oracle."""
+def test_launches_of_several_workgroup_rounds_ragged_sizes_and_mixed_pass_counts(hip, cfg):
+    """Launches of more than one workgroup round of the large codes (one workgroup per CU; double check-node tasks for the
+    low-degree rows): block counts that do not fill the last round, noise levels from "converges in 3 passes" to "never" mixed in
+    one launch (every workgroup finishes at another time), the launch repeated -- every block against the generic kernel, a
+    sample against the oracle, and a one-pass cap."""
     import torch
     BG, Z, R, n = cfg
     K = (22 if BG == 1 else 10) * Z
@@ -389,7 +389,7 @@ def test_persistent_launches_ragged_sizes_and_mixed_pass_counts(hip, cfg):
     for i in range(0, n, 41):
         n_ref, out_ref = O.decode(BG, Z, R, llr_h[i], 8, vec=True)
         assert n_ref == it_h[i] and np.array_equal(out_ref, out_h[i]), i
-    # a one-pass cap: no workgroup ever sees "this pass may be the last" before it is over
+    # a one-pass cap
     hip.decode_batch_device(BG, Z, R, llr, out, it, numMaxIter=0)
     hip.decode_batch_device(BG, Z, R, llr, out_g, it_g, numMaxIter=0, kernel=1)
     torch.cuda.synchronize()
