@@ -13,7 +13,7 @@ def maxval(sub, counter):
         for row in csv.DictReader(open(f)):
             # the headline launch only: homogeneous batch, parity-check stop (bench.py's chain_roofline leg runs other kernels
             # whose argument list mentions ldpc_dec_args)
-            if row["Kernel_Name"].startswith("void ldpc_dec_fast_kernel<false, false>") and row["Counter_Name"] == counter:
+            if row["Kernel_Name"].startswith("void ldpc_dec_fast_kernel<false, false") and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
     return max(vals)   # the fixed-work launches (9 passes) are the largest
 model = sorted(Path("profiles").glob("r0*/valu_issue_model.json"))[-1]  # the newest round's

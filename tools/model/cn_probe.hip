@@ -35,6 +35,18 @@ extern "C" __global__ void __launch_bounds__(1024) probe_cn_19pair(const probe_a
   a.out[threadIdx.x] = ldpc_fast_cn19_pair<false>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.Z, a.rstride, (int)threadIdx.x & 1);
 }
 CN_PROBE(3, 1, 0) CN_PROBE(4, 1, 0) CN_PROBE(5, 1, 0) CN_PROBE(6, 1, 0) CN_PROBE(7, 1, 0) CN_PROBE(8, 1, 0) CN_PROBE(9, 1, 0) CN_PROBE(10, 1, 0)
+/* a double task's item pair (ldpc_fast_cn_ps2: two items of a low-degree extension row walked together): both items' instructions */
+#define CN2_PROBE(D)                                                                                  \
+  extern "C" __global__ void __launch_bounds__(1024) probe_cn2_##D(const probe_args a)                 \
+  {                                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];                                    \
+    const ldpc_fast_lds L = probe_lds(fsm, a);                                                        \
+    uint32_t mb = 0;                                                                                  \
+    const uint32_t ma = ldpc_fast_cn_ps2<D, true, false>(L, a.e0 + (int)threadIdx.x, a.j + (int)threadIdx.x, a.e0 + 7 + (int)threadIdx.x, \
+                                                          a.j + 64 + (int)threadIdx.x, a.Z, a.rstride, mb);                                \
+    a.out[threadIdx.x] = ma ^ (mb << 4);                                                              \
+  }
+CN2_PROBE(3) CN2_PROBE(4) CN2_PROBE(5)
 #define BN_PROBE(M)                                                                        \
   extern "C" __global__ void __launch_bounds__(1024) probe_bn_##M(const probe_args a)       \
   {                                                                                        \

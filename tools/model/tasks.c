@@ -10,9 +10,10 @@ int main(int argc, char **argv)
   if (ldpc_build_code_desc(BG, Z, R, &d) != 0 || !d.f_ok) return 1;
   printf("{\"BG\": %d, \"Z\": %d, \"R\": %d, \"nedges\": %d, \"threads\": %d, \"cn_tasks\": [", BG, Z, R, d.nedges, d.f_n_threads);
   for (int t = 0; t < d.f_n_cn_tasks; t++) {
-    int first = d.f_cn_task[t][2], gend = d.f_cn_task[t][4], items = gend - first < 64 ? gend - first : 64;
-    printf("%s{\"deg\": %d, \"ext\": %d, \"items\": %d, \"pair\": %d}", t ? ", " : "", d.f_cn_task[t][0], d.f_cn_task[t][1], items,
-           d.f_cn_task[t][0] == 19 && d.f_pair19);
+    const int dbl = (d.f_cn_task[t][0] & 0x100) != 0, deg = d.f_cn_task[t][0] & 0xff, per = dbl ? 128 : 64; /* double task: 128 items, two per thread */
+    int first = d.f_cn_task[t][2], gend = d.f_cn_task[t][4], items = gend - first < per ? gend - first : per;
+    printf("%s{\"deg\": %d, \"ext\": %d, \"items\": %d, \"pair\": %d, \"double\": %d}", t ? ", " : "", deg, d.f_cn_task[t][1], items,
+           deg == 19 && d.f_pair19, dbl);
   }
   printf("], \"bn_tasks\": [");
   for (int t = 0; t < d.f_n_bn_tasks; t++) {

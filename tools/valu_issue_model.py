@@ -128,7 +128,8 @@ def main():
     detail = []
     TASK_OVERHEAD_VALU = 14          # queue draw, task record, item index, row record, syndrome mask (ldpc_dec_fast_block.h)
     for t in tasks["cn_tasks"]:
-        k = per_kind["probe_cn_19pair" if t.get("pair") else f"probe_cn_{t['deg']}_{t['ext']}_{2 if t['deg'] == 19 else 0}"]
+        k = per_kind["probe_cn_19pair" if t.get("pair") else (f"probe_cn2_{t['deg']}" if t.get("double") else
+                                                               f"probe_cn_{t['deg']}_{t['ext']}_{2 if t['deg'] == 19 else 0}")]
         tot_ns += k["ns"] + TASK_OVERHEAD_VALU * table["xor_b32"]
         tot_valu += k["valu"] + TASK_OVERHEAD_VALU
         tot_lds += k["lds"]
