@@ -82,6 +82,30 @@ __device__ __forceinline__ int ldpc_draw_issue(int *counter, int lane)
   return t;
 }
 
+/* The code's tables, made absolute for this workgroup's LDS, and the row of zero bytes the padded bit-node lists point at:
+ * [f_lds_etbl, f_lds_zero + Z + 4).  Done by the block body's prologue unless its caller says they are there already
+ * (io.tables_resident(): the resident server's "same code as last time", the fused segment kernel, which copies them while its
+ * de-matching stores drain). */
+__device__ __forceinline__ void ldpc_fast_tables_to_lds(uint8_t *fsm, ldpc_code_ptr_t code, int tid, int nt)
+{
+  const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
+  const int ext_global = code->f_ext_global, ncore = code->ncore, nedges = code->nedges, Z = code->Z;
+  uint32_t *etbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_etbl);
+  uint32_t *ctbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_ctbl);
+  uint32_t *rowtbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_rowtbl);
+  uint32_t *coltbl = reinterpret_cast<uint32_t *>(fsm + code->f_lds_coltbl);
+  for (int i = tid; i < nedges; i += nt)
+    etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
+  for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
+    ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
+  for (int i = tid; i < code->nrows; i += nt)
+    rowtbl[i] = code->f_rowtbl[i];
+  for (int i = tid; i < ncore; i += nt)
+    coltbl[i] = code->f_coltbl[i];
+  for (int i = tid; i < (Z + 4) >> 2; i += nt)
+    reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
+}
+
 /* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
 template <class IO>
 __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const IO &io)
@@ -102,13 +126,12 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   L.etbl = etbl; L.ctbl = ctbl; L.rowtbl = rowtbl; L.coltbl = coltbl;
   int *flags = reinterpret_cast<int *>(fsm + code->f_lds_misc);
   const int tid = io.tid(), nt = blockDim.x, lane = tid & 63;
-  const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z, nedges = code->nedges;
+  const int ncore = code->ncore, num_llr = code->num_llr, ncz = ncore * Z;
   const uint32_t *__restrict__ src32 = io.src32();
   const uint32_t *__restrict__ srcp = io.src32_prologue();
   uint32_t *stage = io.stage_core();
 
   /* ---- tables and state into LDS -------------------------------------------------------------------- */
-  const uint32_t lds0 = ldpc_lds_addr(fsm); /* tables hold absolute LDS addresses from here on */
   const int ext_global = code->f_ext_global;
   L.gllr = reinterpret_cast<const uint8_t *>(src32);
   L.ext_global = ext_global;
@@ -128,16 +151,8 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
     }
   }
   const bool have_tables = io.tables_resident();
-  if (!have_tables) {
-    for (int i = tid; i < nedges; i += nt)
-      etbl[i] = code->f_etbl[i] + ((ext_global && code->e_col[i] >= ncore) ? 0u : lds0);
-    for (int i = tid; i < 2 * code->f_n_ctbl; i += nt)
-      ctbl[i] = code->f_ctbl[i] + ((i & 1) ? lds0 : 0u);
-    for (int i = tid; i < code->nrows; i += nt)
-      rowtbl[i] = code->f_rowtbl[i];
-    for (int i = tid; i < ncore; i += nt)
-      coltbl[i] = code->f_coltbl[i];
-  }
+  if (!have_tables)
+    ldpc_fast_tables_to_lds(fsm, code, tid, nt);
   if (stage) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -146,9 +161,6 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
       ve[k] = ia < n_ext ? io.ld_llr(srcp + n_app + ia) : 0u;
     }
   }
-  if (!have_tables)
-    for (int i = tid; i < (Z + 4) >> 2; i += nt)
-      reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
   if (tid < 16)
     flags[tid] = 0; /* [0], [1] syndrome flags of odd / even passes, [2] CRC register, [3] TB abort seen, [6] eager check,
                        [8], [9] task queues of even / odd passes */

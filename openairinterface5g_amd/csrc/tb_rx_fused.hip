@@ -41,6 +41,7 @@ struct tb_rx_fused_io {
   const ldpc_dec_args &a;
   const tb_rx_fused_args &x;
   ldpc_job_ptr_t job;
+  bool tables_early = false; /* the kernel has put the code's tables into LDS already (behind the de-matching stores) */
   __device__ __forceinline__ tb_seg_ptr_t seg() const { return (tb_seg_ptr_t)x.segs + job->seg_idx; }
   __device__ __forceinline__ tb_tb_ptr_t tb() const { return (tb_tb_ptr_t)x.tbs + seg()->tb; }
   __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(a.llr + (size_t)job->llr_off); }
@@ -58,7 +59,7 @@ struct tb_rx_fused_io {
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ bool eager_check() const { return false; }
   static constexpr bool bn_tickets = true;
-  __device__ __forceinline__ bool tables_resident() const { return false; }
+  __device__ __forceinline__ bool tables_resident() const { return tables_early; }
   __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
   __device__ __forceinline__ uint32_t abort_load() const { return 0u; }
   __device__ __forceinline__ bool abort_is(uint32_t) const { return false; }
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   const ldpc_job_ptr_t job = (ldpc_job_ptr_t)a.jobs + blockIdx.x;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)job->code;
-  const tb_rx_fused_io io{a, x, job};
+  tb_rx_fused_io io{a, x, job};
   if (x.stagger_ticks && blockIdx.x >= x.stagger_cus && blockIdx.x < x.stagger_cus * x.stagger_slots) {
     const long long until = (long long)wall_clock64() + (long long)(blockIdx.x / x.stagger_cus) * (long long)x.stagger_ticks;
     while ((long long)wall_clock64() < until)
@@ -226,6 +227,13 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     const tb_rx_geom g = tb_rx_geometry(sj);
     tb_rx_dematch_block(g, sj->Qm, x.llr + sj->llr_off, x.harq + sj->harq_off, const_cast<int8_t *>(a.llr) + sj->l_off,
                         reinterpret_cast<int16_t *>(fsm), tr ? tr + 7 : nullptr);
+    /* the code's tables go into LDS NOW, their loads in flight beside the de-matching stores that the fence below waits for
+     * anyway -- not behind the barrier, in the decoder's prologue, where nothing hides them.  (Only when the de-matching image,
+     * which other waves may still be reading, ends in front of the tables' place: every large code.) */
+    if (2u * g.span <= (uint32_t)code->f_lds_etbl) {
+      ldpc_fast_tables_to_lds(fsm, code, (int)threadIdx.x, (int)blockDim.x);
+      io.tables_early = true;
+    }
     /* the decoder input is read back by other waves of this workgroup only: workgroup scope (see ldpc_dec_fast_pull_kernel) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
