@@ -33,6 +33,7 @@ NUM_LLR = 68 * Z
 EDGES = 316
 PASSES_FIXED = MAX_ITER + 1
 A_MIN = NUM_LLR + K // 8                                   # compulsory HBM bytes per block (27 168)
+STRONG_DEADLINE_S = int(os.environ.get("BENCH_DEADLINE_S", "120"))   # secondary legs at N > 1: see main()
 A_MSG = A_MIN + PASSES_FIXED * 4 * EDGES * Z               # reference dataflow bytes per block (4 395 552)
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -419,28 +420,8 @@ def main():
         op = {"snr_db": 1.0, "gbps": world * max(5, args.steps // 2) * BATCH * N_TX / dt_op / 1e9,
               "bler": float(stats[0] / stats[2]), "mean_passes": float(stats[1] / stats[2])}
 
-    # ---- strong scaling: one slot's transport blocks sharded over the ranks (configs[4]) --------------
-    strong = None
-    if not args.no_strong:
-        try:
-            strong = strong_slot(pkg, torch, dist, world, rank, max(5, min(args.steps, 20)))
-        except Exception as e:                      # the secondary experiment must not cost the headline line
-            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
-            print(f"[bench] strong-scaling slot failed on rank {rank}: {strong['error']}", file=sys.stderr, flush=True)
-    chain = None
-    if not args.no_chain and rank == 0:
-        try:
-            chain = chain_roofline(pkg, torch)
-        except Exception as e:
-            chain = {"error": f"{type(e).__name__}: {e}"[:300]}
-            print(f"[bench] chain_roofline failed: {chain['error']}", file=sys.stderr, flush=True)
-    devices = [torch.cuda.current_device()]
-    if dist is not None:
-        ords = [None] * world
-        dist.all_gather_object(ords, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(local_rank).name))
-        devices = [o[1] for o in sorted(ords)]
-
-    if rank == 0:
+    def emit(strong, chain, devices, with_cpu):
+        """rank 0: the ONE JSON line of the run"""
         traffic, pmc = None, {}
         tf = ROOT / "profiles" / "hbm_traffic.json"     # PMC-measured per-launch figures (see DESIGN.md), if collected
         if tf.exists():
@@ -510,9 +491,56 @@ def main():
             "rccl_ranks": dist.get_world_size() if dist is not None else 0,
             "rank_devices": devices,
         }
-        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
+        if with_cpu:                                    # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(llr_fixed[:256].cpu().numpy())
         print(json.dumps(line))
+
+    # ---- strong scaling: one slot's transport blocks sharded over the ranks (configs[4]) --------------
+    # The headline is measured by now.  Whatever the secondary legs do on a node nobody has run them on -- an exception
+    # on one rank only, a point-to-point group that never completes -- must not cost that line: a deadline (shorter than
+    # the process group's own watchdog, which aborts the process) prints the line with the leg marked as timed out and
+    # ends every rank quietly.
+    import threading
+
+    def deadline_fire():
+        try:
+            if rank == 0:
+                emit({"error": f"no result within {STRONG_DEADLINE_S} s: leg abandoned, headline line kept"}, None,
+                     [local_rank], False)
+                sys.stdout.flush()
+        finally:
+            os._exit(0)
+
+    deadline = None
+    if dist is not None:
+        deadline = threading.Timer(STRONG_DEADLINE_S, deadline_fire)
+        deadline.daemon = True
+        deadline.start()
+    strong = None
+    if not args.no_strong:
+        try:
+            if os.environ.get("BENCH_TEST_STALL") == "1":   # (tests/test_bench.py: a leg that never comes back)
+                time.sleep(10 * STRONG_DEADLINE_S)
+            strong = strong_slot(pkg, torch, dist, world, rank, max(5, min(args.steps, 20)))
+        except Exception as e:                      # the secondary experiment must not cost the headline line
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] strong-scaling slot failed on rank {rank}: {strong['error']}", file=sys.stderr, flush=True)
+    chain = None
+    if not args.no_chain and rank == 0:
+        try:
+            chain = chain_roofline(pkg, torch)
+        except Exception as e:
+            chain = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] chain_roofline failed: {chain['error']}", file=sys.stderr, flush=True)
+    devices = [torch.cuda.current_device()]
+    if dist is not None:
+        ords = [None] * world
+        dist.all_gather_object(ords, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(local_rank).name))
+        devices = [o[1] for o in sorted(ords)]
+    if deadline is not None:
+        deadline.cancel()
+    if rank == 0:
+        emit(strong, chain, devices, not args.no_cpu_baseline and world == 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -84,3 +84,18 @@ def test_plain_single_process_line(hip):
     s = line["strong_scaling_slot"]
     assert s["prediction"]["for_ranks"] == 1 and s["predicted_ms_range"] is None
     assert abs(s["predicted_ms"] / s["ms_per_slot_events_rank0"] - 1.0) < 0.10, (s["predicted_ms"], s["ms_per_slot_events_rank0"])
+
+
+@pytest.mark.gpu
+def test_a_secondary_leg_that_never_returns_does_not_cost_the_headline_line(hip):
+    """On a node nobody has run the N > 1 legs on, a point-to-point group that never completes would end in the process
+    group's watchdog aborting every rank -- and the measured headline with them.  bench.py's own deadline fires first:
+    the line is printed with the leg marked, every rank exits with 0."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_TEST_STALL="1", BENCH_DEADLINE_S="5", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29549")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-chain",
+                        "--no-operating-point"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] > 10 and line["roofline"]["frac"] > 0
+    assert "leg abandoned" in line["strong_scaling_slot"]["error"] and line["chain_roofline"] is None
