@@ -293,6 +293,14 @@ int32_t nrLDPC_hip_offload_encoder(uint8_t **input, uint8_t **output, encoder_im
 int32_t nrLDPC_hip_segmentation(uint32_t B, uint8_t BG, uint32_t *C, uint32_t *K, uint32_t *Zc, uint32_t *F); /* returns Kb, -1 */
 uint32_t nrLDPC_hip_get_E(uint32_t G, uint32_t C, uint32_t Qm, uint32_t Nl, uint32_t r);
 int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int32_t Z, int32_t *llrLen, int32_t round);
+/* Columns of the code graph nrLDPC_hip_ulsch_decode() decodes a segment on; R = what nr_get_R_ldpc_decoder chose (its mode has
+ * 68 / 35 / 27 resp. 52 / 32 / 17 columns, nrLDPCdecoder_defs.h:53-57, 80-84).  A first transmission (round 0: the soft buffer is
+ * cleared, nr_ulsch_decoding.c:418-422) leaves every position behind the last one it reaches at zero; a check node that closes on
+ * an all-zero degree-1 column sends zeros to its other neighbours in every pass (nrLDPC_cnProc.h:105-114: the minimum over the
+ * OTHER inputs), and the chain stops on the CRC -- so the rows behind the last column that received anything are not run: same
+ * payload, verdict and pass count as on the whole mode.  NRLDPC_HIP_TB_TRUNC=0 turns it off.  -1: invalid parameters. */
+int32_t nrLDPC_hip_ulsch_decoder_columns(int32_t BG, uint32_t Zc, uint32_t C, uint32_t F, uint32_t K, uint32_t Tbslbrm, int32_t rv,
+                                         uint32_t E, int32_t round, int32_t R);
 
 /* Introspection for tests and benchmarks */
 int32_t nrLDPC_hip_num_llr(int BG, int Z, int R);      /* ncols*Z, -1 if invalid */

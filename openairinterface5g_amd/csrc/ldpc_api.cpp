@@ -243,6 +243,7 @@ int rate_index(int BG, int R)
 /* descriptor cache of the current device: built on first use of a (BG, Z, R), uploaded once, never modified afterwards.
  * The per-segment entry points come through here on every call: a published entry is found without taking the library
  * mutex. */
+static const CodeEntry *get_code_impl(int BG, int Z, int R, int ri);
 const CodeEntry *get_code(int BG, int Z, int R)
 {
   const int ri = (BG == 1 || BG == 2) ? rate_index(BG, R) : -1;
@@ -250,10 +251,23 @@ const CodeEntry *get_code(int BG, int Z, int R)
     set_error("invalid (BG, Z, R)");
     return nullptr;
   }
-  if (g.ready) /* (read without the lock: set once, after everything it guards) */
+  return get_code_impl(BG, Z, R, ri);
+}
+/* the code cut to its first `ncols` columns (ldpc_graph.h LDPC_R_COLS; the transport-block chain's plans only) */
+const CodeEntry *get_code_cols(int BG, int Z, int ncols)
+{
+  if ((BG != 1 && BG != 2) || Z < 2 || Z > 384 || ncols <= (BG == 1 ? 26 : 14) || ncols > (BG == 1 ? 68 : 52)) {
+    set_error("invalid (BG, Z, columns)");
+    return nullptr;
+  }
+  return get_code_impl(BG, Z, LDPC_R_COLS + ncols, -1);
+}
+static const CodeEntry *get_code_impl(int BG, int Z, int R, int ri)
+{
+  if (g.ready && ri >= 0) /* (read without the lock: set once, after everything it guards) */
     if (CodeEntry *hit = G().code_tbl[BG - 1][Z][ri].load(std::memory_order_acquire))
       return hit;
-  const uint32_t key = ((uint32_t)BG << 24) | ((uint32_t)Z << 8) | (uint32_t)R;
+  const uint32_t key = ((uint32_t)BG << 28) | ((uint32_t)Z << 16) | (uint32_t)R;
   std::lock_guard<std::mutex> lk(g.mu);
   if (ensure_ready_locked() != 0)
     return nullptr;
@@ -308,7 +322,8 @@ const CodeEntry *get_code(int BG, int Z, int R)
     fprintf(stderr, "[libldpc_hip] code BG%d Z%d R%d on device %d: descriptors at %p (2 x %zu B)\n", BG, Z, R, d.id, (void *)ce->dev,
             sizeof(ldpc_code_desc_t));
   d.codes[key] = ce;
-  d.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
+  if (ri >= 0)
+    d.code_tbl[BG - 1][Z][ri].store(ce, std::memory_order_release);
   return ce;
 }
 

@@ -338,11 +338,15 @@ int ldpc_build_code_desc_shape(int BG, int Z, int R, int shape, ldpc_code_desc_t
     d->ncore = 26; d->kb_full = 22;
     /* nrLDPCdecoder_defs.h:53-57: columns kept per decoder rate mode */
     d->ncols = R == 13 ? 68 : R == 23 ? 35 : R == 89 ? 27 : -1;
+    if (R >= LDPC_R_COLS && R - LDPC_R_COLS > d->ncore && R - LDPC_R_COLS <= 68)
+      d->ncols = R - LDPC_R_COLS; /* a rate mode cut to its first columns (ldpc_graph.h) */
   } else if (BG == 2) {
     deg = nr_ldpc_bg2_row_deg; col = nr_ldpc_bg2_col; sh = nr_ldpc_bg2_shift[ils];
     d->ncore = 14; d->kb_full = 10;
     /* nrLDPCdecoder_defs.h:80-84 */
     d->ncols = R == 15 ? 52 : R == 13 ? 32 : R == 23 ? 17 : -1;
+    if (R >= LDPC_R_COLS && R - LDPC_R_COLS > d->ncore && R - LDPC_R_COLS <= 52)
+      d->ncols = R - LDPC_R_COLS;
   } else
     return -1;
   if (d->ncols < 0)

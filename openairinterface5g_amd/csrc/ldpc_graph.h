@@ -151,7 +151,15 @@ typedef struct ldpc_code_desc {
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* Fill *d for (BG, Z, R).  Returns 0, or -1 if (BG, Z, R) is not a valid NR LDPC configuration. */
+/* Fill *d for (BG, Z, R).  Returns 0, or -1 if (BG, Z, R) is not a valid NR LDPC configuration.
+ * R = a decoder rate mode of the reference (13 / 23 / 89 resp. 15 / 13 / 23: nrLDPCdecoder_defs.h:53-57, 80-84), or -- internal,
+ * never accepted from a caller -- LDPC_R_COLS + n: the code cut to its first n columns (ncore < n <= all of them), i.e. the
+ * first n - kb_full rows.  The transport-block chain decodes a segment on such a graph when every row it drops closes on a
+ * degree-1 column whose channel LLRs are ALL ZERO (never transmitted): the check node's input from that column has magnitude 0,
+ * so every message the row sends to the core columns is 0 (cnProc.h:105-114: min over the OTHER inputs), in every pass -- the
+ * core columns' sums, the hard decisions of the information bits and the CRC verdict of every pass are those of the rate mode
+ * the reference would have run.  (Not so the parity check of such a row: only launches that stop on the CRC may use it.) */
+#define LDPC_R_COLS 1000
 int ldpc_build_code_desc(int BG, int Z, int R, ldpc_code_desc_t *d); /* = throughput shape */
 /* The fast kernel's workgroup shape (waves per workgroup, LLR staging; everything else is identical):
  * THROUGHPUT fills a CU's 16 wave slots with as many workgroups as its LDS admits -- for launches of more than one

@@ -115,6 +115,19 @@ int nr_hip_rate_match_geometry(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_t C
   return g->V > 0 ? 0 : -1;
 }
 
+/* Columns of the decoder input that a FIRST transmission can make non-zero: the soft buffer is cleared (nr_ulsch_decoding.c:
+ * 418-422) and receives E values at the transmittable positions of rank rank0 .. rank0 + E - 1 (mod V) -- everything behind
+ * the last position reached stays 0, the fillers (+127) lie in the information columns.  Returns ceil((2 Zc + reach) / Zc),
+ * where reach = Ncb once the lap wraps. */
+uint32_t nr_hip_first_tx_columns(const nr_hip_rm_t *g, uint32_t E, uint32_t Zc)
+{
+  if (E == 0)
+    return 2;
+  const uint32_t last = g->rank0 + E - 1;
+  const uint32_t reach = g->rank0 + E >= g->V ? g->Ncb : (last < g->Foffset ? last : last + g->Fin) + 1;
+  return (2 * Zc + reach + Zc - 1) / Zc;
+}
+
 /* crc_byte.c:314-380.  Polynomials crc_byte.c:46-54 (left aligned); bit-serial, the host only gets here on the slow path of
  * LDPCdecoder (a caller-supplied predicate is a different function; this one is the library's own, see nrLDPC_hip.h). */
 int nr_hip_check_crc(const uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type)

@@ -60,6 +60,8 @@ typedef struct {
 } nr_hip_rm_t;
 int nr_hip_rate_match_geometry(uint32_t Tbslbrm, int BG, uint32_t Zc, uint32_t C, uint32_t F, uint32_t K, int rv,
                                uint32_t E, nr_hip_rm_t *g);
+/* columns of the decoder input a first transmission of E values can reach (the rest is zero) */
+uint32_t nr_hip_first_tx_columns(const nr_hip_rm_t *g, uint32_t E, uint32_t Zc);
 /* check_crc() of openair1/PHY/CODING/crc_byte.c:314-380 for any n: 1 when the CRC of the first n - 8 L bits (MSB first,
  * L = 3 / 3 / 2 / 1 bytes for crc_type 0..3) equals the L bytes in front of byte n >> 3; 0 otherwise and for an unknown type */
 int nr_hip_check_crc(const uint8_t *decoded_bytes, uint32_t n, uint8_t crc_type);

@@ -324,6 +324,16 @@ int tb_fused_mode()
   return e ? atoi(e) : 1;
 }
 
+/* NRLDPC_HIP_TB_TRUNC=0: first transmissions are decoded on the whole graph of the reference's rate mode (cross-check) */
+bool tb_trunc_enabled()
+{
+  static const int v = [] {
+    const char *e = getenv("NRLDPC_HIP_TB_TRUNC");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return v != 0;
+}
+
 bool tb_abort_enabled()
 {
   static const int v = [] {
@@ -368,6 +378,22 @@ int32_t nrLDPC_hip_segmentation(uint32_t B, uint8_t BG, uint32_t *C, uint32_t *K
   return (int32_t)s.Kb;
 }
 uint32_t nrLDPC_hip_get_E(uint32_t G, uint32_t C, uint32_t Qm, uint32_t Nl, uint32_t r) { return nr_hip_get_E(G, C, Qm, Nl, r); }
+/* columns of the code the chain decodes a segment on (nrLDPC_hip.h) */
+int32_t nrLDPC_hip_ulsch_decoder_columns(int32_t BG, uint32_t Zc, uint32_t C, uint32_t F, uint32_t K, uint32_t Tbslbrm, int32_t rv,
+                                         uint32_t E, int32_t round, int32_t R)
+{
+  ldpc_code_desc_t *d = new ldpc_code_desc_t;
+  const int rc = ldpc_build_code_desc(BG, (int)Zc, R, d);
+  const int ncols = d->ncols, ncore = d->ncore;
+  delete d;
+  nr_hip_rm_t rm;
+  if (rc != 0 || nr_hip_rate_match_geometry(Tbslbrm, BG, Zc, C, F, K, rv, E, &rm) != 0)
+    return -1;
+  if (!tb_trunc_enabled() || round != 0)
+    return ncols;
+  return std::min(ncols, std::max((int)nr_hip_first_tx_columns(&rm, E, Zc), ncore + 1));
+}
+
 int32_t nrLDPC_hip_get_R_ldpc_decoder(int32_t rvidx, int32_t E, int32_t BG, int32_t Z, int32_t *llrLen, int32_t round)
 {
   return nr_hip_get_R_ldpc_decoder(rvidx, E, BG, Z, llrLen, round);
@@ -718,7 +744,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   const int fused_mode = tb_fused_mode();
   uint64_t salt[3] = {(uint64_t)b->harq_stride | ((uint64_t)(harq_lib ? 2 : (harq_staged ? 1 : 0)) << 32),
                             (uint64_t)(fused_mode & 0xff) | ((uint64_t)(tb_multi_mode() & 0xff) << 8) | ((uint64_t)tb_classes_enabled() << 16) |
-                                ((uint64_t)(tb_fill_mode() & 0xff) << 24),
+                                ((uint64_t)(tb_fill_mode() & 0xff) << 24) | ((uint64_t)tb_trunc_enabled() << 32),
                             harq_lib ? harq_tbl.gen.load() : 0};
   TbPlan *hit = c.rx.find(tbs, ntb, salt);
   if (hit) {
@@ -820,10 +846,23 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         const CodeEntry *ce = get_code(t.BG, (int)sg.Zc, R);
         if (!ce)
           return -1;
-        const ldpc_code_desc_t &hc = ce->host;
         nr_hip_rm_t rm;
         if (nr_hip_rate_match_geometry(t.tbslbrm, t.BG, sg.Zc, sg.C, sg.F, sg.K, t.rv, E, &rm) != 0)
           return set_error("nr_rate_matching_rx: invalid parameters");
+        if (tb_trunc_enabled() && t.round == 0) {
+          /* A first transmission leaves every soft-buffer position behind the last one it reaches at 0 (the buffer is cleared,
+           * nr_ulsch_decoding.c:418-422), and with them whole degree-1 columns at the end of the rate mode's graph -- at MCS 27 eight
+           * of the nine extension columns of BG1's R = 2/3 mode.  A row that closes on such a column sends zeros to the core columns
+           * in every pass (ldpc_graph.h LDPC_R_COLS) and the chain stops on the CRC: the segment is decoded on the rate mode's graph
+           * cut behind its last column that received anything -- the same payload, verdict and pass count from 87 edges instead of 144. */
+          const int need = std::max((int)nr_hip_first_tx_columns(&rm, E, sg.Zc), ce->host.ncore + 1);
+          if (need < ce->host.ncols) {
+            ce = get_code_cols(t.BG, (int)sg.Zc, need);
+            if (!ce)
+              return -1;
+          }
+        }
+        const ldpc_code_desc_t &hc = ce->host;
         tb_rx_seg_job j;
         memset(&j, 0, sizeof(j));
         j.llr_off = t.coded_off + r_offset;

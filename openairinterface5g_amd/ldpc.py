@@ -414,7 +414,7 @@ class nrLDPC_hip_tb_batch_t(C.Structure):
 EXPORTS += ["nrLDPC_hip_dlsch_encode", "nrLDPC_hip_ulsch_decode", "nrLDPC_hip_segmentation", "nrLDPC_hip_get_E",
             "nrLDPC_hip_get_R_ldpc_decoder", "nrLDPC_hip_harq_release", "nrLDPC_hip_harq_release_all", "nrLDPC_hip_harq_read",
             "nrLDPC_hip_host_alloc", "nrLDPC_hip_host_free", "nrLDPC_hip_host_register", "nrLDPC_hip_host_unregister",
-            "nrLDPC_hip_chain_timing"]
+            "nrLDPC_hip_chain_timing", "nrLDPC_hip_ulsch_decoder_columns"]
 HARQ_STRIDE = 66 * 384
 
 
@@ -428,6 +428,9 @@ def _tb_lib():
     L.nrLDPC_hip_get_E.restype = C.c_uint32
     L.nrLDPC_hip_get_R_ldpc_decoder.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32), C.c_int32]
     L.nrLDPC_hip_get_R_ldpc_decoder.restype = C.c_int32
+    if hasattr(L, "nrLDPC_hip_ulsch_decoder_columns"):
+        L.nrLDPC_hip_ulsch_decoder_columns.argtypes = [C.c_int32] + [C.c_uint32] * 5 + [C.c_int32, C.c_uint32, C.c_int32, C.c_int32]
+        L.nrLDPC_hip_ulsch_decoder_columns.restype = C.c_int32
     if hasattr(L, "nrLDPC_hip_harq_release"):       # (absent from older builds of the library loaded through NRLDPC_HIP_LIB for A/B runs)
         L.nrLDPC_hip_harq_release.argtypes = [C.c_uint64]
         L.nrLDPC_hip_harq_read.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -498,6 +501,11 @@ def nr_get_R_ldpc_decoder(rv, E, BG, Z, llrLen, rnd):
     ll = C.c_int32(llrLen)
     R = _tb_lib().nrLDPC_hip_get_R_ldpc_decoder(rv, E, BG, Z, C.byref(ll), rnd)
     return R, ll.value
+
+
+def ulsch_decoder_columns(BG, Zc, C_, F, K, tbslbrm, rv, E, rnd, R):
+    """columns of the code graph nrLDPC_hip_ulsch_decode() runs a segment on (nrLDPC_hip.h)"""
+    return _tb_lib().nrLDPC_hip_ulsch_decoder_columns(BG, Zc, C_, F, K, tbslbrm, rv, E, rnd, R)
 
 
 def _tb_array(tbs, offs_payload, offs_coded, offs_harq, numMaxIter=8):

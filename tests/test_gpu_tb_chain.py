@@ -645,3 +645,48 @@ def test_abort_stops_the_siblings_of_a_failed_segment(hip):
     assert on["harq"] == off["harq"]                # the soft buffers are written before the decoder runs
     print(f"abort on {on['ms']:.3f} ms, off {off['ms']:.3f} ms")
     assert on["ms"] < 1.05 * off["ms"], (on["ms"], off["ms"])
+
+
+def test_first_transmissions_on_the_cut_graph_equal_the_whole_rate_mode(hip):
+    """High-rate first transmissions (the MCS 27 regime: E reaches column 27-30 of BG1's 35-column R = 2/3 mode, or a few columns
+    of BG2's) are decoded on the rate mode's graph cut behind the last column that received anything
+    (nrLDPC_hip_ulsch_decoder_columns).  The oracle runs the WHOLE mode, as the reference does: payload, ACK and the largest
+    pass count of every block must be equal at noise levels on both sides of the waterfall (pass counts 3 .. cap, lost blocks)."""
+    m = hip.ldpc
+    rng = np.random.default_rng(4242)
+    tbs, n_cut = [], 0
+    for bits, rate, BG, Qm in [(40000, 0.86, 1, 6), (40000, 0.80, 1, 6), (25000, 0.72, 1, 4), (8424 * 3, 0.90, 1, 8), (3000, 0.62, 2, 2),
+                               (1500, 0.55, 2, 4), (40000, 0.86, 1, 6), (60000, 0.78, 1, 6)]:
+        A = valid_tbs(bits, BG)
+        sg = O.segmentation(None, O.len_with_crc(1, A), BG)
+        G = int(A / rate) // (Qm * sg["C"]) * Qm * sg["C"]
+        t = dict(A=A, G=G, BG=BG, Qm=Qm, Nl=1, rv=0, round=0, tbslbrm=0)
+        E = O.get_E(G, sg["C"], Qm, 1, 0)
+        R = O.get_R(0, E, BG, sg["Z"], 0, 0)[0]
+        cols = m.ulsch_decoder_columns(BG, sg["Z"], sg["C"], sg["F"], sg["K"], 0, 0, E, 0, R)
+        n_cut += cols < m.NCOLS[(BG, R)]
+        tbs.append(t)
+    assert n_cut >= 6, n_cut                                     # the cut is what this test exercises
+    pays = [rng.integers(0, 256, t["A"] // 8, dtype=np.uint8) for t in tbs]
+    segs = [O.segmentation(None, O.len_with_crc(1, t["A"]), t["BG"])["C"] for t in tbs]
+    stride = m.HARQ_STRIDE
+    seen = set()
+    for sigma in (1.5, 2.6, 3.2, 4.0):
+        harq_gpu = np.zeros((sum(segs), stride), np.int16)
+        llrs = []
+        for t, p in zip(tbs, pays):
+            f = O.dlsch_encode(t, p)
+            llrs.append(np.clip(np.round((1 - 2 * f.astype(np.float64)) * 8 + sigma * rng.standard_normal(f.size)), -200, 200).astype(np.int16))
+        out, ack, itm = m.ulsch_decode_host(tbs, llrs, harq_gpu, numMaxIter=8)
+        row = 0
+        for i, t in enumerate(tbs):
+            harq_ref = [np.zeros(stride, np.int16) for _ in range(segs[i])]
+            p_ref, ack_ref, its, _ = O.ulsch_decode(t, llrs[i], harq_ref, 8, 0, 0)
+            assert bool(ack[i]) == ack_ref and itm[i] == max(its), (sigma, t, its, int(itm[i]))
+            if ack_ref:
+                assert np.array_equal(out[i], p_ref) and np.array_equal(out[i], pays[i])
+            for r in range(segs[i]):
+                assert np.array_equal(harq_gpu[row + r], harq_ref[r]), (sigma, i, r)
+            row += segs[i]
+            seen.add((bool(ack_ref), max(its)))
+    assert any(a for a, _ in seen) and any(not a for a, _ in seen) and len({n for a, n in seen if a}) >= 3, seen

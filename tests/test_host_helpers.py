@@ -152,3 +152,48 @@ def test_decoder_rate_mode_at_the_exact_boundaries(built):
                         assert R1 == want and ll1 == max(7 * Z, info), (name, BG, Z, rv, E)
                         n += 1
         assert n > 3000
+
+
+def test_columns_a_first_transmission_can_reach_against_the_literal_rate_matching_loop(built):
+    """The chain decodes a first transmission on the rate mode's graph cut behind the last column that received anything
+    (nrLDPC_hip_ulsch_decoder_columns).  The claim that everything behind is zero is checked against the oracle's restatement
+    of nr_rate_matching_ldpc_rx (nr_rate_matching.c:507-603: the literal walk of the circular buffer): E ones go in, the
+    cleared soft buffer comes back, and NO position at or behind the reported column may be non-zero -- while the column in
+    front of it must hold something (the cut is tight), for every rv, with and without LBRM, with fillers, with wrap-around."""
+    import openairinterface5g_amd as pkg
+    m = pkg.ldpc
+    rng = np.random.default_rng(5)
+    n_cut = n_all = n_bad = 0
+    while n_all < 300:
+        BG = int(rng.integers(1, 3))
+        B = int(rng.integers(40, 60000)) * 8
+        sg = m.nr_segmentation(B, BG)
+        if sg is None:
+            continue
+        Z, K, F, C_ = sg["Z"], sg["K"], sg["F"], sg["C"]
+        N = (66 if BG == 1 else 50) * Z
+        rv = int(rng.integers(0, 4))
+        tbslbrm = 0 if rng.random() < 0.6 else int(rng.integers(C_ * N // 3, C_ * N))
+        E = int(rng.integers(K - F, 3 * N)) if rng.random() < 0.3 else int(rng.integers((K - F) // 1, max(K - F + 1, N)))
+        E -= E % 2
+        Foffset = K - F - 2 * Z
+        w = np.zeros(N + 8 * Z, dtype=np.int16)
+        rc, w = O.rate_match_rx(tbslbrm, BG, Z, w, np.ones(E, dtype=np.int16), C_, rv, 1, E, F, Foffset)
+        R, _ = m.nr_get_R_ldpc_decoder(rv, E, BG, Z, 0, 0)
+        cols = m.ulsch_decoder_columns(BG, Z, C_, F, K, tbslbrm, rv, E, 0, R)
+        if rc != 0:
+            assert cols == -1, (BG, B, rv, tbslbrm, E)
+            n_bad += 1
+            continue
+        ncols_mode = m.NCOLS[(BG, R)]
+        ncore = 26 if BG == 1 else 14
+        assert ncore < cols <= ncols_mode
+        nz = np.flatnonzero(w)
+        reach_col = (2 * Z + int(nz[-1])) // Z + 1            # columns 0 .. reach_col - 1 hold something
+        assert cols >= min(reach_col, ncols_mode), (BG, Z, rv, tbslbrm, E, cols, reach_col)      # nothing non-zero is cut off
+        assert cols == min(max(reach_col, ncore + 1), ncols_mode), (BG, Z, rv, tbslbrm, E, cols, reach_col)   # and the cut is tight
+        n_all += 1
+        n_cut += cols < ncols_mode
+        # a retransmission is never cut: the soft buffer's history is the caller's
+        assert m.ulsch_decoder_columns(BG, Z, C_, F, K, tbslbrm, rv, E, 1, R) == ncols_mode
+    assert n_cut > 80 and n_all - n_cut > 80, (n_all, n_cut, n_bad)
