@@ -58,7 +58,7 @@ struct TbPlan {
    * its jobs, so a batch that mixes code sizes is cut into launches by how many workgroups of a job's shape a CU holds
    * (1, 2, 4, 8, 16+): a Zc = 8 segment does not occupy the LDS of a Zc = 384 one.  kind 0: fast kernel, 1: generic
    * kernel, 2 / 3: several small segments per workgroup (f_sub = 1 / 4; grp_off = their ldpc_dec_mgroup array) */
-  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; };
+  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; bool all_fused = false; int max_llr = 0; uint32_t lrow = 0; };
   std::vector<DecLaunch> dec;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
   /* decode: segments / transport blocks that go through the separate de-matching, reassembly and verdict kernels (the others
@@ -331,6 +331,12 @@ bool tb_trunc_enabled()
     const char *e = getenv("NRLDPC_HIP_TB_TRUNC");
     return (e && atoi(e) == 0) ? 0 : 1;
   }();
+  return v != 0;
+}
+
+bool tb_lrow_enabled()
+{
+  static const int v = [] { const char *e = getenv("NRLDPC_HIP_TB_LROW"); return e ? atoi(e) : 1; }();
   return v != 0;
 }
 
@@ -744,7 +750,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   const int fused_mode = tb_fused_mode();
   uint64_t salt[3] = {(uint64_t)b->harq_stride | ((uint64_t)(harq_lib ? 2 : (harq_staged ? 1 : 0)) << 32),
                             (uint64_t)(fused_mode & 0xff) | ((uint64_t)(tb_multi_mode() & 0xff) << 8) | ((uint64_t)tb_classes_enabled() << 16) |
-                                ((uint64_t)(tb_fill_mode() & 0xff) << 24) | ((uint64_t)tb_trunc_enabled() << 32),
+                                ((uint64_t)(tb_fill_mode() & 0xff) << 24) | ((uint64_t)tb_trunc_enabled() << 32) | ((uint64_t)tb_lrow_enabled() << 33),
                             harq_lib ? harq_tbl.gen.load() : 0};
   TbPlan *hit = c.rx.find(tbs, ntb, salt);
   if (hit) {
@@ -756,7 +762,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     std::vector<uint8_t> key_tb((const uint8_t *)tbs, (const uint8_t *)tbs + (size_t)ntb * sizeof(nrLDPC_hip_tb_t));
     std::vector<tb_rx_tb_job> tbj(ntb);
     std::vector<tb_rx_seg_job> sj, sj_legacy;
-    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; };
+    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; int num_llr; };
     std::vector<ShapedJob> single; /* segments that get a workgroup of their own */
     Arena ar;
     TbExtent ex;
@@ -778,9 +784,9 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       const ldpc_code_desc_t &hc = ce->host, &shape = lat_shape ? ce->host_lat : ce->host;
       const double cost = (double)hc.num_llr * dj.num_max_iter;
       if (hc.f_ok)
-        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, std::max(shape.f_lds_total, (int)fused_lds), cost});
+        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, std::max(shape.f_lds_total, (int)fused_lds), cost, hc.num_llr});
       else
-        single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost});
+        single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost, hc.num_llr});
     };
     struct MultiCand { const CodeEntry *ce; ldpc_dec_job dj; };
     std::vector<MultiCand> cands;
@@ -999,8 +1005,12 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         }
       }
       TbPlan::DecLaunch dl{kind, q * sizeof(ldpc_dec_job), 0, (uint32_t)(e - q), threads, lds, false};
-      for (size_t i = q; i < e; i++)
+      dl.all_fused = true;
+      for (size_t i = q; i < e; i++) {
         dl.fused |= single[i].dj.seg_idx >= 0;
+        dl.all_fused &= single[i].dj.seg_idx >= 0;
+        dl.max_llr = std::max(dl.max_llr, single[i].num_llr);
+      }
       dec.push_back(dl);
       q = e;
     }
@@ -1040,6 +1050,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         dec[k - 1].threads = std::max(dec[k - 1].threads, dec[k].threads);
         dec[k - 1].lds = std::max(dec[k - 1].lds, dec[k].lds);
         dec[k - 1].fused |= dec[k].fused;
+        dec[k - 1].all_fused &= dec[k].all_fused;
+        dec[k - 1].max_llr = std::max(dec[k - 1].max_llr, dec[k].max_llr);
         dec.erase(dec.begin() + (long)k);
       } else {
         k++;
@@ -1047,6 +1059,16 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     }
     for (TbPlan::DecLaunch &dl : dec)
       dl.jobs_off += o_single;
+    /* a launch of fused segments keeps the int8 decoder input in LDS when that costs the CU no workgroup (tb_chain.h lrow_off):
+     * no row through memory, no wait for the soft-buffer stores in front of the decoder.  NRLDPC_HIP_TB_LROW=0: off */
+    for (TbPlan::DecLaunch &dl : dec)
+      if (tb_lrow_enabled() && dl.kind == 0 && dl.fused && dl.all_fused) {
+        const int base = (int)align_up((size_t)dl.lds, 16), with_row = base + (int)align_up((size_t)dl.max_llr, 16);
+        if (with_row <= 160 * 1024 && per_cu_of(0, dl.threads, with_row) == per_cu_of(0, dl.threads, dl.lds)) {
+          dl.lrow = (uint32_t)base;
+          dl.lds = with_row;
+        }
+      }
     if (!mgrp[0].empty())
       dec.push_back(TbPlan::DecLaunch{2, o_mj0, o_mg0, (uint32_t)mgrp[0].size(), m_threads[0], m_lds[0], false});
     if (!mgrp[1].empty())
@@ -1227,6 +1249,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   fx.done = d_abort + ntb; fx.gen = reinterpret_cast<uint32_t *>(d_abort + 2 * ntb);
   fx.slots = reinterpret_cast<unsigned long long *>(pl.jobs_d.p + pl.off[6]); fx.pow24a = G().crc_pow_24a_long;
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
+  fx.lrow_off = 0;
   fx.trace = nullptr;
   /* A call that mixes code sizes has several decoder launches (TbPlan::DecLaunch); nothing orders them among themselves --
    * disjoint jobs, scratch rows, per-block state.  NRLDPC_HIP_TB_OVERLAP=1 sends them out on side streams, forked from and
@@ -1278,6 +1301,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         HIP_TRY(hipMemsetAsync(c.trace_d.p, 0, (size_t)dl.n * 128, s));
         fx.trace = reinterpret_cast<unsigned long long *>(c.trace_d.p);
       }
+      fx.lrow_off = dl.lrow;
       HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
       TB_DEBUG_STAGE("fused segment kernel");
       if (fx.trace) {

@@ -51,6 +51,10 @@ struct tb_rx_fused_args {
    * workgroup's prologue runs under its neighbour's decoding; a workgroup that finishes is replaced at once, so the later
    * rounds inherit the offset.  0 ticks: off. */
   uint32_t stagger_ticks, stagger_cus, stagger_slots;
+  /* != 0: the int8 decoder input of a segment never leaves the CU -- it lives this many bytes into the workgroup's LDS (behind
+   * the decoder's own arrays: the launch's LDS size includes it) instead of in the segment's scratch row; every job of the
+   * launch is a fused one then.  The plan does this when the row fits without costing the CU a workgroup. */
+  uint32_t lrow_off;
   /* diagnostics (NRLDPC_HIP_TB_TRACE=<file>): per workgroup {HW_ID, XCC_ID, wall clock at start, after the prologue, after
    * the last pass, at the end, pass count, after: the LDS image is cleared, the LLRs are scattered, the soft buffer is streamed,
    * the decoder input is visible to the workgroup, 0...} as 16 x uint64; NULL normally */

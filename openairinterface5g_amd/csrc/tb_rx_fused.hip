@@ -37,14 +37,23 @@ typedef const tb_rx_tb_job LDPC_CONST_AS *tb_tb_ptr_t;
 template <class T> __device__ __forceinline__ void tb_store_out(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void tb_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-struct tb_rx_fused_io {
+/* LROW: the decoder input lives in the workgroup's LDS (tb_rx_fused_args.lrow_off) -- a compile-time property, so that the
+ * block body's reads of the channel LLRs are LDS instructions and not flat ones */
+template <bool LROW> struct tb_rx_fused_io {
   const ldpc_dec_args &a;
   const tb_rx_fused_args &x;
   ldpc_job_ptr_t job;
+  uint8_t *lds;
   bool tables_early = false; /* the kernel has put the code's tables into LDS already (behind the de-matching stores) */
   __device__ __forceinline__ tb_seg_ptr_t seg() const { return (tb_seg_ptr_t)x.segs + job->seg_idx; }
   __device__ __forceinline__ tb_tb_ptr_t tb() const { return (tb_tb_ptr_t)x.tbs + seg()->tb; }
-  __device__ __forceinline__ const uint32_t *src32() const { return reinterpret_cast<const uint32_t *>(a.llr + (size_t)job->llr_off); }
+  __device__ __forceinline__ const uint32_t *src32() const
+  {
+    if constexpr (LROW)
+      return reinterpret_cast<const uint32_t *>(lds + x.lrow_off);
+    else
+      return reinterpret_cast<const uint32_t *>(a.llr + (size_t)job->llr_off);
+  }
   __device__ __forceinline__ int8_t *out() const { return a.out + (size_t)job->out_off; }
   __device__ __forceinline__ int max_pass() const { return job->num_max_iter + 1; }
   __device__ __forceinline__ int use_crc() const { return 1; }
@@ -205,12 +214,13 @@ struct tb_rx_fused_io {
   }
 };
 
+template <bool LROW>
 __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a, const tb_rx_fused_args x)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   const ldpc_job_ptr_t job = (ldpc_job_ptr_t)a.jobs + blockIdx.x;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)job->code;
-  tb_rx_fused_io io{a, x, job};
+  tb_rx_fused_io<LROW> io{a, x, job, fsm};
   if (x.stagger_ticks && blockIdx.x >= x.stagger_cus && blockIdx.x < x.stagger_cus * x.stagger_slots) {
     const long long until = (long long)wall_clock64() + (long long)(blockIdx.x / x.stagger_cus) * (long long)x.stagger_ticks;
     while ((long long)wall_clock64() < until)
@@ -222,22 +232,35 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* HW_REG_XCC_ID */
     tr[2] = wall_clock64();
   }
-  if (io.tb_fused()) {
+  if (LROW || io.tb_fused()) {
     const tb_seg_ptr_t sj = io.seg();
     const tb_rx_geom g = tb_rx_geometry(sj);
-    tb_rx_dematch_block(g, sj->Qm, x.llr + sj->llr_off, x.harq + sj->harq_off, const_cast<int8_t *>(a.llr) + sj->l_off,
-                        reinterpret_cast<int16_t *>(fsm), tr ? tr + 7 : nullptr);
-    /* the code's tables go into LDS NOW, their loads in flight beside the de-matching stores that the fence below waits for
-     * anyway -- not behind the barrier, in the decoder's prologue, where nothing hides them.  (Only when the de-matching image,
-     * which other waves may still be reading, ends in front of the tables' place: every large code.) */
+    int8_t *l;
+    if constexpr (LROW)
+      l = reinterpret_cast<int8_t *>(fsm + x.lrow_off);
+    else
+      l = const_cast<int8_t *>(a.llr) + sj->l_off;
+    tb_rx_dematch_block(g, sj->Qm, x.llr + sj->llr_off, x.harq + sj->harq_off, l, reinterpret_cast<int16_t *>(fsm), tr ? tr + 7 : nullptr);
+    /* the code's tables go into LDS NOW, their loads in flight beside the de-matching stores -- not behind the barrier, in the
+     * decoder's prologue, where nothing hides them.  (Only when the de-matching image, which other waves may still be
+     * reading, ends in front of the tables' place: every large code.) */
     if (2u * g.span <= (uint32_t)code->f_lds_etbl) {
       ldpc_fast_tables_to_lds(fsm, code, (int)threadIdx.x, (int)blockDim.x);
       io.tables_early = true;
     }
-    /* the decoder input is read back by other waves of this workgroup only: workgroup scope (see ldpc_dec_fast_pull_kernel) */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (LROW) {
+      /* the decoder input is in LDS: a barrier behind the LDS writes makes it visible, and nobody waits for the soft-buffer
+       * stores -- they drain under the decoding.  (__syncthreads() is a workgroup-scope release over every address space: it
+       * waits for the wave's stores to memory too, as the release of the memory-resident row below must.) */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else {
+      /* the decoder input is read back by other waves of this workgroup only: workgroup scope (see ldpc_dec_fast_pull_kernel) */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     if (tr && threadIdx.x == 0)
       tr[10] = wall_clock64();
   }
@@ -254,7 +277,10 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
 
 hipError_t tb_rx_fused_init(void)
 {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess)
+    return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x, int n_threads, int lds_bytes, uint32_t n_jobs, hipStream_t s)
@@ -263,6 +289,9 @@ hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x,
     return hipSuccess;
   if (!a.jobs || !x.segs || !x.tbs)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(tb_rx_fused_kernel, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  if (x.lrow_off)
+    hipLaunchKernelGGL(tb_rx_fused_kernel<true>, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  else
+    hipLaunchKernelGGL(tb_rx_fused_kernel<false>, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
   return hipGetLastError();
 }
