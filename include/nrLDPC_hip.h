@@ -142,7 +142,10 @@ int32_t ldpc_autoinit(void *arg);
  * parameters, HIP failure) is reported as numMaxIter+1 with *ab set, so that callers which only test
  * `<= numMaxIter` (nr_ulsch_decoding.c:219-222) NACK; nrLDPC_hip_last_error() tells why.
  * Calls are served by a resident GPU kernel through per-thread mailboxes (no HIP runtime call per segment); see
- * csrc/ldpc_server.h for NRLDPC_HIP_SERVER / _SRV_SLOTS / _SRV_IDLE_US. */
+ * csrc/ldpc_server.h for NRLDPC_HIP_SERVER / _SRV_SLOTS / _SRV_IDLE_US.
+ * With check_crc set and whole columns of zeros at the end of p_llr (a high-rate first transmission), the call is decoded
+ * without the rows that close on those columns: they send zeros in every pass (nrLDPC_cnProc.h:105-114), so p_out and the
+ * return value are those of the whole rate mode (NRLDPC_HIP_CUT=0: off). */
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab);
 /* Up to 8 segments per call (ldpc_encoder_optim8segmulti.c:46-213): input[j] K/8 bytes MSB first,

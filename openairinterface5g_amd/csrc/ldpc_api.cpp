@@ -1246,6 +1246,50 @@ int32_t LDPCdecoder_batch(const nrLDPC_hip_dec_batch_t *b)
   return rc;
 }
 
+namespace {
+/* NRLDPC_HIP_CUT=0: per-segment calls always run the whole rate mode */
+bool cut_enabled()
+{
+  static const int v = [] { const char *e = getenv("NRLDPC_HIP_CUT"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+/* the rate mode of `ce` cut behind the last column of `llr` that holds a non-zero value, or nullptr when that is the mode
+ * itself.  The scan runs backwards over at most the extension columns (a few KB of zeros when it pays, one word when not). */
+const CodeEntry *cut_code_for(const CodeEntry *ce, const int8_t *llr)
+{
+  if (!cut_enabled())
+    return nullptr;
+  const ldpc_code_desc_t &hc = ce->host;
+  const int Z = hc.Z, floor_cols = hc.ncore + 1;
+  int i = hc.num_llr; /* bytes [i, num_llr) are zero */
+  const int stop = floor_cols * Z;
+  while (i - 8 >= stop) {
+    uint64_t w;
+    memcpy(&w, llr + i - 8, 8);
+    if (w)
+      break;
+    i -= 8;
+  }
+  while (i > stop && llr[i - 1] == 0)
+    i--;
+  const int need = std::max((i + Z - 1) / Z, floor_cols);
+  if (need >= hc.ncols)
+    return nullptr;
+  /* per-thread memo: the published table of get_code() is indexed by rate mode; cut codes live in the locked map */
+  struct Memo { const CodeEntry *full; int need; const CodeEntry *cut; };
+  static thread_local Memo memo[4] = {};
+  for (const Memo &m : memo)
+    if (m.full == ce && m.need == need)
+      return m.cut;
+  const CodeEntry *c = get_code_cols(hc.BG, Z, need);
+  if (!c)
+    return nullptr;
+  static thread_local unsigned next = 0;
+  memo[next++ & 3] = Memo{ce, need, c};
+  return c;
+}
+} // namespace
+
 int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t ulsch_id, uint8_t C, int8_t *p_llr,
                     int8_t *p_out, t_nrLDPC_time_stats *p_profiler, decode_abort_t *ab)
 {
@@ -1271,8 +1315,17 @@ int32_t LDPCdecoder(t_nrLDPC_dec_params *p_decParams, uint8_t harq_pid, uint8_t 
     rc = 1;
     /* resident submission path: no runtime call, no shared lock (ldpc_server.inc.cpp); a CRC predicate that has to run on
      * the host goes through the batch entry point (dec_host_predicate) */
-    if (!(p_decParams->check_crc && !crc_on_device(*p_decParams, ce)) && srv_ready(srv) == 0)
-      rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter, ab);
+    if (!(p_decParams->check_crc && !crc_on_device(*p_decParams, ce)) && srv_ready(srv) == 0) {
+      /* CRC stop with the columns at the end of the rate mode all zero -- what nr_ulsch_decoding.c hands over for a high-rate
+       * first transmission: the rows that close on them send zeros in every pass (ldpc_graph.h LDPC_R_COLS), so the call is
+       * served on the mode cut behind its last column that holds anything; fewer bytes over the link both ways */
+      const CodeEntry *cut = p_decParams->check_crc ? cut_code_for(ce, p_llr) : nullptr;
+      if (cut)
+        rc = srv_decode(p_decParams, cut, p_llr, p_out, &n_iter, ab,
+                        out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1));
+      if (!cut || rc == 1)
+        rc = srv_decode(p_decParams, ce, p_llr, p_out, &n_iter, ab);
+    }
     if (rc == 1) { /* server switched off, or a code it cannot hold: one launch per call on this thread's stream */
       const int ob = out_bytes_of(ce->host, p_decParams->outMode == nrLDPC_outMode_BIT ? 0 : 1);
       nrLDPC_hip_dec_batch_t b;

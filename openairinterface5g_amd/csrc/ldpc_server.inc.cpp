@@ -358,7 +358,11 @@ int srv_submit(Server &S, const SrvCall &c, srv_req &rq, int32_t *n_iter, decode
 }
 
 /* 0: decoded through the server, 1: this code cannot be served (caller uses the launch path), -1: error */
-int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *llr, int8_t *out, int32_t *n_iter, decode_abort_t *ab)
+/* ob_full: the output bytes of the rate mode the caller asked for when `ce` is that mode cut to its first columns (ldpc_api.cpp
+ * LDPCdecoder): what lies behind the cut code's output is zeros -- the hard decisions of degree-1 columns, nrLDPC_bnProc.h has no
+ * code for them -- and is written here; 0: `ce` is the mode itself */
+int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *llr, int8_t *out, int32_t *n_iter, decode_abort_t *ab,
+               int ob_full = 0)
 {
   const ldpc_code_desc_t &hl = ce->host_lat;
   uint32_t kind;
@@ -454,6 +458,8 @@ int srv_decode(const t_nrLDPC_dec_params *p, const CodeEntry *ce, const int8_t *
       } else {
         memcpy(out, c.out, (size_t)ob);
       }
+      if (ob_full > ob)
+        memset(out + ob, 0, (size_t)(ob_full - ob));
     }
   }
   srv.slots[c.slot].host_total_s += srv_now() - t_call;

@@ -278,6 +278,32 @@ def test_per_segment_entry_point_every_code_and_mode(hip):
     assert after["status"] == 0 and after["calls"] - before["calls"] == n_calls, (before, after, n_calls)
 
 
+def test_per_segment_calls_with_an_all_zero_tail_run_on_the_cut_graph_and_say_the_same(hip):
+    """What nr_ulsch_decoding.c hands LDPCdecoder() for a high-rate first transmission: the decoder input of the rate mode
+    nr_get_R_ldpc_decoder chose, with the columns behind the last received value all zero.  In CRC-stop mode the library serves
+    such a call on the mode cut behind its last non-zero column (ldpc_graph.h LDPC_R_COLS); the oracle runs the whole mode:
+    pass counts and EVERY output byte of the whole mode's row (zeros behind the cut) must be equal -- converging and lost
+    blocks, several iteration caps, tails that end inside a column, at a column edge, nowhere (no cut) and everywhere."""
+    rng = np.random.default_rng(77)
+    n_cut = 0
+    for (BG, Z, R, ct) in [(1, 384, 23, 1), (1, 384, 13, 1), (1, 176, 23, 1), (2, 208, 13, 1), (2, 64, 15, 1), (1, 96, 89, 1), (2, 16, 23, 2)]:
+        K, ncols, ncore = kbits(BG, Z), O.NCOLS[(BG, R)], 26 if BG == 1 else 14
+        if K % 8:
+            continue
+        for keep_cols in (ncore - 1.5, ncore + 0.3, ncore + 1.0, ncore + 2.6, (ncore + ncols) / 2, ncols - 0.01, ncols):
+            for kind in (1.0, 4.0, 9.0):
+                info = random_info(rng, BG, Z, with_crc24b=(ct == 1))
+                llr = make_llr(rng, BG, Z, R, kind, info)
+                llr[int(keep_cols * Z):] = 0
+                for it in (2, 3, 8):
+                    p = hip.make_dec_params(BG, Z, R, it, check_crc=True, E=K, crc_type=ct)
+                    n, out = hip.LDPCdecoder(p, llr, p_out=np.full(hip.ldpc.out_bytes(BG, Z, R), 0x33, np.uint8))
+                    n_ref, out_ref = O.decode(BG, Z, R, llr, it, 0, True, K, ct, out_init=0x33)
+                    assert n == n_ref and np.array_equal(out, out_ref), (BG, Z, R, keep_cols, kind, it, n, n_ref)
+                n_cut += keep_cols < ncols - 1
+    assert n_cut > 50
+
+
 def test_bad_parameters(hip):
     with pytest.raises(RuntimeError):
         hip.decode_batch_host(1, 17, 13, np.zeros((1, 68 * 17), np.int8))       # 17 is not a lifting size
