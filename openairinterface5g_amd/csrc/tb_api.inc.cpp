@@ -447,7 +447,7 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   const nrLDPC_hip_tb_t *tbs = b->tb + tb0;
   TbCtx &c = tls_tb;
   const bool fused = ldpc_enc_is_packed() != 0;
-  const uint64_t salt[3] = {fused ? 1u : 0u, 0, 0};
+  const uint64_t salt[3] = {(fused ? 1u : 0u) | (tb_trunc_enabled() ? 2u : 0u), 0, 0};
   TbPlan *hit = c.tx.find(tbs, ntb, salt);
   TbPlan &pl = hit ? *hit : c.tx.victim();
   if (!hit) {
@@ -520,8 +520,17 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         }
         r_offset += j.E;
         sj.push_back(j);
+        /* the fused kernel selects the E transmitted bits straight from the code word in LDS: parity columns behind the last
+         * position the selection reaches are never looked at, so their rows are not computed -- the segment is encoded on the
+         * code cut to the columns it sends (at MCS 27: 2 of BG1's 42 extension rows).  Same output bits. */
+        const CodeEntry *ce_seg = ce;
+        if (fused && tb_trunc_enabled()) {
+          const int need = std::max((int)nr_hip_first_tx_columns(&rm, j.E, sg.Zc), hc.ncore + 1);
+          if (need < hc.ncols && !(ce_seg = get_code_cols(t.BG, (int)sg.Zc, need)))
+            return -1;
+        }
         ldpc_enc_job e;
-        e.code = ce->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
+        e.code = ce_seg->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
         ej.push_back(e);
       }
     }

@@ -263,7 +263,7 @@ def test_slot_prediction_model():
     for N in (1, 2, 4, 8):
         seg, llr, back = [1664 // N] * N, [31451136 // N] * N, [64 * 26650 // N] * N
         res[N] = P.predict_slot_ms(seg, llr, back)
-    assert abs(res[1]["predicted_ms"] - 0.137) < 1e-9 and res[1]["bound"] == "compute"
+    assert abs(res[1]["predicted_ms"] - P.SLOT_MODEL["chain_us_by_segments"][-1][1] / 1e3) < 1e-9 and res[1]["bound"] == "compute"
     assert res[2]["predicted_ms"] > res[4]["predicted_ms"] > res[8]["predicted_ms"] > res[1]["predicted_ms"]
     for N in (2, 4, 8):
         lo, hi = res[N]["predicted_ms_range"]
