@@ -259,14 +259,16 @@ def chain_roofline(pkg, torch):
     for r in range(C_):
         E = m.nr_get_E(G, C_, 6, 1, r)
         R, llr_len = m.nr_get_R_ldpc_decoder(0, E, 1, Zc, llr_len, 0)
-        ncols = m.NCOLS[(1, R)]
+        # columns the chain decodes the segment on: the rate mode's, cut behind the last one a first transmission reaches
+        ncols = m.ulsch_decoder_columns(1, Zc, C_, sg["F"], sg["K"], 0, 0, E, 0, R)
         n = max(66 * Zc, ncols * Zc - 2 * Zc)
         alg += 2 * E + 2 * n + ncols * Zc
     alg *= n_tb
     res = {"kernel": "tb_rx_dematch_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "segments": int(sum(segs)),
            "algorithmic_bytes_per_launch": int(alg),
            "model": "per segment: E int16 in + max(Ncb, decoder positions) int16 soft values out + ncols*Zc int8 out (first "
-                    "transmission: the soft buffer is cleared, not read)"}
+                    "transmission: the soft buffer is cleared, not read; ncols = nrLDPC_hip_ulsch_decoder_columns: the rate "
+                    "mode cut behind the last column that receives anything)"}
     prev = os.environ.get("NRLDPC_HIP_TB_FUSED")
     try:
         for mode, key in (("0", "dematch_us"), ("1", "fused_segment_kernel_us")):
