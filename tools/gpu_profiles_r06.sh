@@ -13,3 +13,8 @@ echo "== decoder timelines"; timeout 300 python tools/dec_trace.py 2>/dev/null >
 DEC_TRACE_CODE=1,384,23 timeout 300 python tools/dec_trace.py 2>/dev/null > $O/dec_trace_r23.txt
 echo "== noise sweep"; timeout 600 python tools/ab_snr.py head: 2>/dev/null | tee $O/snr_sweep.txt
 echo "== soaks"; timeout 200 python tools/soak.py 90 777 2>&1 | tail -3 | tee $O/soak_decoder.txt; timeout 120 python tools/soak_enc.py 45 2>&1 | tail -3 | tee $O/soak_encoder.txt
+echo "== cut graphs (first transmissions / zero tails)"
+for a in 0 1; do echo "NRLDPC_HIP_TB_TRUNC=$a"; NRLDPC_HIP_TB_TRUNC=$a python tools/slot_chain.py 2>&1 | tail -1; done | tee $O/ab_trunc_slot_final.txt
+for a in 0 1; do echo "NRLDPC_HIP_TB_LROW=$a"; NRLDPC_HIP_TB_LROW=$a python tools/slot_chain.py 2>&1 | tail -1; done | tee $O/ab_lrow_slot_final.txt
+for a in 0 1; do echo "NRLDPC_HIP_CUT=$a"; NRLDPC_HIP_CUT=$a python tools/seg_call_latency.py 3000 2>&1 | tail -1; done | tee $O/seg_call_latency.txt
+echo "== BLER curves against the oracle"; timeout 600 python tools/bler_curve.py 2>/dev/null | tee $O/bler_curve.txt
