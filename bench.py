@@ -193,7 +193,7 @@ def strong_slot(pkg, torch, dist, world, rank, steps):
     shares_seg = [int(sum(segs[a:b])) for a, b in sh.tb_ranges]
     shares_llr = [int(co[b] - co[a]) * 2 for a, b in sh.tb_ranges]
     shares_res = [int(po[b] - po[a]) + 5 * int(b - a) for a, b in sh.tb_ranges]
-    pred = parallel.predict_slot_ms(shares_seg, shares_llr, shares_res, chunks=3)
+    pred = parallel.predict_slot_ms(shares_seg, shares_llr, shares_res, chunks=sh.chunks)
     ok = bool(ack.all().item()) and all(torch.equal(pay[po[i]:po[i] + A // 8], payload[po[i]:po[i] + A // 8]) for i in range(n_tb))
     return {"loopback_virtual_ranks": loop, "rccl_p2p_bytes": int(sh.p2p_bytes), "rccl_p2p_bytes_per_slot": int(sh.p2p_bytes // (steps + 2)),
             "workload": "64 PUSCH transport blocks of one slot (273 PRB x 13 symbols, 64QAM, TBS 213 176 bit: 1664 code "

@@ -335,7 +335,7 @@ class ShardedUlsch:
     calls run on the same GPU, one after the other)."""
 
     def __init__(self, tbs: Sequence[dict], root: int = 0, group=None, device=None, numMaxIter: int = 8,
-                 decode_fn: Optional[Callable] = None, chunks: int = 3, loopback: int = 0, transport=None):
+                 decode_fn: Optional[Callable] = None, chunks: Optional[int] = None, loopback: int = 0, transport=None):
         import torch
         from . import ldpc
         self.ldpc, self.root, self.group, self.numMaxIter, self.decode_fn = ldpc, root, group, numMaxIter, decode_fn
@@ -354,6 +354,16 @@ class ShardedUlsch:
         self.tb_ranges = list(zip(self.cut[:-1], self.cut[1:]))
         # chunk k of rank r = transport blocks [chunk_cut[r][k], chunk_cut[r][k+1]) (global indices), balanced by cost;
         # the root's own range is one piece (nothing travels)
+        if chunks is None:
+            # pipeline depth by the model of measured pieces (SLOT_MODEL): every chunk costs the root one more send group, so
+            # the more peers there are the fewer chunks pay -- 3 per peer for two ranks, 2 for four, 1 for eight
+            chunks = 1
+            if self.world > 1:
+                seg_r = [int(sum(self.segs[a:b])) for a, b in self.tb_ranges]
+                llr_r = [int(self.co[b] - self.co[a]) * 2 for a, b in self.tb_ranges]
+                res_r = [int(self.po[b] - self.po[a]) + 5 * int(b - a) for a, b in self.tb_ranges]
+                chunks = min((1, 2, 3), key=lambda n: predict_slot_ms(seg_r, llr_r, res_r, chunks=n, root=root)["predicted_ms"])
+        self.chunks = int(chunks)
         self.chunk_cut = []
         for r, (a, b) in enumerate(self.tb_ranges):
             n = 1 if (r == root or self.world == 1) else max(1, min(chunks, b - a))

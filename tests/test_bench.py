@@ -31,7 +31,7 @@ def test_gpus_n_without_a_launcher_spawns_its_own_ranks(built):
 @pytest.mark.gpu
 def test_rccl_path_runs_on_one_gpu(hip):
     """BENCH_FORCE_DIST=1: process group of one rank on the nccl (= RCCL) backend; the slot of configs[4] is cut for four
-    virtual ranks, 48 of its 64 transport blocks travel as isend / irecv pairs to rank 0 itself in three chunks per virtual
+    virtual ranks, 48 of its 64 transport blocks travel as isend / irecv pairs to rank 0 itself in two chunks per virtual
     peer and their payloads / ACKs / pass counts come back the same way; every payload byte must equal what was sent."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
@@ -42,7 +42,7 @@ def test_rccl_path_runs_on_one_gpu(hip):
     assert line["value"] > 10.0 and line["roofline"]["frac"] > 0 and line["config"]["mean_passes"] == 9.0
     s = line["strong_scaling_slot"]
     assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["transport_blocks_per_rank"] == [16, 16, 16, 16]
-    assert s["loopback_virtual_ranks"] == 4 and s["pipeline_chunks_per_rank"] == [1, 3, 3, 3]
+    assert s["loopback_virtual_ranks"] == 4 and s["pipeline_chunks_per_rank"] == [1, 2, 2, 2]   # (depth by the model: parallel.ShardedUlsch)
     # 48 transport blocks' LLRs out (int16) + their payload bytes, ACKs and pass counts back, per slot
     assert s["rccl_p2p_bytes_per_slot"] >= 48 * (245700 * 2 + 213176 // 8 + 5)
     c = line["chain_roofline"]
@@ -59,7 +59,7 @@ def test_rccl_path_runs_on_one_gpu(hip):
 @pytest.mark.gpu
 def test_rccl_path_with_eight_virtual_ranks(hip):
     """The node's width before the node does it: the slot cut for EIGHT virtual ranks (8 transport blocks each, seven peers'
-    LLRs and results through RCCL send / receive pairs in three chunks per peer), every payload byte compared."""
+    LLRs and results through RCCL send / receive pairs, one chunk per peer -- the depth the model picks for eight ranks), every payload byte compared."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_LOOPBACK_RANKS="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-chain",
                         "--no-operating-point"], capture_output=True, text=True, env=env, timeout=900)
@@ -68,7 +68,7 @@ def test_rccl_path_with_eight_virtual_ranks(hip):
     s = line["strong_scaling_slot"]
     assert "error" not in s and s["all_ack_and_payload_equal"] is True and s["loopback_virtual_ranks"] == 8
     assert s["transport_blocks_per_rank"] == [8] * 8 and s["segments_per_rank"] == [208] * 8
-    assert s["pipeline_chunks_per_rank"] == [1] + [3] * 7
+    assert s["pipeline_chunks_per_rank"] == [1] + [1] * 7       # (eight ranks: one send group per peer, by the model)
     assert s["rccl_p2p_bytes_per_slot"] >= 56 * (245700 * 2 + 213176 // 8 + 5)
 
 

@@ -108,7 +108,7 @@ def _tb_worker(rank, world, port, ret):
             box[0] = [all_tbs[i] for i in (0, 2, 3, 4, 5, 10, 11, 12, 0, 2)]      # real descriptors, CPU-sized
         dist.broadcast_object_list(box, src=0)
         tbs = box[0]
-        sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6)
+        sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, chunks=3)   # (the pipeline exercised whatever the model would pick)
         assert sh.cut[0] == 0 and sh.cut[-1] == len(tbs) and len(sh.cut) == world + 1 and sh.cut == sorted(sh.cut) and 0 < sh.cut[1] < len(tbs)
         # a peer's range travels and is decoded in up to three pieces (of whole transport blocks), the root's own range in one
         assert len(sh.chunk_cut[0]) == 2
@@ -205,7 +205,7 @@ def _loop_worker(port, ret, backend="gloo", device="cpu"):
         from test_gpu_tb_chain import make_tbs
         all_tbs = make_tbs()
         tbs = [all_tbs[i] for i in (0, 2, 3, 4, 5, 10, 11, 12, 0, 2, 3, 4)]
-        sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, loopback=3, device=torch.device(device),
+        sh = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, loopback=3, chunks=3, device=torch.device(device),
                                    transport=parallel.CopyTransport() if backend == "gloo" else None)   # gloo cannot send to itself
         one = parallel.ShardedUlsch(tbs, decode_fn=_oracle_chain_fn, numMaxIter=6, device=torch.device(device))
         assert sh.world == 3 and len(sh.shares) == 3 and [len(c) for c in sh.chunk_cut] == [2, 4, 4]
