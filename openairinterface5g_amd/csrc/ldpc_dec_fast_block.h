@@ -50,6 +50,8 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *   bool tables_resident()    the code's tables are still in this workgroup's LDS from the previous block (resident
  *                             server, same code as last time): the prologue does not copy them again
  *   static bool syndrome      false: the launch stops on the CRC only, the parity of the hard decisions is not computed
+ *   static bool mute_items    with syndrome == false: when io.mute_check() says so for this block, extension-row items whose
+ *   bool mute_check()         degree-1 bits have channel LLR 0 are not run (ldpc_fast_item_is_mute)
  *   static bool bn_tickets    bit-node queue by tickets (f_bn_ticket: short tasks grouped) or by tasks (f_bn_group)
  *   static bool tb_epilogue   the caller may end a block with the transport-block chain's epilogue (tb_rx_fused.hip):
  *   bool tb_fused()           ... and does so for this block: instead of an output row, io.tb_finish(n_iter, bits_word,
@@ -61,6 +63,9 @@ typedef const ldpc_dec_job LDPC_CONST_AS *ldpc_job_ptr_t; /* job records are rea
  *                             pass, instead of folding it into the next pass' check-node phase (which costs a whole
  *                             check-node phase when the block has converged); same results, same pass counts */
 
+#ifndef LDPC_MUTE_ITEMS
+#define LDPC_MUTE_ITEMS 1 /* A/B: tools/build_variant.sh <name> -DLDPC_MUTE_ITEMS=0 */
+#endif
 #define LDPC_EAGER_MAX_BAD_LANES 96
 #define LDPC_TIMING_SLOTS 28
 
@@ -104,6 +109,29 @@ __device__ __forceinline__ void ldpc_fast_tables_to_lds(uint8_t *fsm, ldpc_code_
     coltbl[i] = code->f_coltbl[i];
   for (int i = tid; i < (Z + 4) >> 2; i += nt)
     reinterpret_cast<uint32_t *>(fsm + code->f_lds_zero)[i] = 0u;
+}
+
+/* CRC-stop launches only (IO::syndrome == false).  An extension row's item whose four degree-1 bits have channel LLR 0 -- a
+ * position no transmission has reached -- sends zeros to its core neighbours whatever they say (the minimum over the OTHER inputs
+ * includes that 0, nrLDPC_cnProc.h:105-114), pass after pass; what it sends to the degree-1 bit itself feeds nothing but the row's
+ * own parity check, which a CRC-stop launch does not evaluate.  Such an item writes its zeros in the first pass and is not run
+ * again.  (Whole rows of them at the end of a rate mode are cut from the graph beforehand, ldpc_graph.h LDPC_R_COLS; this catches
+ * the column a transmission ends in, the holes a retransmission leaves, and callers the plan knows nothing about.) */
+__device__ __forceinline__ bool ldpc_fast_item_is_mute(const ldpc_fast_lds &L, int e0, int deg, int j)
+{
+  const uint32_t info = L.etbl[e0 + deg - 1];
+  const uint32_t lw = L.ext_global ? (*reinterpret_cast<const uint32_t *>(L.gllr + info + 4u * (uint32_t)j) ^ 0x80808080u)
+                                   : ldpc_lds_ld32(L.base, info + 4u * (uint32_t)j);
+  return lw == 0x80808080u;
+}
+__device__ __forceinline__ void ldpc_fast_item_zero_messages(const ldpc_fast_lds &L, int e0, int deg, int j, int Z, int rstride)
+{
+  uint8_t *rrow = L.r + e0 * rstride + 4 * j;
+  uint8_t *rpad = rrow + (j == 0 ? Z : 0);
+  for (int k = 0; k < deg; k++) {
+    *reinterpret_cast<uint32_t *>(rrow + k * rstride) = 0x80808080u;
+    *reinterpret_cast<uint32_t *>(rpad + k * rstride) = 0x80808080u;
+  }
 }
 
 /* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
@@ -204,6 +232,10 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
   const int n_cn_tasks = code->f_n_cn_tasks, n_bn_tickets = code->f_n_bn_tickets, n_bn_tasks = code->f_n_bn_tasks,
             bn_group = code->f_bn_group;
   int cn_ticket = 0;
+  bool mute_check = false; /* (wave-uniform: the job's flag) */
+  if constexpr (!IO::syndrome && IO::mute_items)
+    mute_check = io.mute_check();
+  (void)mute_check;
 #ifdef LDPC_TIMING
   /* diagnostic build (tools/task_timing.sh): block 0 logs, for pass 2, every task of every wave into its (oversized)
    * output row as {start << 20 | phase << 8 | degree or loop bound, end} in shader clocks */
@@ -289,7 +321,15 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
           const int e0a = (int)(reca & 0x1ffu), e0b = (int)(recb & 0x1ffu);
           const int valida = (int)(reca >> 16) - 4 * ja, validb = (int)(recb >> 16) - 4 * jb;
           uint32_t ma = 0, mb = 0;
-          if (p == 1)
+          bool mute = false;
+          if constexpr (!IO::syndrome && IO::mute_items)
+            mute = mute_check && ldpc_fast_item_is_mute(L, e0a, deg, ja) && ldpc_fast_item_is_mute(L, e0b, deg, jb);
+          if (mute) {
+            if (p == 1) {
+              ldpc_fast_item_zero_messages(L, e0a, deg, ja, Z, rstride);
+              ldpc_fast_item_zero_messages(L, e0b, deg, jb, Z, rstride);
+            }
+          } else if (p == 1)
             (void)ldpc_fast_cn2_dispatch<true>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
           else
             ma = ldpc_fast_cn2_dispatch<false>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
@@ -312,7 +352,13 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
          * on, the eager check from pass 2 on), so it is not accumulated and the bodies drop it as dead code */
         uint32_t m = 0;
         (void)half;
-        if (p == 1) {
+        bool mute = false;
+        if constexpr (!IO::syndrome && IO::mute_items)
+          mute = mute_check && ext && ldpc_fast_item_is_mute(L, e0, deg, j);
+        if (mute) {
+          if (p == 1)
+            ldpc_fast_item_zero_messages(L, e0, deg, j, Z, rstride);
+        } else if (p == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
           if (pair)
             (void)ldpc_fast_cn19_pair<true>(L, e0, j, Z, rstride, half);

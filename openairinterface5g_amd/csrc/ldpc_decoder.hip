@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_generic_kernel(const ldpc_dec_a
   io.max_pass = (job ? job->num_max_iter : a.num_max_iter) + 1;
   io.use_crc = a.use_crc;
   io.crcE = job ? job->E : a.E;
-  io.crc_pow = job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow;
+  io.crc_pow = job ? a.crc_pow_tbl[job->crc_type & 3] : a.crc_pow;
   io.out_mode = a.out_mode;
   io.tb_abort = (job && a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr;
   io.trace = nullptr;

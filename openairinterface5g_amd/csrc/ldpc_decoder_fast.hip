@@ -33,7 +33,7 @@ template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io 
   __device__ __forceinline__ int use_crc() const { return CRC ? 1 : 0; }
   static constexpr bool syndrome = !CRC;
   __device__ __forceinline__ int crcE() const { return job ? job->E : a.E; }
-  __device__ __forceinline__ const uint32_t *crc_pow() const { return job ? a.crc_pow_tbl[job->crc_type] : a.crc_pow; }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return job ? a.crc_pow_tbl[job->crc_type & 3] : a.crc_pow; }
   __device__ __forceinline__ int out_mode() const { return a.out_mode; }
   __device__ __forceinline__ int *tb_abort() const
   {
@@ -50,6 +50,8 @@ template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io 
   /* homogeneous launches: the parity check of a pass right after it when the block is close to converging (a block that
    * stops saves the next pass' check-node phase; one that does not converge never gets close and pays nothing) */
   __device__ __forceinline__ bool eager_check() const { return !JOBS; }
+  static constexpr bool mute_items = false; /* (the fused segment kernel's retransmission launches only: tb_rx_fused.hip) */
+  __device__ __forceinline__ bool mute_check() const { return false; }
   static constexpr bool bn_tickets = true; /* short bit-node tasks come several to a ticket (ldpc_graph.h f_bn_ticket) */
   static constexpr bool tb_epilogue = false; /* (the chain's fused segment kernel has an IO of its own: tb_rx_fused.hip) */
   __device__ __forceinline__ bool tables_resident() const { return false; }

@@ -10,13 +10,15 @@
 #define LDPC_CRC_POW_LEN 8448 /* x^j mod g for j < 8448 = largest code block */
 
 /* heterogeneous batches (transport-block chain): one job per workgroup overrides code / buffers / E / crc */
+#define LDPC_JOB_MUTE_CHECK 0x100
 struct ldpc_dec_job {
   const ldpc_code_desc_t *code; /* device */
   uint64_t llr_off;             /* bytes from ldpc_dec_args.llr */
   uint64_t out_off;             /* bytes from ldpc_dec_args.out */
   int32_t num_max_iter;
   int32_t E;                    /* CRC mode: bits covered */
-  int32_t crc_type;             /* CRC mode: index into ldpc_dec_args.crc_pow_tbl */
+  int32_t crc_type;             /* CRC mode: index into ldpc_dec_args.crc_pow_tbl (bits 0..7); LDPC_JOB_MUTE_CHECK: extension-row items
+                                   whose degree-1 bits have channel LLR 0 are looked for and not run (ldpc_dec_fast_block.h) */
   int32_t iter_idx;             /* where in ldpc_dec_args.n_iter this block reports */
   int32_t abort_idx;            /* index into ldpc_dec_args.tb_abort of the block's transport block, -1: none */
   int32_t seg_idx;              /* fused segment kernel (tb_rx_fused.hip): index of the segment's tb_rx_seg_job -- the workgroup

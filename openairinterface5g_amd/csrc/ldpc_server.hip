@@ -104,6 +104,8 @@ template <bool CRC> struct srv_fast_io { /* the request header sits in LDS: read
   __device__ __forceinline__ bool eager_check() const { return true; }
   /* one block per CU with as many waves as tasks: grouping short bit-node tasks buys nothing here, and the plain loop is
    * 3 % faster on the large codes (profiles/r03/README.md) */
+  static constexpr bool mute_items = false; /* (the entry point cuts whole zero columns on the host: ldpc_api.cpp cut_code_for) */
+  __device__ __forceinline__ bool mute_check() const { return false; }
   static constexpr bool bn_tickets = false;
   static constexpr bool tb_epilogue = false;
   static constexpr bool syndrome = !CRC;

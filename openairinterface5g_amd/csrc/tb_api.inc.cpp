@@ -58,7 +58,7 @@ struct TbPlan {
    * its jobs, so a batch that mixes code sizes is cut into launches by how many workgroups of a job's shape a CU holds
    * (1, 2, 4, 8, 16+): a Zc = 8 segment does not occupy the LDS of a Zc = 384 one.  kind 0: fast kernel, 1: generic
    * kernel, 2 / 3: several small segments per workgroup (f_sub = 1 / 4; grp_off = their ldpc_dec_mgroup array) */
-  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; bool all_fused = false; int max_llr = 0; uint32_t lrow = 0; };
+  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; bool all_fused = false; int max_llr = 0; uint32_t lrow = 0; bool mute = false; };
   std::vector<DecLaunch> dec;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
   /* decode: segments / transport blocks that go through the separate de-matching, reassembly and verdict kernels (the others
@@ -908,6 +908,13 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         dj.num_max_iter = t.numMaxIter;
         dj.E = nr_hip_len_with_crc((int)sg.C, (int)t.A); /* nr_ulsch_decoding.c:190 */
         dj.crc_type = nr_hip_crc_type((int)sg.C, (int)t.A);
+        /* a retransmission is decoded on the whole rate mode (what earlier rounds left in the soft buffer is the caller's
+         * business) -- but the mode it lands in is usually a larger one, with columns between and behind the transmissions that
+         * nothing has reached: their rows' items are looked for in the kernel and not run (ldpc_dec_fast_block.h; -6 % on the
+         * rv 2 retransmission of the MCS 27 slot).  Not for first transmissions: the cut graph has taken the rows already, and the
+         * look costs two dependent loads per extension item (+1.7 % on that slot). */
+        if (t.round != 0 && tb_trunc_enabled())
+          dj.crc_type |= LDPC_JOB_MUTE_CHECK;
         dj.iter_idx = (int32_t)sj.size();
         dj.abort_idx = tb_abort_enabled() ? (int32_t)i : -1;
         dj.seg_idx = fused_tb ? (int32_t)sj.size() : -1;
@@ -937,12 +944,12 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       if (x.ce != y.ce) return x.ce < y.ce;
       if (x.dj.num_max_iter != y.dj.num_max_iter) return x.dj.num_max_iter < y.dj.num_max_iter;
       if (x.dj.E != y.dj.E) return x.dj.E < y.dj.E;
-      return x.dj.crc_type < y.dj.crc_type;
+      return (x.dj.crc_type & 3) < (y.dj.crc_type & 3);
     });
     for (size_t i0 = 0; i0 < cands.size();) {
       size_t i1 = i0;
       while (i1 < cands.size() && cands[i1].ce == cands[i0].ce && cands[i1].dj.num_max_iter == cands[i0].dj.num_max_iter &&
-             cands[i1].dj.E == cands[i0].dj.E && cands[i1].dj.crc_type == cands[i0].dj.crc_type)
+             cands[i1].dj.E == cands[i0].dj.E && (cands[i1].dj.crc_type & 3) == (cands[i0].dj.crc_type & 3))
         i1++;
       const CodeEntry *ce = cands[i0].ce;
       const ldpc_code_desc_t &hm = ce->host_multi;
@@ -955,7 +962,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
           gq.code = ce->dev_multi;
           gq.first_job = (uint32_t)mjobs[cls].size();
           gq.n_valid = (uint32_t)std::min(per_wg, i1 - k);
-          gq.num_max_iter = cands[i0].dj.num_max_iter; gq.E = cands[i0].dj.E; gq.crc_type = cands[i0].dj.crc_type;
+          gq.num_max_iter = cands[i0].dj.num_max_iter; gq.E = cands[i0].dj.E; gq.crc_type = cands[i0].dj.crc_type & 3;
           for (size_t q = k; q < k + gq.n_valid; q++)
             mjobs[cls].push_back(cands[q].dj);
           mgrp[cls].push_back(gq);
@@ -1018,6 +1025,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       for (size_t i = q; i < e; i++) {
         dl.fused |= single[i].dj.seg_idx >= 0;
         dl.all_fused &= single[i].dj.seg_idx >= 0;
+        dl.mute |= (single[i].dj.crc_type & LDPC_JOB_MUTE_CHECK) != 0;
         dl.max_llr = std::max(dl.max_llr, single[i].num_llr);
       }
       dec.push_back(dl);
@@ -1060,6 +1068,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         dec[k - 1].lds = std::max(dec[k - 1].lds, dec[k].lds);
         dec[k - 1].fused |= dec[k].fused;
         dec[k - 1].all_fused &= dec[k].all_fused;
+        dec[k - 1].mute |= dec[k].mute;
         dec[k - 1].max_llr = std::max(dec[k - 1].max_llr, dec[k].max_llr);
         dec.erase(dec.begin() + (long)k);
       } else {
@@ -1259,6 +1268,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   fx.slots = reinterpret_cast<unsigned long long *>(pl.jobs_d.p + pl.off[6]); fx.pow24a = G().crc_pow_24a_long;
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
   fx.lrow_off = 0;
+  fx.mute = 0;
   fx.trace = nullptr;
   /* A call that mixes code sizes has several decoder launches (TbPlan::DecLaunch); nothing orders them among themselves --
    * disjoint jobs, scratch rows, per-block state.  NRLDPC_HIP_TB_OVERLAP=1 sends them out on side streams, forked from and
@@ -1311,6 +1321,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         fx.trace = reinterpret_cast<unsigned long long *>(c.trace_d.p);
       }
       fx.lrow_off = dl.lrow;
+      fx.mute = dl.mute ? 1u : 0u;
       HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
       TB_DEBUG_STAGE("fused segment kernel");
       if (fx.trace) {

@@ -55,6 +55,8 @@ struct tb_rx_fused_args {
    * the decoder's own arrays: the launch's LDS size includes it) instead of in the segment's scratch row; every job of the
    * launch is a fused one then.  The plan does this when the row fits without costing the CU a workgroup. */
   uint32_t lrow_off;
+  /* != 0: some job of the launch carries LDPC_JOB_MUTE_CHECK (retransmissions): the instantiation that looks for mute items */
+  uint32_t mute;
   /* diagnostics (NRLDPC_HIP_TB_TRACE=<file>): per workgroup {HW_ID, XCC_ID, wall clock at start, after the prologue, after
    * the last pass, at the end, pass count, after: the LDS image is cleared, the LLRs are scattered, the soft buffer is streamed,
    * the decoder input is visible to the workgroup, 0...} as 16 x uint64; NULL normally */

@@ -39,7 +39,7 @@ __device__ __forceinline__ void tb_wait_stores() { asm volatile("s_waitcnt vmcnt
 
 /* LROW: the decoder input lives in the workgroup's LDS (tb_rx_fused_args.lrow_off) -- a compile-time property, so that the
  * block body's reads of the channel LLRs are LDS instructions and not flat ones */
-template <bool LROW> struct tb_rx_fused_io {
+template <bool LROW, bool MUTE = false> struct tb_rx_fused_io {
   const ldpc_dec_args &a;
   const tb_rx_fused_args &x;
   ldpc_job_ptr_t job;
@@ -59,7 +59,7 @@ template <bool LROW> struct tb_rx_fused_io {
   __device__ __forceinline__ int use_crc() const { return 1; }
   static constexpr bool syndrome = false; /* CRC stop: nobody looks at the parity of the hard decisions */
   __device__ __forceinline__ int crcE() const { return job->E; }
-  __device__ __forceinline__ const uint32_t *crc_pow() const { return a.crc_pow_tbl[job->crc_type]; }
+  __device__ __forceinline__ const uint32_t *crc_pow() const { return a.crc_pow_tbl[job->crc_type & 3]; }
   __device__ __forceinline__ int out_mode() const { return 0; }
   __device__ __forceinline__ int *tb_abort() const { return (a.tb_abort && job->abort_idx >= 0) ? a.tb_abort + job->abort_idx : nullptr; }
   __device__ __forceinline__ uint32_t *stamps() const { return nullptr; }
@@ -67,6 +67,9 @@ template <bool LROW> struct tb_rx_fused_io {
   __device__ __forceinline__ int fair_turns() const { return a.fair; }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ bool eager_check() const { return false; }
+  static constexpr bool mute_items = MUTE; /* launches that hold retransmissions: an instantiation of their own, so that the look
+                                              for mute items costs first transmissions nothing (its mere presence was +1 %) */
+  __device__ __forceinline__ bool mute_check() const { return job->crc_type & LDPC_JOB_MUTE_CHECK; }
   static constexpr bool bn_tickets = true;
   __device__ __forceinline__ bool tables_resident() const { return tables_early; }
   __device__ __forceinline__ uint32_t out_tag() const { return 0u; }
@@ -214,13 +217,13 @@ template <bool LROW> struct tb_rx_fused_io {
   }
 };
 
-template <bool LROW>
+template <bool LROW, bool MUTE>
 __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a, const tb_rx_fused_args x)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   const ldpc_job_ptr_t job = (ldpc_job_ptr_t)a.jobs + blockIdx.x;
   ldpc_code_ptr_t code = (ldpc_code_ptr_t)job->code;
-  tb_rx_fused_io<LROW> io{a, x, job, fsm};
+  tb_rx_fused_io<LROW, MUTE> io{a, x, job, fsm};
   if (x.stagger_ticks && blockIdx.x >= x.stagger_cus && blockIdx.x < x.stagger_cus * x.stagger_slots) {
     const long long until = (long long)wall_clock64() + (long long)(blockIdx.x / x.stagger_cus) * (long long)x.stagger_ticks;
     while ((long long)wall_clock64() < until)
@@ -277,10 +280,14 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
 
 hipError_t tb_rx_fused_init(void)
 {
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess)
-    return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(tb_rx_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void *k[4] = {reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false>),
+                      reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true>)};
+  for (const void *f : k) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x, int n_threads, int lds_bytes, uint32_t n_jobs, hipStream_t s)
@@ -289,9 +296,13 @@ hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x,
     return hipSuccess;
   if (!a.jobs || !x.segs || !x.tbs)
     return hipErrorInvalidValue;
-  if (x.lrow_off)
-    hipLaunchKernelGGL(tb_rx_fused_kernel<true>, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  if (x.lrow_off && x.mute)
+    hipLaunchKernelGGL((tb_rx_fused_kernel<true, true>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  else if (x.lrow_off)
+    hipLaunchKernelGGL((tb_rx_fused_kernel<true, false>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+  else if (x.mute)
+    hipLaunchKernelGGL((tb_rx_fused_kernel<false, true>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
   else
-    hipLaunchKernelGGL(tb_rx_fused_kernel<false>, dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    hipLaunchKernelGGL((tb_rx_fused_kernel<false, false>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
   return hipGetLastError();
 }
