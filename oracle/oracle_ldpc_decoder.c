@@ -48,13 +48,20 @@ int oracle_ldpc_graph(int BG, int Z, int R, oracle_graph_t *g)
   if (BG == 1) {
     deg = oracle_bg1_row_deg; col = oracle_bg1_col; sh = oracle_bg1_shift[ils];
     nrows_all = 46; g->ncore = 26;
-    if (R == 13) g->ncols = 68; else if (R == 23) g->ncols = 35; else if (R == 89) g->ncols = 27; else return -1;
+    if (R == 13) g->ncols = 68; else if (R == 23) g->ncols = 35; else if (R == 89) g->ncols = 27;
+    else if (R > 1000 + 26 && R <= 1000 + 68) g->ncols = R - 1000; /* NOT a mode of the reference: see below */
+    else return -1;
   } else if (BG == 2) {
     deg = oracle_bg2_row_deg; col = oracle_bg2_col; sh = oracle_bg2_shift[ils];
     nrows_all = 42; g->ncore = 14;
-    if (R == 15) g->ncols = 52; else if (R == 13) g->ncols = 32; else if (R == 23) g->ncols = 17; else return -1;
+    if (R == 15) g->ncols = 52; else if (R == 13) g->ncols = 32; else if (R == 23) g->ncols = 17;
+    else if (R > 1000 + 14 && R <= 1000 + 52) g->ncols = R - 1000;
+    else return -1;
   } else
     return -1;
+  /* (R = 1000 + n: the base graph cut to its first n columns.  The reference has no such mode; the product decodes CRC-stop calls
+   * whose last columns are all zero on such a graph and claims the results are the whole mode's -- tests/test_oracle.py runs
+   * THIS restatement of the reference's arithmetic both ways to check the claim without a GPU.) */
   /* ncols = ncore-4+... : rows processed = ncols - Kb_full  (68-22 = 46, 35-22 = 13, 27-22 = 5, ...) */
   g->nrows = g->ncols - (BG == 1 ? 22 : 10);
   if (g->nrows > nrows_all)

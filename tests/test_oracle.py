@@ -204,3 +204,38 @@ def test_oai_rng_is_deterministic_and_gaussian():
     assert O.OaiRng(2).uniform() == O.OaiRng(3).uniform()       # even seeds are bumped to odd (rangen_double.c:67-68)
     assert O.lib().oracle_quantize(0.5, 1000.0, 8) == 127 and O.lib().oracle_quantize(0.5, -1000.0, 8) == -128
     assert O.lib().oracle_quantize(0.5, -0.1, 8) == -1            # floor, not round
+
+
+def test_rows_that_close_on_all_zero_columns_say_nothing_in_crc_stop_mode():
+    """The claim behind the product's cut graphs (ldpc_graph.h LDPC_R_COLS), checked on the ORACLE alone -- the
+    restatement of the reference's arithmetic, no GPU, no product code: a decoder input whose last columns are all zero, decoded
+    in CRC-stop mode (a) on the whole rate mode, as the reference would, and (b) on the base graph cut behind the last non-zero
+    column.  Pass counts and every output byte in front of the cut must be equal, what lies behind the cut in (a) must be
+    zeros (degree-1 columns get no hard decision: F5) -- for converging and lost blocks, every iteration cap, cuts inside a
+    column, at a column edge and right behind the core.  In PARITY-CHECK mode the claim does NOT hold (the dropped rows' own
+    checks count), and the test shows that too."""
+    rng = np.random.default_rng(606)
+    n_cases, pc_differs = 0, 0
+    for (BG, Z, R) in [(1, 384, 23), (1, 96, 13), (1, 176, 23), (2, 208, 13), (2, 64, 15), (1, 32, 89), (2, 16, 23)]:
+        K, ncols, ncore = kbits(BG, Z), O.NCOLS[(BG, R)], 26 if BG == 1 else 14
+        if K % 8:
+            continue
+        for keep in (ncore + 0.4, ncore + 1.0, ncore + 2.7, (ncore + ncols) / 2):
+            if keep >= ncols - 1:
+                continue
+            for kind in (0.5, 3.0, 8.0):
+                info = random_info(rng, BG, Z, with_crc24b=True)
+                llr = make_llr(rng, BG, Z, R, kind, info)
+                llr[int(keep * Z):] = 0
+                need = max(-(-int(keep * Z) // Z), ncore + 1)
+                for it in (1, 3, 8):
+                    n_a, out_a = O.decode(BG, Z, R, llr, it, 0, True, K, 1, out_init=0x5a)
+                    n_b, out_b = O.decode(BG, Z, 1000 + need, llr[:need * Z], it, 0, True, K, 1, out_init=0x5a)
+                    assert n_a == n_b, (BG, Z, R, keep, kind, it, n_a, n_b)
+                    if n_a >= 3 and n_a <= it + 1:      # (the reference leaves p_out alone before the first CRC look)
+                        assert np.array_equal(out_a[:out_b.size], out_b) and not out_a[out_b.size:].any(), (BG, Z, R, keep, kind, it)
+                    n_cases += 1
+                n_pa, _ = O.decode(BG, Z, R, llr, 8)
+                n_pb, _ = O.decode(BG, Z, 1000 + need, llr[:need * Z], 8)
+                pc_differs += n_pa != n_pb
+    assert n_cases > 150 and pc_differs > 0, (n_cases, pc_differs)
