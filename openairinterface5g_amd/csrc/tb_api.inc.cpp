@@ -495,6 +495,8 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       enc_threads = std::max(enc_threads, nthr);
       enc_lds = std::max(enc_lds, nlds);
       uint32_t r_offset = 0;
+      const CodeEntry *cut_ce = nullptr;
+      int cut_need = 0;
       for (uint32_t r = 0; r < sg.C; r++) {
         tb_tx_seg_job j;
         memset(&j, 0, sizeof(j));
@@ -526,8 +528,14 @@ int tb_tx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         const CodeEntry *ce_seg = ce;
         if (fused && tb_trunc_enabled()) {
           const int need = std::max((int)nr_hip_first_tx_columns(&rm, j.E, sg.Zc), hc.ncore + 1);
-          if (need < hc.ncols && !(ce_seg = get_code_cols(t.BG, (int)sg.Zc, need)))
-            return -1;
+          if (need < hc.ncols) {
+            if (!(cut_ce && cut_need == need)) {
+              cut_ce = get_code_cols(t.BG, (int)sg.Zc, need);
+              cut_need = need;
+            }
+            if (!(ce_seg = cut_ce))
+              return -1;
+          }
         }
         ldpc_enc_job e;
         e.code = ce_seg->dev; e.in_off = j.c_off; e.out_off = j.d_off; e.Kb = (int32_t)sg.Kb; e.pad = 0;
@@ -854,6 +862,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       ex.pay_sum += t.A / 8;
       uint32_t r_offset = 0;
       int llrLen = t.llrLen;
+      const CodeEntry *cut_ce = nullptr;
+      int cut_need = 0;
       for (uint32_t r = 0; r < sg.C; r++) {
         const uint32_t E = nr_hip_get_E(t.G, sg.C, t.Qm, t.Nl, r);
         /* nr_ulsch_decoding.c:439-444: decoder rate mode, stateful in llrLen */
@@ -872,7 +882,11 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
            * cut behind its last column that received anything -- the same payload, verdict and pass count from 87 edges instead of 144. */
           const int need = std::max((int)nr_hip_first_tx_columns(&rm, E, sg.Zc), ce->host.ncore + 1);
           if (need < ce->host.ncols) {
-            ce = get_code_cols(t.BG, (int)sg.Zc, need);
+            if (!(cut_ce && cut_need == need)) { /* (the segments of a block agree but for one symbol: one locked look-up per block) */
+              cut_ce = get_code_cols(t.BG, (int)sg.Zc, need);
+              cut_need = need;
+            }
+            ce = cut_ce;
             if (!ce)
               return -1;
           }
@@ -1269,6 +1283,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
   fx.lrow_off = 0;
   fx.mute = 0;
+  fx.prio_pro = 0;
   fx.trace = nullptr;
   /* A call that mixes code sizes has several decoder launches (TbPlan::DecLaunch); nothing orders them among themselves --
    * disjoint jobs, scratch rows, per-block state.  NRLDPC_HIP_TB_OVERLAP=1 sends them out on side streams, forked from and
@@ -1322,6 +1337,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       }
       fx.lrow_off = dl.lrow;
       fx.mute = dl.mute ? 1u : 0u;
+      {
+        static const int prio_env = [] { const char *e = getenv("NRLDPC_HIP_TB_PRIO"); return e ? atoi(e) : 1; }();
+        fx.prio_pro = per_cu >= 2 ? (uint32_t)prio_env : 0u;
+      }
       HIP_TRY(tb_launch_rx_fused(da, fx, dl.threads, dl.lds, dl.n, s));
       TB_DEBUG_STAGE("fused segment kernel");
       if (fx.trace) {

@@ -112,10 +112,23 @@ TB_RX_HD void tb_rx_phase_load_first(const tb_rx_geom &g, const int16_t *__restr
   }
 }
 /* one symbol's Qm values to their slots (lap `lap` of `nlaps`: only the values whose k falls into this lap) */
-template <int QM>
+/* ONE: the transmission is a single lap of the circular buffer (E <= V: everything but repetition) -- every value is a plain
+ * store, and the code is straight-line: the general form below is a branch per value (is k in this lap? first lap or add?), and
+ * with two dozen values per thread the branches, not the arithmetic, were the 3.9 us this phase took (profiles/r06) */
+template <int QM, bool ONE = false>
 TB_RX_HD void tb_rx_scatter_symbol(const tb_rx_geom &g, const tb_sym<QM> &sy, uint32_t jj, int16_t *e_lds, uint32_t lap, uint32_t nlaps)
 {
   const uint32_t V = g.V, rank0 = g.rank0, Foffset = g.Foffset, Fin = g.Fin, p_align = g.p_align, Ncb = g.Ncb, EQ = g.E / QM;
+  if (ONE) {
+#pragma unroll
+    for (int i = 0; i < QM; i++) {
+      const int16_t v = (int16_t)(sy.w[i >> 1] >> (16 * (i & 1)));
+      uint32_t r = rank0 + (uint32_t)i * EQ + jj;
+      r = r >= V ? r - V : r;
+      e_lds[tb_rx_slot(r < Foffset ? r : r + Fin, p_align, Ncb)] = v;
+    }
+    return;
+  }
   const uint32_t k_lo = lap * V, k_hi = k_lo + V; /* this lap's k range; (rank0 + k - k_lo) < 2V: one conditional subtract */
 #pragma unroll
   for (int i = 0; i < QM; i++) {
@@ -129,7 +142,7 @@ TB_RX_HD void tb_rx_scatter_symbol(const tb_rx_geom &g, const tb_sym<QM> &sy, ui
     }
   }
 }
-template <int QM>
+template <int QM, bool ONE = false>
 TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__restrict__ f, int16_t *e_lds, uint32_t lap, uint32_t nlaps,
                                       uint32_t tid, uint32_t nt, const tb_rx_ahead &first)
 {
@@ -143,7 +156,7 @@ TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__rest
 #pragma unroll
       for (int i = 0; i < QM / 2; i++)
         sy.w[i] = first.w[u][i];
-      tb_rx_scatter_symbol<QM>(g, sy, jj, e_lds, lap, nlaps);
+      tb_rx_scatter_symbol<QM, ONE>(g, sy, jj, e_lds, lap, nlaps);
     }
   }
   for (uint32_t jj0 = tid + TB_RX_U * nt; jj0 < EQ; jj0 += 2 * nt) { /* the rest, two symbols per step */
@@ -164,7 +177,7 @@ TB_RX_HD void tb_rx_phase_scatter_lap(const tb_rx_geom &g, const int16_t *__rest
     for (int u = 0; u < 2; u++) {
       const uint32_t jj = jj0 + (uint32_t)u * nt;
       if (jj < EQ)
-        tb_rx_scatter_symbol<QM>(g, sy[u], jj, e_lds, lap, nlaps);
+        tb_rx_scatter_symbol<QM, ONE>(g, sy[u], jj, e_lds, lap, nlaps);
     }
   }
 }
@@ -289,6 +302,15 @@ __device__ __forceinline__ void tb_rx_dematch_block(const tb_rx_geom &g, uint32_
   if (stamps && tid == 0)
     stamps[0] = wall_clock64();
   const uint32_t nlaps = tb_rx_laps(g);
+  if (nlaps == 1) {
+    switch (Qm) {
+      case 2: tb_rx_phase_scatter_lap<2, true>(g, f, e_lds, 0, 1, tid, nt, first); break;
+      case 4: tb_rx_phase_scatter_lap<4, true>(g, f, e_lds, 0, 1, tid, nt, first); break;
+      case 6: tb_rx_phase_scatter_lap<6, true>(g, f, e_lds, 0, 1, tid, nt, first); break;
+      default: tb_rx_phase_scatter_lap<8, true>(g, f, e_lds, 0, 1, tid, nt, first); break;
+    }
+    __syncthreads();
+  } else
   switch (Qm) {
     case 2:
       for (uint32_t lap = 0; lap < nlaps; lap++) { tb_rx_phase_scatter_lap<2>(g, f, e_lds, lap, nlaps, tid, nt, first); __syncthreads(); }

@@ -89,6 +89,8 @@ template <bool LROW, bool MUTE = false> struct tb_rx_fused_io {
   template <class Bits> __device__ __forceinline__ void tb_finish(int n_iter, Bits bits_word, int *flags) const
   {
     const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u;
+    if (x.prio_pro & 2u)
+      __builtin_amdgcn_s_setprio(3);
     if (x.trace && tid == 0)
       x.trace[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
     const tb_seg_ptr_t sj = seg();
@@ -236,6 +238,11 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     tr[2] = wall_clock64();
   }
   if (LROW || io.tb_fused()) {
+    /* the prologue is a chain of short steps (clear, scatter, stream) with little arithmetic: at the CU's other workgroup's
+     * mercy -- an older wave that decodes wins every issue slot -- it took 8 us; with the issue priority raised for its duration
+     * it costs the decoder next door a few hundred instructions (x.prio_pro; profiles/r06/ab_prologue_priority.txt) */
+    if (x.prio_pro)
+      __builtin_amdgcn_s_setprio(3);
     const tb_seg_ptr_t sj = io.seg();
     const tb_rx_geom g = tb_rx_geometry(sj);
     int8_t *l;
@@ -266,6 +273,8 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
     }
     if (tr && threadIdx.x == 0)
       tr[10] = wall_clock64();
+    if (x.prio_pro)
+      __builtin_amdgcn_s_setprio(0);
   }
   if (tr && threadIdx.x == 0)
     tr[3] = wall_clock64();

@@ -401,6 +401,11 @@ template <int QM> static void emul_scatter(const tb_rx_geom &g, const int16_t *f
     tb_rx_phase_zero(g, e_lds, l, (uint32_t)tid, (uint32_t)nt);
   }
   const uint32_t nlaps = tb_rx_laps(g);
+  if (nlaps == 1) { /* the straight-line form of a single lap, as tb_rx_dematch_block picks it */
+    for (int tid = 0; tid < nt; tid++)
+      tb_rx_phase_scatter_lap<QM, true>(g, f, e_lds, 0, 1, (uint32_t)tid, (uint32_t)nt, first[tid]);
+    return;
+  }
   for (uint32_t lap = 0; lap < nlaps; lap++)
     for (int tid = 0; tid < nt; tid++)
       tb_rx_phase_scatter_lap<QM>(g, f, e_lds, lap, nlaps, (uint32_t)tid, (uint32_t)nt, first[tid]);
