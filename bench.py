@@ -4,6 +4,9 @@
 metric   : coded Gb/s of the NR LDPC decoder, BG1 Zc=384 R=1/3, 8-iteration cap (configs[1]): batch of 1024
            code blocks per GPU and step, inputs resident in HBM before the timed region starts.
 step     : one decode of the whole batch through LDPCdecoder_batch (C ABI, device pointers).
+clocks   : the GPU's clocks ramp for ~30 ms of continuous work after idling (profiles/r06/clock_ramp.txt).  The W + K steps are
+           taken twice: straight after set-up ("after_idle", what rounds 1-5 called value) and again after untimed launches
+           have brought the clocks up (value).  Both timed regions are exactly K full steps.
 value    : ranks * steps * 1024 * 25 344 coded bits / wall time (max over ranks), FIXED-WORK regime: the LLRs are
            a code word buried in noise (Es/N0 = -12 dB) so the parity check never passes and all 9 CN/BN passes
            run for every block -- the worst case the 8-iteration cap allows.  An operating-point run (early
@@ -398,9 +401,39 @@ def main():
         timed.per_rank_ms = [x / steps * 1e3 for x in per_rank]
         return dt, kern_ms
 
+    def settle(llr):
+        """Untimed launches until the GPU's clocks have come up.  After an idle period (process start, set-up on the host)
+        the clocks ramp for ~30 ms of continuous work (profiles/r06/clock_ramp.txt: 0.417 -> 0.376 ms per launch); the
+        driver's W = 5 warm-up steps are 2 ms.  Chunks of 25 launches, event-timed, until a chunk is no longer 0.5 % faster
+        than the one before it (twice), at most 40 chunks.  Nothing of this is inside a timed region; the W warm-up steps
+        and the K timed steps follow as the contract says.  BENCH_NO_SETTLE=1 switches it off."""
+        chunks = []
+        if os.environ.get("BENCH_NO_SETTLE") == "1":
+            return chunks
+        flat = 0
+        while len(chunks) < 40 and flat < 2:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(25):
+                step(llr)
+            e1.record()
+            e1.synchronize()
+            chunks.append(e0.elapsed_time(e1) / 25)
+            flat = flat + 1 if len(chunks) > 1 and chunks[-1] > 0.995 * chunks[-2] else 0
+        return chunks
+
     if dist is not None:   # first collectives set up the communicator: keep that out of every timed region
         dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- the same K steps right after set-up, clocks still ramping (what rounds 1-5's lines measured) ---
+    dt_cold, _ = timed(llr_fixed, args.steps, args.warmup)
+    cold = {"ms_per_step": dt_cold / args.steps * 1e3, "gbps": world * args.steps * BATCH * N_TX / dt_cold / 1e9,
+            "what": "W warm-up + K timed steps taken first, straight after set-up: the GPU's clocks are still ramping "
+                    "(profiles/r06/clock_ramp.txt); rounds 1-5 reported this figure as `value`"}
+    settle_ms = settle(llr_fixed)
+    cold["settle_launches"] = 25 * len(settle_ms)
+    cold["settle_ms_per_launch_first_last"] = [settle_ms[0], settle_ms[-1]] if settle_ms else None
 
     # ---- headline: fixed work (all 9 passes) ----------------------------------------------------------
     dt, kern_ms = timed(llr_fixed, args.steps, args.warmup)
@@ -412,14 +445,18 @@ def main():
     # ---- operating point: Es/N0 = 1 dB, early stop on parity check ------------------------------------
     op = None
     if not args.no_operating_point:
-        dt_op, _ = timed(llr_op, max(5, args.steps // 2), 2)
+        # a launch of this leg is 0.24 ms: with K // 2 steps (10 at the driver's K = 20) the closing synchronize() and the host
+        # clock were 4 % of the figure; the leg takes its own step count (it is not the contract's timed region)
+        op_steps = max(40, args.steps)
+        dt_op, _ = timed(llr_op, op_steps, 2)
         it_h = n_iter.cpu().numpy()
         ok = it_h <= MAX_ITER
         good = ok & (out[:, :K // 8] == info_op).all(dim=1).cpu().numpy()
         stats = torch.tensor([float((~good).sum()), float(it_h.sum()), float(BATCH)], dtype=torch.float64, device="cuda")
         if dist is not None:
             dist.all_reduce(stats)                          # result gather, outside every timed region
-        op = {"snr_db": 1.0, "gbps": world * max(5, args.steps // 2) * BATCH * N_TX / dt_op / 1e9,
+        op = {"snr_db": 1.0, "gbps": world * op_steps * BATCH * N_TX / dt_op / 1e9, "steps": op_steps,
+              "ms_per_step": dt_op / op_steps * 1e3,
               "bler": float(stats[0] / stats[2]), "mean_passes": float(stats[1] / stats[2])}
 
     def emit(strong, chain, devices, with_cpu):
@@ -468,6 +505,7 @@ def main():
                                    "fixed work (Es/N0=-12 dB: all 9 passes run), parity-check stop mode",
                        "blocks_per_gpu": BATCH, "coded_bits_per_block": N_TX, "mean_passes": passes_fixed,
                        "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective"},
+            "after_idle": cold,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # `traffic` and binding_resource's counter figures are NOT measured in this run: rocprofv3 PMC
