@@ -22,7 +22,7 @@ int dec_jobs_enqueue(const nrLDPC_hip_dec_job_t *jobs, uint32_t n, int32_t *n_it
   const t_nrLDPC_dec_params &p0 = jobs[0].params;
   const int out_mode = p0.outMode == nrLDPC_outMode_BIT ? 0 : 1, use_crc = p0.check_crc != nullptr;
   if (!hit) {
-    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; };
+    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; int zc; };
     std::vector<ShapedJob> v(n);
     const bool lat_shape = n <= (uint32_t)G().n_cus;
     const bool classes = tb_classes_enabled() && !lat_shape;
@@ -56,6 +56,7 @@ int dec_jobs_enqueue(const nrLDPC_hip_dec_job_t *jobs, uint32_t n, int32_t *n_it
       v[i].threads = fast ? shape.f_n_threads : hc.n_threads;
       v[i].lds = fast ? shape.f_lds_total : hc.lds_total;
       v[i].cost = (double)hc.num_llr * p.numMaxIter;
+      v[i].zc = (fast && shape.f_mb == 1 && shape.f_rstride == shape.Z + 4 && shape.f_astride == 2 * shape.Z) ? shape.Z : 0;
     }
     auto per_cu_of = [&](int kind, int threads, int lds) {
       const int waves = kind == 0 ? 16 : 32;
@@ -90,7 +91,12 @@ int dec_jobs_enqueue(const nrLDPC_hip_dec_job_t *jobs, uint32_t n, int32_t *n_it
           room--;
         }
       }
-      dec.push_back(TbPlan::DecLaunch{kind, q * sizeof(ldpc_dec_job), 0, (uint32_t)(e - q), threads, lds, false});
+      TbPlan::DecLaunch dl{kind, q * sizeof(ldpc_dec_job), 0, (uint32_t)(e - q), threads, lds, false};
+      dl.zc = v[q].zc;
+      for (size_t i = q; i < e; i++)
+        if (v[i].zc != dl.zc)
+          dl.zc = 0;
+      dec.push_back(dl);
       q = e;
     }
     const size_t bytes = align_up((size_t)n * sizeof(ldpc_dec_job), 16);
@@ -114,7 +120,7 @@ int dec_jobs_enqueue(const nrLDPC_hip_dec_job_t *jobs, uint32_t n, int32_t *n_it
   for (const TbPlan::DecLaunch &dl : pl.dec) {
     da.jobs = reinterpret_cast<const ldpc_dec_job *>(pl.jobs_d.p + dl.jobs_off);
     if (dl.kind == 0)
-      HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s));
+      HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s, dl.zc));
     else
       HIP_TRY(ldpc_launch_dec_generic_jobs(da, dl.threads, dl.lds, dl.n, s));
   }

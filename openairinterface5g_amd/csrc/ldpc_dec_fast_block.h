@@ -135,11 +135,17 @@ __device__ __forceinline__ void ldpc_fast_item_zero_messages(const ldpc_fast_lds
 }
 
 /* Returns the pass count as LDPCdecoder reports it (numMaxIter + 2: the transport block was given up, decoder.c:556-559). */
-template <class IO>
+/* ZC != 0: the instantiation for ONE lifting size (the launcher guarantees code->Z == ZC).  With the row strides known at compile
+ * time the k-th message of an item is `ds_read_b32 v, base offset:k * (ZC + 4)` -- the general build forms base + k * rstride with
+ * a VALU add per edge for the read / first store and another one for the wrap-around store (rstride sits in an SGPR), two of the
+ * check-node body's ~26 VALU instructions per edge, and keeps those addresses in a register each. */
+template <class IO, int ZC = 0>
 __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t code, const IO &io)
 {
-  const int Z = code->Z, zq = code->f_zq, rstride = code->f_rstride, astride = code->f_astride;
-  const uint32_t zq_magic = code->f_zq_magic;
+  const int Z = ZC ? ZC : code->Z, zq = ZC ? ZC / 4 : code->f_zq, rstride = ZC ? ZC + 4 : code->f_rstride,
+            astride = ZC ? 2 * ZC : code->f_astride;
+  const uint32_t zq_magic = ZC ? (uint32_t)((0x100000000ULL + (unsigned long long)(ZC ? ZC / 4 : 1) - 1) / (unsigned long long)(ZC ? ZC / 4 : 1))
+                               : code->f_zq_magic;
   const uint32_t z_magic = 0xffffffffu / (uint32_t)Z + 1u; /* ceil(2^32 / Z) for Z not a power of two, exact enough
                                                                for b < 2^16 either way (checked on the host) */
   ldpc_fast_lds L;

@@ -9,6 +9,7 @@
  * aligned LLR rows; other cases are served by the generic kernel.
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ldpc_kernels.h"
 #include "ldpc_dec_fast_block.h"
 #include "ldpc_dec_fast_mblock.h"
@@ -70,7 +71,10 @@ template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io 
  * waves per CU: the throughput shapes put k workgroups of w <= 16 / k waves on a CU and count on all 16 wave slots
  * (a variant compiled for <= 768 threads may take 129+ VGPRs and silently drop the CU to 12 waves: measured 180 -> 262 us
  * on the 1664-segment slot). */
-template <bool JOBS, bool CRC = false, bool TRACE = false>
+#ifndef LDPC_FAST_ZC
+#define LDPC_FAST_ZC 384 /* the lifting size that has instantiations of its own (0: none; A/B: tools/build_variant.sh) */
+#endif
+template <bool JOBS, bool CRC = false, bool TRACE = false, int ZC = 0>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args
     tr[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* HW_REG_XCC_ID */
     tr[2] = wall_clock64();
   }
-  const int n_iter = ldpc_dec_fast_block(fsm, code, io);
+  const int n_iter = ldpc_dec_fast_block<ldpc_batch_io<JOBS, CRC, TRACE>, ZC>(fsm, code, io);
   if (threadIdx.x == 0)
     a.n_iter[job ? (uint32_t)job->iter_idx : blockIdx.x] = n_iter;
   if (TRACE) {
@@ -187,11 +191,23 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
   ldpc_dec_fast_mblock<SUB, true, CRC>(fsm, code, io, (int)gr->n_valid);
 }
 
+bool ldpc_fast_zc_enabled(int zc)
+{
+  static const bool on = !(getenv("NRLDPC_HIP_ZC") && atoi(getenv("NRLDPC_HIP_ZC")) == 0);
+  return LDPC_FAST_ZC != 0 && on && zc == LDPC_FAST_ZC;
+}
+
 hipError_t ldpc_fast_kernel_init(void)
 {
   const void *k[] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
+#if LDPC_FAST_ZC
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, false, LDPC_FAST_ZC>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true, false, LDPC_FAST_ZC>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true, false, LDPC_FAST_ZC>),
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, false, false, LDPC_FAST_ZC>),
+#endif
                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, true>),
@@ -211,6 +227,16 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     return hipSuccess;
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
+#if LDPC_FAST_ZC
+  /* the lifting size with instantiations of its own (one block per workgroup: f_rstride = Z + 4, f_astride = 2 Z) */
+  if (ldpc_fast_zc_enabled(hc.Z) && hc.f_mb == 1 && hc.f_rstride == LDPC_FAST_ZC + 4 && hc.f_astride == 2 * LDPC_FAST_ZC && !a.trace) {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
+    return hipGetLastError();
+  }
+#endif
   if (a.use_crc) /* CRC stop: the instantiation without the parity of the hard decisions */
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else if (a.trace)
@@ -278,10 +304,19 @@ hipError_t ldpc_launch_dec_fast_pull(const ldpc_dec_args &a, const ldpc_code_des
   return hipGetLastError();
 }
 
-hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream)
+hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream, int zc)
 {
   if (n_blocks == 0)
     return hipSuccess;
+#if LDPC_FAST_ZC
+  if (ldpc_fast_zc_enabled(zc)) {
+    if (a.use_crc)
+      hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, true, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+    else
+      hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, false, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
+    return hipGetLastError();
+  }
+#endif
   if (a.use_crc) /* (the chain's launches) */
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   else

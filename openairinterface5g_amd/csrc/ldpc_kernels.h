@@ -91,7 +91,9 @@ hipError_t ldpc_launch_dec_generic_trace(const ldpc_dec_args &a, const ldpc_code
                                          uint32_t trace_stride, uint32_t n_trace, hipStream_t stream);
 /* job-array launches: explicit workgroup size and dynamic LDS (maxima over the jobs) */
 hipError_t ldpc_launch_dec_generic_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
-hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
+/* zc: the lifting size EVERY job of the launch has (one block per workgroup: f_rstride = Z + 4), or 0 */
+hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream, int zc = 0);
+bool ldpc_fast_zc_enabled(int zc); /* is there an instantiation for this lifting size (and is it switched on: NRLDPC_HIP_ZC) */
 hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
 /* fast decoder (Zc % 4 == 0, 4-byte aligned LLR rows, hc.f_ok): one workgroup per code block */
 hipError_t ldpc_fast_kernel_init(void);

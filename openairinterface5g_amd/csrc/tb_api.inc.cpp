@@ -58,7 +58,9 @@ struct TbPlan {
    * its jobs, so a batch that mixes code sizes is cut into launches by how many workgroups of a job's shape a CU holds
    * (1, 2, 4, 8, 16+): a Zc = 8 segment does not occupy the LDS of a Zc = 384 one.  kind 0: fast kernel, 1: generic
    * kernel, 2 / 3: several small segments per workgroup (f_sub = 1 / 4; grp_off = their ldpc_dec_mgroup array) */
-  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; bool all_fused = false; int max_llr = 0; uint32_t lrow = 0; bool mute = false; };
+  struct DecLaunch { int kind; size_t jobs_off, grp_off; uint32_t n; int threads, lds; bool fused; bool all_fused = false; int max_llr = 0; uint32_t lrow = 0; bool mute = false;
+                     int zc = 0; /* kind 0: the lifting size every job of the launch has (one block per workgroup), else 0 -- selects the
+                                    kernels' instantiation for that size (ldpc_dec_fast_block.h ZC) */ };
   std::vector<DecLaunch> dec;
   std::vector<int32_t> llr_len; /* decode: the llrLen every TB leaves with */
   /* decode: segments / transport blocks that go through the separate de-matching, reassembly and verdict kernels (the others
@@ -779,7 +781,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     std::vector<uint8_t> key_tb((const uint8_t *)tbs, (const uint8_t *)tbs + (size_t)ntb * sizeof(nrLDPC_hip_tb_t));
     std::vector<tb_rx_tb_job> tbj(ntb);
     std::vector<tb_rx_seg_job> sj, sj_legacy;
-    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; int num_llr; };
+    struct ShapedJob { ldpc_dec_job dj; int kind, threads, lds; double cost; int num_llr; int zc; };
     std::vector<ShapedJob> single; /* segments that get a workgroup of their own */
     Arena ar;
     TbExtent ex;
@@ -801,9 +803,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       const ldpc_code_desc_t &hc = ce->host, &shape = lat_shape ? ce->host_lat : ce->host;
       const double cost = (double)hc.num_llr * dj.num_max_iter;
       if (hc.f_ok)
-        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, std::max(shape.f_lds_total, (int)fused_lds), cost, hc.num_llr});
+        single.push_back(ShapedJob{dj, 0, shape.f_n_threads, std::max(shape.f_lds_total, (int)fused_lds), cost, hc.num_llr,
+                                   (shape.f_mb == 1 && shape.f_rstride == shape.Z + 4 && shape.f_astride == 2 * shape.Z) ? shape.Z : 0});
       else
-        single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost, hc.num_llr});
+        single.push_back(ShapedJob{dj, 1, hc.n_threads, hc.lds_total, cost, hc.num_llr, 0});
     };
     struct MultiCand { const CodeEntry *ce; ldpc_dec_job dj; };
     std::vector<MultiCand> cands;
@@ -1036,7 +1039,10 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       }
       TbPlan::DecLaunch dl{kind, q * sizeof(ldpc_dec_job), 0, (uint32_t)(e - q), threads, lds, false};
       dl.all_fused = true;
+      dl.zc = single[q].zc;
       for (size_t i = q; i < e; i++) {
+        if (single[i].zc != dl.zc)
+          dl.zc = 0;
         dl.fused |= single[i].dj.seg_idx >= 0;
         dl.all_fused &= single[i].dj.seg_idx >= 0;
         dl.mute |= (single[i].dj.crc_type & LDPC_JOB_MUTE_CHECK) != 0;
@@ -1083,6 +1089,8 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
         dec[k - 1].fused |= dec[k].fused;
         dec[k - 1].all_fused &= dec[k].all_fused;
         dec[k - 1].mute |= dec[k].mute;
+        if (dec[k - 1].zc != dec[k].zc)
+          dec[k - 1].zc = 0;
         dec[k - 1].max_llr = std::max(dec[k - 1].max_llr, dec[k].max_llr);
         dec.erase(dec.begin() + (long)k);
       } else {
@@ -1283,6 +1291,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
   fx.stagger_ticks = fx.stagger_cus = fx.stagger_slots = 0;
   fx.lrow_off = 0;
   fx.mute = 0;
+  fx.zc = 0;
   fx.prio_pro = 0;
   fx.trace = nullptr;
   /* A call that mixes code sizes has several decoder launches (TbPlan::DecLaunch); nothing orders them among themselves --
@@ -1337,6 +1346,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
       }
       fx.lrow_off = dl.lrow;
       fx.mute = dl.mute ? 1u : 0u;
+      fx.zc = (uint32_t)dl.zc;
       {
         static const int prio_env = [] { const char *e = getenv("NRLDPC_HIP_TB_PRIO"); return e ? atoi(e) : 1; }();
         fx.prio_pro = per_cu >= 2 ? (uint32_t)prio_env : 0u;
@@ -1356,7 +1366,7 @@ int tb_rx_enqueue(const nrLDPC_hip_tb_batch_t *b, uint32_t tb0, uint32_t ntb, bo
     }
     else if (dl.kind == 0)
     {
-      HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s));
+      HIP_TRY(ldpc_launch_dec_fast_jobs(da, dl.threads, dl.lds, dl.n, s, dl.zc));
       TB_DEBUG_STAGE("decoder launch (fast kernel, job array)");
     }
     else if (dl.kind == 1)

@@ -57,6 +57,8 @@ struct tb_rx_fused_args {
   uint32_t lrow_off;
   /* != 0: some job of the launch carries LDPC_JOB_MUTE_CHECK (retransmissions): the instantiation that looks for mute items */
   uint32_t mute;
+  /* != 0: every job of the launch has this lifting size, one block per workgroup (ldpc_dec_fast_block.h ZC) */
+  uint32_t zc;
   /* bit 0: the prologue runs at raised issue priority, bit 1: the epilogue too (NRLDPC_HIP_TB_PRIO, default 1: level with 3) */
   uint32_t prio_pro;
   /* diagnostics (NRLDPC_HIP_TB_TRACE=<file>): per workgroup {HW_ID, XCC_ID, wall clock at start, after the prologue, after

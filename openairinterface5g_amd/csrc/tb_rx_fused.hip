@@ -219,7 +219,10 @@ template <bool LROW, bool MUTE = false> struct tb_rx_fused_io {
   }
 };
 
-template <bool LROW, bool MUTE>
+#ifndef LDPC_FAST_ZC
+#define LDPC_FAST_ZC 384 /* as in ldpc_decoder_fast.hip */
+#endif
+template <bool LROW, bool MUTE, int ZC = 0>
 __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a, const tb_rx_fused_args x)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
   }
   if (tr && threadIdx.x == 0)
     tr[3] = wall_clock64();
-  const int n_iter = ldpc_dec_fast_block(fsm, code, io);
+  const int n_iter = ldpc_dec_fast_block<tb_rx_fused_io<LROW, MUTE>, ZC>(fsm, code, io);
   if (tr && threadIdx.x == 0) {
     tr[5] = wall_clock64();
     tr[6] = (unsigned long long)n_iter;
@@ -289,8 +292,12 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
 
 hipError_t tb_rx_fused_init(void)
 {
-  const void *k[4] = {reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false>),
-                      reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true>)};
+  const void *k[] = {reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false>),
+#if LDPC_FAST_ZC
+                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false, LDPC_FAST_ZC>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false, LDPC_FAST_ZC>),
+                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true, LDPC_FAST_ZC>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true, LDPC_FAST_ZC>),
+#endif
+                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true>)};
   for (const void *f : k) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
@@ -305,6 +312,19 @@ hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x,
     return hipSuccess;
   if (!a.jobs || !x.segs || !x.tbs)
     return hipErrorInvalidValue;
+#if LDPC_FAST_ZC
+  if (ldpc_fast_zc_enabled((int)x.zc)) { /* every job has this lifting size: the instantiations with compile-time row strides */
+    if (x.lrow_off && x.mute)
+      hipLaunchKernelGGL((tb_rx_fused_kernel<true, true, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    else if (x.lrow_off)
+      hipLaunchKernelGGL((tb_rx_fused_kernel<true, false, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    else if (x.mute)
+      hipLaunchKernelGGL((tb_rx_fused_kernel<false, true, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    else
+      hipLaunchKernelGGL((tb_rx_fused_kernel<false, false, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    return hipGetLastError();
+  }
+#endif
   if (x.lrow_off && x.mute)
     hipLaunchKernelGGL((tb_rx_fused_kernel<true, true>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
   else if (x.lrow_off)
