@@ -152,8 +152,9 @@ def decode_sharded(BG: int, Z: int, R: int, llr_root, n_blocks: int, numMaxIter:
 SLOT_MODEL = {
     # UL-SCH chain, device resident, one call: microseconds by code segments in the call (BG1 Zc = 384, 64QAM, 3 passes to the
     # CRC, first transmissions on the cut graph): profiles/r06/tb_latency.txt (1 .. 64 transport blocks of 26 segments) -- the
-    # slot of 64 blocks back to back: 121 us (final run of round 6; 132 before the front step's straight-line scatter)
-    "chain_us_by_segments": [(26, 39.1), (52, 39.4), (104, 40.1), (208, 42.0), (416, 51.4), (832, 84.4), (1664, 121.0)],
+    # slot of 64 blocks back to back: 118 us (final run of round 6, Zc = 384 instantiations; 132 before the front step's
+    # straight-line scatter)
+    "chain_us_by_segments": [(26, 37.7), (52, 38.0), (104, 38.8), (208, 40.8), (416, 50.4), (832, 82.6), (1664, 118.0)],
     # one batch_isend_irecv group through RCCL (Python, group launch, stream ordering): from the loopback slot of
     # profiles/r05/bench_dist1.json -- 1409 us per slot with 4 virtual ranks = 12 groups + 10 chain calls of 423 us in total +
     # 47.5 MB of device-local copies (~45 us): (1409 - 423 - 45) / 12
