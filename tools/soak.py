@@ -26,7 +26,7 @@ t0 = time.time()
 batches = blocks = 0
 while time.time() - t0 < budget:
     BG = int(rng.integers(1, 3))
-    Z = int(rng.choice(O.LIFT_SIZES))
+    Z = int(os.environ["SOAK_Z"]) if os.environ.get("SOAK_Z") else int(rng.choice(O.LIFT_SIZES))   # (SOAK_Z=384: the lifting size with kernels of its own)
     R = int(rng.choice(ALL_RATES[BG]))
     n = int(rng.choice([1, 2, 3, 17, 64, 255, 256, 257, 300, 513]))
     it = int(rng.choice([0, 1, 2, 3, 5, 8, 12]))
