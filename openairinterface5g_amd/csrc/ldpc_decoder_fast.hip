@@ -71,9 +71,6 @@ template <bool JOBS, bool CRC = false, bool TRACE = false> struct ldpc_batch_io 
  * waves per CU: the throughput shapes put k workgroups of w <= 16 / k waves on a CU and count on all 16 wave slots
  * (a variant compiled for <= 768 threads may take 129+ VGPRs and silently drop the CU to 12 waves: measured 180 -> 262 us
  * on the 1664-segment slot). */
-#ifndef LDPC_FAST_ZC
-#define LDPC_FAST_ZC 384 /* the lifting size that has instantiations of its own (0: none; A/B: tools/build_variant.sh) */
-#endif
 template <bool JOBS, bool CRC = false, bool TRACE = false, int ZC = 0>
 __global__ void __launch_bounds__(1024) ldpc_dec_fast_kernel(const ldpc_dec_args a)
 {
@@ -194,7 +191,32 @@ __global__ void __launch_bounds__(1024) ldpc_dec_fast_multi_jobs_kernel(const ld
 bool ldpc_fast_zc_enabled(int zc)
 {
   static const bool on = !(getenv("NRLDPC_HIP_ZC") && atoi(getenv("NRLDPC_HIP_ZC")) == 0);
-  return LDPC_FAST_ZC != 0 && on && zc == LDPC_FAST_ZC;
+  if (!on)
+    return false;
+  switch (zc) {
+#define X(z) case z:
+    LDPC_FAST_ZC_LIST(X)
+#undef X
+      return LDPC_FAST_ZC != 0;
+    default:
+      return false;
+  }
+}
+
+/* launch of the instantiation for lifting size zc (false: there is none) */
+template <bool JOBS, bool CRC>
+static bool ldpc_launch_zc(int zc, uint32_t n_blocks, int n_threads, int lds_bytes, hipStream_t stream, const ldpc_dec_args &a)
+{
+  switch (zc) {
+#define X(z) \
+  case z: \
+    hipLaunchKernelGGL((ldpc_dec_fast_kernel<JOBS, CRC, false, z>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a); \
+    return true;
+    LDPC_FAST_ZC_LIST(X)
+#undef X
+    default:
+      return false;
+  }
 }
 
 hipError_t ldpc_fast_kernel_init(void)
@@ -202,12 +224,13 @@ hipError_t ldpc_fast_kernel_init(void)
   const void *k[] = {reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true>), reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true>),
-#if LDPC_FAST_ZC
-                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, false, LDPC_FAST_ZC>),
-                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true, false, LDPC_FAST_ZC>),
-                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true, false, LDPC_FAST_ZC>),
-                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, false, false, LDPC_FAST_ZC>),
-#endif
+#define X(z) \
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, false, false, z>), \
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<false, true, false, z>), \
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, true, false, z>), \
+                     reinterpret_cast<const void *>(ldpc_dec_fast_kernel<true, false, false, z>),
+                     LDPC_FAST_ZC_LIST(X)
+#undef X
                      reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<false>), reinterpret_cast<const void *>(ldpc_dec_fast_pull_kernel<true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<1, true>),
                      reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, false>), reinterpret_cast<const void *>(ldpc_dec_fast_multi_kernel<4, true>),
@@ -227,16 +250,12 @@ hipError_t ldpc_launch_dec_fast(const ldpc_dec_args &a, const ldpc_code_desc_t &
     return hipSuccess;
   if (a.jobs)
     return ldpc_launch_dec_fast_jobs(a, hc.f_n_threads, hc.f_lds_total, n_blocks, stream);
-#if LDPC_FAST_ZC
-  /* the lifting size with instantiations of its own (one block per workgroup: f_rstride = Z + 4, f_astride = 2 Z) */
-  if (ldpc_fast_zc_enabled(hc.Z) && hc.f_mb == 1 && hc.f_rstride == LDPC_FAST_ZC + 4 && hc.f_astride == 2 * LDPC_FAST_ZC && !a.trace) {
-    if (a.use_crc)
-      hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
-    else
-      hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, false, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
-    return hipGetLastError();
+  /* a lifting size with instantiations of its own (one block per workgroup: f_rstride = Z + 4, f_astride = 2 Z) */
+  if (ldpc_fast_zc_enabled(hc.Z) && hc.f_mb == 1 && hc.f_rstride == hc.Z + 4 && hc.f_astride == 2 * hc.Z && !a.trace) {
+    if (a.use_crc ? ldpc_launch_zc<false, true>(hc.Z, n_blocks, hc.f_n_threads, hc.f_lds_total, stream, a)
+                  : ldpc_launch_zc<false, false>(hc.Z, n_blocks, hc.f_n_threads, hc.f_lds_total, stream, a))
+      return hipGetLastError();
   }
-#endif
   if (a.use_crc) /* CRC stop: the instantiation without the parity of the hard decisions */
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<false, true>), dim3(n_blocks), dim3(hc.f_n_threads), hc.f_lds_total, stream, a);
   else if (a.trace)
@@ -308,15 +327,11 @@ hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int 
 {
   if (n_blocks == 0)
     return hipSuccess;
-#if LDPC_FAST_ZC
   if (ldpc_fast_zc_enabled(zc)) {
-    if (a.use_crc)
-      hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, true, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
-    else
-      hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, false, false, LDPC_FAST_ZC>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
-    return hipGetLastError();
+    if (a.use_crc ? ldpc_launch_zc<true, true>(zc, n_blocks, n_threads, lds_bytes, stream, a)
+                  : ldpc_launch_zc<true, false>(zc, n_blocks, n_threads, lds_bytes, stream, a))
+      return hipGetLastError();
   }
-#endif
   if (a.use_crc) /* (the chain's launches) */
     hipLaunchKernelGGL((ldpc_dec_fast_kernel<true, true>), dim3(n_blocks), dim3(n_threads), lds_bytes, stream, a);
   else

@@ -94,6 +94,17 @@ hipError_t ldpc_launch_dec_generic_jobs(const ldpc_dec_args &a, int n_threads, i
 /* zc: the lifting size EVERY job of the launch has (one block per workgroup: f_rstride = Z + 4), or 0 */
 hipError_t ldpc_launch_dec_fast_jobs(const ldpc_dec_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream, int zc = 0);
 bool ldpc_fast_zc_enabled(int zc); /* is there an instantiation for this lifting size (and is it switched on: NRLDPC_HIP_ZC) */
+/* The lifting sizes whose one-block-per-workgroup decoder kernels (batch, job array, fused segment kernel) have instantiations of
+ * their own with compile-time row strides (ldpc_dec_fast_block.h ZC): the sizes the segments of large transport blocks come in
+ * (K' between 0.6 and 1.0 of the largest code block) and BASELINE configs[2]'s 208.  LDPC_FAST_ZC=0 (build switch): none. */
+#ifndef LDPC_FAST_ZC
+#define LDPC_FAST_ZC 1
+#endif
+#if LDPC_FAST_ZC
+#define LDPC_FAST_ZC_LIST(X) X(384) X(352) X(320) X(288) X(256) X(208)
+#else
+#define LDPC_FAST_ZC_LIST(X)
+#endif
 hipError_t ldpc_launch_enc_jobs(const ldpc_enc_args &a, int n_threads, int lds_bytes, uint32_t n_blocks, hipStream_t stream);
 /* fast decoder (Zc % 4 == 0, 4-byte aligned LLR rows, hc.f_ok): one workgroup per code block */
 hipError_t ldpc_fast_kernel_init(void);

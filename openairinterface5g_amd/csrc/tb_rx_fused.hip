@@ -219,9 +219,6 @@ template <bool LROW, bool MUTE = false> struct tb_rx_fused_io {
   }
 };
 
-#ifndef LDPC_FAST_ZC
-#define LDPC_FAST_ZC 384 /* as in ldpc_decoder_fast.hip */
-#endif
 template <bool LROW, bool MUTE, int ZC = 0>
 __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a, const tb_rx_fused_args x)
 {
@@ -293,10 +290,11 @@ __global__ void __launch_bounds__(1024) tb_rx_fused_kernel(const ldpc_dec_args a
 hipError_t tb_rx_fused_init(void)
 {
   const void *k[] = {reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false>),
-#if LDPC_FAST_ZC
-                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false, LDPC_FAST_ZC>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false, LDPC_FAST_ZC>),
-                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true, LDPC_FAST_ZC>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true, LDPC_FAST_ZC>),
-#endif
+#define X(z) \
+                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, false, z>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, false, z>), \
+                     reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true, z>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true, z>),
+                     LDPC_FAST_ZC_LIST(X)
+#undef X
                      reinterpret_cast<const void *>(tb_rx_fused_kernel<false, true>), reinterpret_cast<const void *>(tb_rx_fused_kernel<true, true>)};
   for (const void *f : k) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -312,19 +310,25 @@ hipError_t tb_launch_rx_fused(const ldpc_dec_args &a, const tb_rx_fused_args &x,
     return hipSuccess;
   if (!a.jobs || !x.segs || !x.tbs)
     return hipErrorInvalidValue;
-#if LDPC_FAST_ZC
   if (ldpc_fast_zc_enabled((int)x.zc)) { /* every job has this lifting size: the instantiations with compile-time row strides */
-    if (x.lrow_off && x.mute)
-      hipLaunchKernelGGL((tb_rx_fused_kernel<true, true, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
-    else if (x.lrow_off)
-      hipLaunchKernelGGL((tb_rx_fused_kernel<true, false, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
-    else if (x.mute)
-      hipLaunchKernelGGL((tb_rx_fused_kernel<false, true, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
-    else
-      hipLaunchKernelGGL((tb_rx_fused_kernel<false, false, LDPC_FAST_ZC>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
+    switch ((int)x.zc) {
+#define X(z) \
+  case z: \
+    if (x.lrow_off && x.mute) \
+      hipLaunchKernelGGL((tb_rx_fused_kernel<true, true, z>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x); \
+    else if (x.lrow_off) \
+      hipLaunchKernelGGL((tb_rx_fused_kernel<true, false, z>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x); \
+    else if (x.mute) \
+      hipLaunchKernelGGL((tb_rx_fused_kernel<false, true, z>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x); \
+    else \
+      hipLaunchKernelGGL((tb_rx_fused_kernel<false, false, z>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x); \
     return hipGetLastError();
+      LDPC_FAST_ZC_LIST(X)
+#undef X
+      default:
+        break;
+    }
   }
-#endif
   if (x.lrow_off && x.mute)
     hipLaunchKernelGGL((tb_rx_fused_kernel<true, true>), dim3(n_jobs), dim3(n_threads), lds_bytes, s, a, x);
   else if (x.lrow_off)

@@ -650,10 +650,11 @@ def test_server_generations_wait_modes_and_a_server_that_cannot_be_relaunched(hi
 
 
 def test_general_kernels_for_the_lifting_size_that_has_instantiations_of_its_own():
-    """Zc = 384 runs on instantiations with compile-time row strides (ldpc_dec_fast_block.h ZC: batch, job-array and fused
-    segment kernels); NRLDPC_HIP_ZC=0 sends it through the general kernels every other lifting size uses.  The tests that
-    decode Zc = 384 -- code-block batches, mixed job arrays, both transport-block chains, the fused segment kernel against the
-    four-launch path -- are run again that way: same oracle, same fixtures."""
+    """Zc = 384 (and 352, 320, 288, 256, 208: ldpc_kernels.h LDPC_FAST_ZC_LIST) runs on instantiations with compile-time row
+    strides (ldpc_dec_fast_block.h ZC: batch, job-array and fused segment kernels); NRLDPC_HIP_ZC=0 sends it through the general
+    kernels every other lifting size uses.  The tests that decode those sizes -- every lifting size and rate, code-block batches,
+    mixed job arrays, both transport-block chains, the fused segment kernel against the four-launch path -- are run again that
+    way: same oracle, same fixtures."""
     import os
     import subprocess
     import sys
@@ -664,7 +665,7 @@ def test_general_kernels_for_the_lifting_size_that_has_instantiations_of_its_own
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_decoder.py"),
                         os.path.join(root, "tests", "test_gpu_tb_chain.py"), os.path.join(root, "tests", "test_gpu_tb_resident.py"),
                         "-m", "gpu", "-q", "-x", "-k",
-                        "iteration_caps or crc_early_stop or reference_hybrid or several_workgroup_rounds or ulsch_decode_matches "
+                        "every_lifting_size or iteration_caps or crc_early_stop or reference_hybrid or several_workgroup_rounds or ulsch_decode_matches "
                         "or harq_rounds or fused_segment_kernel_against or first_transmissions_on_the_cut_graph"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -15,6 +15,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 CODES = [(1, 384, 13), (1, 384, 23), (1, 384, 89), (1, 192, 13), (2, 208, 15), (2, 384, 15), (2, 384, 23)]
+if os.environ.get("AB_CODES"):          # e.g. AB_CODES=1:352:13,1:320:23
+    CODES = [tuple(int(x) for x in c.split(":")) for c in os.environ["AB_CODES"].split(",")]
 
 
 def child():
