@@ -339,8 +339,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
             (void)ldpc_fast_cn2_dispatch<true>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
           else
             ma = ldpc_fast_cn2_dispatch<false>(deg, L, e0a, ja, e0b, jb, Z, rstride, mb);
-          const uint32_t maska = valida >= 4 ? 0xfu : (valida <= 0 ? 0u : ((1u << valida) - 1u));
-          const uint32_t maskb = validb >= 4 ? 0xfu : (validb <= 0 ? 0u : ((1u << validb) - 1u));
+          const uint32_t maska = ldpc_fast_valid_lanes(valida), maskb = ldpc_fast_valid_lanes(validb);
           if constexpr (IO::syndrome)
             syn |= (ma & maska) | (mb & maskb);
           else
@@ -379,7 +378,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
 #endif
             m = ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
         }
-        const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+        const uint32_t mask = ldpc_fast_valid_lanes(valid);
         if constexpr (IO::syndrome)
           syn |= m & mask;
         else
@@ -514,8 +513,7 @@ __device__ __forceinline__ int ldpc_dec_fast_block(uint8_t *fsm, ldpc_code_ptr_t
         const int e0 = (int)(rowrec & 0x1ffu), deg = (int)((rowrec >> 9) & 0x1fu), ext = (int)((rowrec >> 14) & 1u);
         const int valid = (int)(rowrec >> 16) - 4 * j;
         const uint32_t m = ldpc_fast_pc(L, deg, ext, e0, j, rstride);
-        const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-        esyn |= m & mask;
+        esyn |= m & ldpc_fast_valid_lanes(valid);
       }
       if (__any(esyn != 0) && lane == 0)
         flags[6] = 1;

@@ -113,9 +113,31 @@ LDPC_HD uint32_t ldpc_window_al(const uint8_t *base, uint32_t a, uint32_t sh)
 /* unaligned 4-byte window starting at LDS address `off` */
 LDPC_HD uint32_t ldpc_window(const uint8_t *base, uint32_t off) { return ldpc_window_al(base, off & ~3u, off); }
 
+/* What a check-node item reports: byte i of the result = 1 when the parity of the previous pass' hard decisions over lane
+ * t + i's neighbours is odd (the check is not satisfied), 0 otherwise.  parw = xor of the biased APP windows of the row's core
+ * columns (bit 7 of a byte = "not negative"); extl / exth = the degree-1 bit's biased sums llr' + r' in 16-bit halves (bit 8 of a
+ * half = "not negative", cnProc.h:940) -- the bytes that hold those bits are gathered with one v_perm.  Parity of the hard
+ * decisions = parity of the not-negative ones ^ (D & 1).  (Until round 6 the bodies returned a 4-bit mask: seven shifts and ors
+ * to pack it and ten for the degree-1 bit, per item -- 4.6 % of the headline kernel's VALU instructions.) */
+LDPC_HD uint32_t ldpc_fast_odd_lanes(uint32_t parw, bool ext, uint32_t extl, uint32_t exth, int D)
+{
+  uint32_t np = parw >> 7;
+  if (ext)
+    np ^= ldpc_perm(exth, extl, 0x07050301u);
+  if (D & 1)
+    np = ~np;
+  return np & 0x01010101u;
+}
+/* byte i = 1 for the first `valid` of an item's four lanes (valid <= 0: none, >= 4: all): the lanes whose check counts */
+LDPC_HD uint32_t ldpc_fast_valid_lanes(int valid)
+{
+  const uint32_t v = (uint32_t)(valid < 4 ? valid : 4);
+  return valid <= 0 ? 0u : (0x01010101u & (0xffffffffu >> ((32u - 8u * v) & 31u)));
+}
+
 /* One check-node item: lifted row with first edge e0, lanes t..t+3 (t = 4j).  D = row degree; EXT = the
  * last edge goes to the row's degree-1 column; KEEP = keep the per-edge magnitudes in registers between
- * the two sweeps (false for the degree-19 rows, which would spill).  Returns a 4-bit mask: bit i set =
+ * the two sweeps (false for the degree-19 rows, which would spill).  Returns ldpc_fast_odd_lanes(): byte i = 1 when
  * the parity of the previous pass' hard decisions of lane t+i is odd.
  *
  * Arithmetic, per 16-bit half (two lanes per register, a' = app + 128, r' = r + 128 as stored):
@@ -241,14 +263,7 @@ LDPC_HD uint32_t ldpc_fast_cn(const ldpc_fast_lds &L, int e0, int j, int Z, int 
   }
   /* per lane: number of "not negative" neighbours mod 2, from bit 7 of the biased APP bytes and bit 8 of
    * the extension sums; parity of the hard decisions = that ^ (D & 1) */
-  uint32_t np = (parw >> 7) & 0x01010101u;
-  if (EXT) {
-    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
-    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
-  }
-  if (D & 1)
-    np ^= 0x01010101u;
-  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+  return ldpc_fast_odd_lanes(parw, EXT, extl, exth, D);
 }
 
 /* The same check-node item with the "minimum of the OTHER edges" taken from prefixes and suffixes instead of through the
@@ -325,14 +340,7 @@ LDPC_HD uint32_t ldpc_fast_cn_ps(const ldpc_fast_lds &L, int e0, int j, int Z, i
       sh = last ? ldpc_pminu(a0h, a1h) : ldpc_pmin3_keys(sh, a0h, a1h);
     }
   }
-  uint32_t np = (parw >> 7) & 0x01010101u;
-  if (EXT) {
-    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
-    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
-  }
-  if (D & 1)
-    np ^= 0x01010101u;
-  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+  return ldpc_fast_odd_lanes(parw, EXT, extl, exth, D);
 }
 
 /* TWO items of one degree group per thread (a double task, ldpc_graph.h f_cn_task), walked edge by edge TOGETHER: the same
@@ -421,14 +429,7 @@ LDPC_HD uint32_t ldpc_fast_cn_ps2(const ldpc_fast_lds &L, int e0a, int ja, int e
   uint32_t out[N];
 #pragma unroll
   for (int n = 0; n < N; n++) {
-    uint32_t np = (parw[n] >> 7) & 0x01010101u;
-    if (EXT) {
-      np ^= ((extl[n] >> 8) & 1u) | (((extl[n] >> 24) & 1u) << 8);
-      np ^= (((exth[n] >> 8) & 1u) << 16) | (((exth[n] >> 24) & 1u) << 24);
-    }
-    if (D & 1)
-      np ^= 0x01010101u;
-    out[n] = (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+    out[n] = ldpc_fast_odd_lanes(parw[n], EXT, extl[n], exth[n], D);
   }
   mask_b = out[1];
   return out[0];
@@ -521,13 +522,11 @@ __device__ __forceinline__ uint32_t ldpc_fast_cn19_pair(const ldpc_fast_lds &L, 
       sh = ldpc_pmin3_keys(sh, ldpc_as_v2u(m_hi[2 * i]), ldpc_as_v2u(m_hi[2 * i + 1]));
     }
   }
-  uint32_t np = (parw >> 7) & 0x01010101u;
-  np ^= 0x01010101u; /* D = 19 is odd */
-  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+  return ldpc_fast_odd_lanes(parw, false, 0u, 0u, 19);
 }
 #endif
 
-/* Parity check of one check-node item on its own (no message update): the same 4-bit mask ldpc_fast_cn returns, from the
+/* Parity check of one check-node item on its own (no message update): the same byte flags ldpc_fast_cn returns, from the
  * APP signs of the row's core columns and, for an extension row, sat8(llr + r) of its degree-1 column (cnProc.h:940).
  * Used by the latency path (ldpc_dec_fast_block.h, eager check): ~6 VALU per edge instead of a check-node update. */
 LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, int j, int rstride)
@@ -553,20 +552,16 @@ LDPC_HD uint32_t ldpc_fast_pc(const ldpc_fast_lds &L, int D, int ext, int e0, in
   }
   for (; k < ncore_edges; k++)
     parw ^= ldpc_window(L.base, L.etbl[e0 + k] + (uint32_t)t);
-  uint32_t np = (parw >> 7) & 0x01010101u;
+  uint32_t extl = 0, exth = 0;
   if (ext) {
     const uint32_t info = L.etbl[e0 + D - 1];
     const uint32_t lw = L.ext_global ? (*reinterpret_cast<const uint32_t *>(L.gllr + info + (uint32_t)t) ^ 0x80808080u)
                                      : ldpc_lds_ld32(L.base, info + (uint32_t)t);
     const uint32_t rw = *reinterpret_cast<const uint32_t *>(L.r + (e0 + D - 1) * rstride + t);
-    const uint32_t extl = ldpc_perm(0x80808080u, lw, 0x05010400u) + ldpc_perm(0u, rw, 0x0c010c00u);
-    const uint32_t exth = ldpc_perm(0x80808080u, lw, 0x05030402u) + ldpc_perm(0u, rw, 0x0c030c02u);
-    np ^= ((extl >> 8) & 1u) | (((extl >> 24) & 1u) << 8);
-    np ^= (((exth >> 8) & 1u) << 16) | (((exth >> 24) & 1u) << 24);
+    extl = ldpc_perm(0x80808080u, lw, 0x05010400u) + ldpc_perm(0u, rw, 0x0c010c00u);
+    exth = ldpc_perm(0x80808080u, lw, 0x05030402u) + ldpc_perm(0u, rw, 0x0c030c02u);
   }
-  if (D & 1)
-    np ^= 0x01010101u;
-  return (np & 1u) | ((np >> 7) & 2u) | ((np >> 14) & 4u) | ((np >> 21) & 8u);
+  return ldpc_fast_odd_lanes(parw, ext != 0, extl, exth, D);
 }
 
 #ifndef LDPC_F_MODE_D19

@@ -257,15 +257,14 @@ __device__ __forceinline__ void ldpc_dec_fast_mblock(uint8_t *fsm, ldpc_code_ptr
           const uint32_t rowrec = rowtbl[srow0 + rig];
           const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
           const uint32_t m = ldpc_fast_cn_dispatch(deg, ext, L, e0, j, Z, rstride, b * pr, b * pa);
-          const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-          const uint32_t bad = m & mask;
+          const uint32_t bad = m & ldpc_fast_valid_lanes(valid); /* byte i = lane 4j + i */
           if (SUB == 1) {
             if (bad)
               flags[LDPC_MB_SYN(p & 1) + b] = 1; /* (same value from every lane that writes) */
           } else { /* bit i = lane 4j + i of the virtual code = lane j of block i */
 #pragma unroll
             for (int q = 0; q < SUB; q++)
-              if (bad & (1u << q))
+              if (bad & (1u << (8 * q)))
                 flags[LDPC_MB_SYN(p & 1) + SUB * b + q] = 1;
           }
         }

@@ -289,8 +289,7 @@ extern "C" int ldpc_emul_decode_fast(int BG, int Z, int R, int numMaxIter, int o
           const int e0 = (int)(rowrec & 0x1ffu), valid = (int)(rowrec >> 16) - 4 * j;
           const uint32_t m = p == 1 ? ldpc_fast_cn_dispatch<true>(deg, ext, L, e0, j, Z, rstride)
                                     : ldpc_fast_cn_dispatch<false>(deg, ext, L, e0, j, Z, rstride);
-          const uint32_t mask = valid >= 4 ? 0xfu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-          syn |= m & mask;
+          syn |= m & ldpc_fast_valid_lanes(valid);
         }
         if (syn)
           flags[p & 1] = 1;
