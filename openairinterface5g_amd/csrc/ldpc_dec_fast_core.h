@@ -128,12 +128,11 @@ LDPC_HD uint32_t ldpc_fast_odd_lanes(uint32_t parw, bool ext, uint32_t extl, uin
     np = ~np;
   return np & 0x01010101u;
 }
-/* byte i = 1 for the first `valid` of an item's four lanes (valid <= 0: none, >= 4: all): the lanes whose check counts */
-LDPC_HD uint32_t ldpc_fast_valid_lanes(int valid)
-{
-  const uint32_t v = (uint32_t)(valid < 4 ? valid : 4);
-  return valid <= 0 ? 0u : (0x01010101u & (0xffffffffu >> ((32u - 8u * v) & 31u)));
-}
+/* The lanes of an item whose check counts, as byte flags: valid = pc_lo[row] - 4 j = how many of the item's four lanes lie in
+ * front of the row's first excluded lane (ldpc_graph.c [F6]).  With Zc % 4 == 0 -- the only codes these bodies serve -- pc_lo is a
+ * multiple of 4 (a class of nr rows drops lanes nr Z - 32 .. nr Z - 1; ldpc_build_code_desc checks it), so an item counts whole
+ * or not at all: a compare and a select, where the general mask cost seven instructions per item. */
+LDPC_HD uint32_t ldpc_fast_valid_lanes(int valid) { return valid > 0 ? 0x01010101u : 0u; }
 
 /* One check-node item: lifted row with first edge e0, lanes t..t+3 (t = 4j).  D = row degree; EXT = the
  * last edge goes to the row's degree-1 column; KEEP = keep the per-edge magnitudes in registers between

@@ -317,6 +317,11 @@ static void build_fast_section(ldpc_code_desc_t *d, int shape, int mb, int pair1
     d->f_bn_rec[k][2] = d->f_bn_task[task][2];
     d->f_bn_rec[k][3] = d->f_bn_ticket[k][1];
   }
+  /* the kernels treat an item's four lanes as checked or excluded TOGETHER (ldpc_fast_valid_lanes): the first excluded lane of a
+   * row is a multiple of 4 -- nr Z - 32 - k Z with Z % 4 == 0, resp. 4 times the real code's for the interleaved form */
+  for (int r = 0; r < d->nrows; r++)
+    if (d->pc_lo[r] & 3)
+      return; /* (never for NR's lifting sizes; f_ok stays 0: the generic kernel serves the code) */
   d->f_ok = 1;
 }
 
